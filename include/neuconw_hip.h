@@ -1,0 +1,122 @@
+/* neuconw_hip.h -- C ABI of libneuconw_hip.so: the MI355X (gfx950) native hot path of
+ * NeuralRecon-W's volume renderer.
+ *
+ * The reference (zju3dv/NeuralRecon-W) has no FFI: its hot path is Python calling torch ops.  The
+ * entry points below are the functions a maintainer would bind (ctypes -- see INTEGRATION.md) to
+ * replace, one for one, the torch-op bodies of
+ *     rendering/renderer.py  (sample_pdf :15-48, up_sample :257-341, cat_z_vals :343-363,
+ *                             render_core_outside :157-228, render_core :570-783,
+ *                             get_near_far_* :380-456)
+ *     models/neuconw.py      (SDFNetwork :183-296, RenderingNetwork :59-170, NeuconW :299-376)
+ *     models/nerf.py         (NeRF :86-183)
+ *     tools/prepare_data/generate_voxel.py  (get_near_far :311-439, kaolin raytrace)
+ *
+ * Conventions: all pointers are DEVICE pointers unless a parameter is documented as a host
+ * struct; `stream` is a hipStream_t passed as void*; every function is asynchronous on `stream`
+ * and returns 0 on success or a hipError_t / negative NCW_E_* code.  No torch types appear here.
+ * prec: 0 = exact-fp32 MFMA (v_mfma_f32_32x32x2_f32; parity mode), 1 = bf16 MFMA with f32
+ * accumulation (v_mfma_f32_32x32x16_bf16; throughput mode).
+ */
+#ifndef NEUCONW_HIP_H
+#define NEUCONW_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NCW_PREC_F32 0
+#define NCW_PREC_BF16 1
+#define NCW_MAX_LAYERS 12
+#define NCW_MAX_SEGS 4
+
+#define NCW_E_BADARG (-1)
+#define NCW_E_UNSUPPORTED (-2)
+
+/* library / device info; returns the ABI version (bumped on any signature change) */
+int ncw_abi_version(void);
+/* writes "gfx950" style arch name of device 0 into buf; returns CU count (0 if no device) */
+int ncw_device_info(char* buf, int buflen);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight packing (replaces nn.utils.weight_norm's reparametrisation + the implicit cuBLAS
+ * operand layout; models/neuconw.py:104-105,256-257).  One descriptor = one nn.Linear (or a row
+ * range of it) scattered into one zero-padded matrix in MFMA fragment order.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct NcwSeg {
+    int32_t col0;   /* first source column of the segment                       */
+    int32_t ncols;  /* number of source columns                                 */
+    int32_t dcol0;  /* destination (padded, logical) input-feature index        */
+    int32_t _pad;
+} NcwSeg;
+
+typedef struct NcwPackDesc {
+    const float* src;    /* weight (or weight_v) [rows_total, ld] row-major     */
+    const float* g;      /* weight_g [rows_total] or NULL (plain Linear)        */
+    const float* bias;   /* bias [rows_total] or NULL                            */
+    void* dst_w;         /* packed matrix (pre-zeroed once; padding never rewritten) */
+    float* dst_b;        /* packed bias [rb_out*32] (C-layout order) or NULL    */
+    int32_t ld;          /* source leading dimension = in_features               */
+    int32_t row0, nrows; /* source row range packed by this descriptor           */
+    int32_t drow0;       /* destination (padded, logical) output-feature index   */
+    int32_t rb_out, rb_in; /* destination block dims (x32) in its own orientation */
+    int32_t transpose;   /* 1: destination is the transpose (out<->in swapped)    */
+    int32_t prec;        /* element type of dst_w                                 */
+    float scale;         /* e.g. 1/sqrt(2) folded into the skip layer             */
+    int32_t nseg;
+    NcwSeg seg[NCW_MAX_SEGS];
+} NcwPackDesc;
+
+/* descs: device array of n descriptors; row_prefix: device int32[n+1] exclusive prefix sum of
+ * nrows (grid = row_prefix[n] blocks, passed as total_rows). */
+int ncw_pack_weights(const NcwPackDesc* descs, const int32_t* row_prefix, int n, int total_rows,
+                     void* stream);
+
+/* Reverse of ncw_pack_weights for gradients: reads the dense padded gradient matrices produced by
+ * ncw_wgrad and writes d(weight_g), d(weight_v) / d(weight), d(bias) of the original parameters
+ * (weight-norm backward: g_bar = sum(Wbar * v/|v|), v_bar = g/|v| (Wbar - g_bar v/|v|)). */
+typedef struct NcwUnpackDesc {
+    const float* dw;     /* dense padded gradient [rb_out*32, ldw], forward orientation */
+    const float* db;     /* dense padded bias gradient [rb_out*32] or NULL               */
+    const float* src;    /* weight_v / weight                                            */
+    const float* g;      /* weight_g or NULL                                             */
+    float* d_src;        /* out: grad of weight_v / weight  [rows_total, ld]             */
+    float* d_g;          /* out: grad of weight_g or NULL                                */
+    float* d_bias;       /* out: grad of bias or NULL                                    */
+    int32_t ld, ldw;
+    int32_t row0, nrows, drow0;
+    float scale;
+    int32_t accumulate;  /* 1: add into d_* (torch .grad accumulation), 0: overwrite     */
+    int32_t nseg;
+    NcwSeg seg[NCW_MAX_SEGS];
+} NcwUnpackDesc;
+int ncw_unpack_grads(const NcwUnpackDesc* descs, const int32_t* row_prefix, int n, int total_rows,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SDF network (models/neuconw.py:183-296).  HOST struct of device pointers to packed weights.
+ * Layer l in [0, n_layers): w[l] = packed [32*rb (or 32 for the sdf row) x K_l]; the skip layer's
+ * K is [rb blocks of h | 2 blocks of gamma]; wt[l] = packed transpose (adjoint / backward).
+ * The last Linear is split: w[n_layers-1] = sdf row (1 out-block), w_feat = feature rows.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct NcwSdfNet {
+    const void* w[NCW_MAX_LAYERS];
+    const float* b[NCW_MAX_LAYERS];
+    const void* wt[NCW_MAX_LAYERS];
+    const void* w_feat;   /* last layer rows 1..W   [32*rb x 32*rb]        */
+    const float* b_feat;
+    const void* wt_feat;  /* its transpose                                  */
+    int32_t n_layers;     /* number of Linear layers (9 for the 8x256 net)  */
+    int32_t skip_layer;   /* index l whose input is cat([h, gamma])/sqrt2, or -1 */
+    int32_t rb;           /* hidden width / 32 (2, 8 or 16)                 */
+    int32_t multires;     /* 6                                              */
+    float scale;          /* SDFNetwork.scale                               */
+} NcwSdfNet;
+
+/* a-2 `sdf(x)` (neuconw.py:281-282): x [n,3] f32 -> sdf [n] f32.  No grad, last layer 1 row. */
+int ncw_sdf_infer(const NcwSdfNet* net, int prec, const float* x, int64_t n, float* sdf, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,9 @@
+"""neuralrecon-w_amd: MI355X (gfx950) native volume-rendering hot path of NeuralRecon-W.
+
+Drop-in for the reference's `models.neuconw.NeuconW`, `models.nerf.NeRF` and
+`rendering.renderer.NeuconWRenderer`.  All compute is in
+libneuconw_hip.so (hand-written HIP, C ABI in include/neuconw_hip.h).
+"""
+from . import lib  # noqa: F401
+from .lib import PREC_BF16, PREC_F32, NeuconwHipError  # noqa: F401
+from .neuconw import SDFNetwork  # noqa: F401

@@ -1,0 +1,61 @@
+"""Builds libneuconw_hip.so (gfx950) in-tree from csrc/*.hip with hipcc.  No torch involved.
+
+    python -m neuralrecon_w_amd.build        (or __graft_entry__.build())
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "build")
+LIB = os.path.join(HERE, "libneuconw_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "neuconw_hip.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src[:-4] + ".o")
+    srcp = os.path.join(CSRC, src)
+    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), _deps_mtime()):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", srcp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    return obj, True
+
+
+def build(verbose=True, force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    srcs = _sources()
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(_compile, srcs))
+    objs = [o for o, _ in res]
+    rebuilt = any(c for _, c in res)
+    if rebuilt or not os.path.exists(LIB) or force:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("[neuralrecon_w_amd.build] %s (%d objects, %s)" % (LIB, len(objs), "rebuilt" if rebuilt else "up to date"))
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

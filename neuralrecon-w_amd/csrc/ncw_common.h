@@ -1,0 +1,324 @@
+// Shared device-side vocabulary of the NeuralRecon-W hot-path kernels for gfx950 (CDNA4).
+//
+// Point-per-lane ("swapped operand") MLP formulation
+// --------------------------------------------------
+// Every MLP on the path (SDF net models/neuconw.py:183-296, colour net :59-170, background NeRF
+// models/nerf.py:86-183) is evaluated as   Y^T = W . X^T   with the WEIGHTS as the MFMA A operand
+// and the per-point activations as the B operand.  One wave owns 32 points; lane l holds point
+// p = l & 31 and "half" h = l >> 5.  A feature vector of 32*RB (zero-padded) features lives in
+// the 32x32 MFMA C/D register layout
+//
+//      v[rb][r]  on lane (p,h)   ==   feature  32*rb + (r&3) + 8*(r>>2) + 4*h   of point p
+//
+// which is exactly what a 32x32 MFMA writes for output rows = features, columns = points.  The
+// next layer consumes the same registers as its B operand without any cross-lane traffic, because
+// the K order of the weights is permuted to match when they are packed (ncw_pack.hip):
+//
+//   bf16  v_mfma_f32_32x32x16_bf16 : k-step s = 2*rb + t takes registers 8t..8t+7 of block rb;
+//         logical k = 8h + e  <->  feature 16 s + 4 h + (e&3) + 8 (e>>2)
+//   f32   v_mfma_f32_32x32x2_f32   : k-step (rb, r) takes register r of block rb;
+//         logical k = h      <->  feature 32 rb + (r&3) + 8 (r>>2) + 4 h
+//
+// Activations never leave registers between layers; weights stream from L2 in fragment order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NCW_PREC_F32 0
+#define NCW_PREC_BF16 1
+
+#define NCW_DEV __device__ __forceinline__
+
+// feature index (within a 32-block) of C-layout register r on half h
+NCW_DEV constexpr int ncw_feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+NCW_DEV int ncw_lane() { return threadIdx.x & 63; }
+
+// ---------------------------------------------------------------------------------------------
+// Precision traits
+// ---------------------------------------------------------------------------------------------
+struct PrecF32 {
+    static constexpr int id = NCW_PREC_F32;
+    typedef float welem;   // packed weight element
+    typedef float selem;   // stash element
+    // elements of packed weights per (in-block rb_in) per out-block: 16 k-steps * 64 lanes * 1
+    static constexpr int W_PER_INBLOCK = 16 * 64;
+};
+struct PrecBF16 {
+    static constexpr int id = NCW_PREC_BF16;
+    typedef __bf16 welem;
+    typedef __bf16 selem;
+    // 2 k-steps * 64 lanes * 8
+    static constexpr int W_PER_INBLOCK = 2 * 64 * 8;
+};
+// Both precisions: a packed [32*RB_OUT x 32*RB_IN] matrix holds RB_IN*RB_OUT*1024 elements, laid
+// out [in-block][k-sub-step][out-block][lane][e].  (f32: 16 sub-steps x 1 elem, bf16: 2 x 8.)
+
+// A feature vector in C layout, f32 (the MFMA accumulator itself).
+template <int RB>
+struct CVec {
+    f32x16 v[RB];
+};
+
+template <int RB>
+NCW_DEV void cvec_zero(CVec<RB>& c) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c.v[i][r] = 0.f;
+}
+
+// B-operand form of a feature vector.
+template <class P, int RB>
+struct Act;
+template <int RB>
+struct Act<PrecF32, RB> {
+    f32x16 v[RB];
+};
+template <int RB>
+struct Act<PrecBF16, RB> {
+    bf16x8 f[2 * RB];
+};
+
+template <int RB>
+NCW_DEV void to_act(Act<PrecF32, RB>& a, const CVec<RB>& c) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) a.v[i] = c.v[i];
+}
+template <int RB>
+NCW_DEV void to_act(Act<PrecBF16, RB>& a, const CVec<RB>& c) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a.f[2 * i + t][e] = (__bf16)c.v[i][8 * t + e];
+}
+
+// ---------------------------------------------------------------------------------------------
+// acc[RB_OUT] += Wp . in   over the first KB_USED in-blocks of `in` (compile-time), weights in
+// packed fragment order at `wp` (see ncw_pack.hip).  K_REAL = number of real (non-padding) input
+// features: k-steps that only touch padding are skipped at compile time.
+// ---------------------------------------------------------------------------------------------
+template <int RB_IN, int RB_OUT, int K_REAL>
+NCW_DEV void mma(CVec<RB_OUT>& acc, const Act<PrecF32, RB_IN>& in, const float* __restrict__ wp, int lane) {
+#pragma unroll
+    for (int rb = 0; rb < RB_IN; ++rb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (32 * rb + ncw_feat_of(r, 0) >= K_REAL) continue;  // h=1 feature is even larger
+            const float* w = wp + ((size_t)(rb * 16 + r) * RB_OUT) * 64 + lane;
+#pragma unroll
+            for (int ro = 0; ro < RB_OUT; ++ro) {
+                float a = w[ro * 64];
+                acc.v[ro] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, in.v[rb][r], acc.v[ro], 0, 0, 0);
+            }
+        }
+    }
+}
+template <int RB_IN, int RB_OUT, int K_REAL>
+NCW_DEV void mma(CVec<RB_OUT>& acc, const Act<PrecBF16, RB_IN>& in, const __bf16* __restrict__ wp, int lane) {
+#pragma unroll
+    for (int s = 0; s < 2 * RB_IN; ++s) {
+        if (16 * s >= K_REAL) continue;
+        const bf16x8* w = reinterpret_cast<const bf16x8*>(wp) + ((size_t)s * RB_OUT) * 64 + lane;
+#pragma unroll
+        for (int ro = 0; ro < RB_OUT; ++ro) {
+            bf16x8 a = w[ro * 64];
+            acc.v[ro] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, in.f[s], acc.v[ro], 0, 0, 0);
+        }
+    }
+}
+
+// number of packed weight elements of a [32*RB_OUT x 32*RB_IN] matrix
+NCW_DEV constexpr size_t ncw_packed_elems(int rb_out, int rb_in) { return (size_t)rb_out * rb_in * 1024; }
+
+// ---------------------------------------------------------------------------------------------
+// bias: packed per out-block as [rb][h][16] f32 (C-layout order)  -> acc initialisation
+// ---------------------------------------------------------------------------------------------
+template <int RB>
+NCW_DEV void load_bias(CVec<RB>& acc, const float* __restrict__ bp, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const f32x4* b4 = reinterpret_cast<const f32x4*>(bp + (rb * 2 + h) * 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 t = b4[g];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc.v[rb][4 * g + c] = t[c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Activation functions
+// ---------------------------------------------------------------------------------------------
+// Softplus(beta=100) with torch's threshold 20 (models/neuconw.py:261) and its derivative
+// sigma(100 z) (exactly 1 above the threshold).  FAST selects hardware exp2/log2.
+template <bool FAST>
+NCW_DEV void softplus100(float z, float& y, float& s) {
+    const float bz = 100.f * z;
+    if (FAST) {
+        float e = __builtin_amdgcn_exp2f(bz * 1.4426950408889634f);  // exp(bz)
+        float l = __builtin_amdgcn_logf(1.f + e) * (0.6931471805599453f * 0.01f);
+        float sg = e * __builtin_amdgcn_rcpf(1.f + e);
+        y = bz > 20.f ? z : l;
+        s = bz > 20.f ? 1.f : sg;
+    } else {
+        float e = expf(bz);
+        float l = log1pf(e) * 0.01f;
+        float sg = 1.f / (1.f + expf(-bz));
+        y = bz > 20.f ? z : l;
+        s = bz > 20.f ? 1.f : sg;
+    }
+}
+
+template <bool FAST>
+NCW_DEV float sigmoidf_(float x) {
+    if (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-x * 1.4426950408889634f));
+    return 1.f / (1.f + expf(-x));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Frequency encoding (models/neuconw.py:7-55) of a d-dimensional point straight into C layout.
+// feature f:  f < D -> x[f];  else j = f - D, k = j / (2D), rem = j % (2D):
+//             rem < D -> sin(2^k x[rem]),  else cos(2^k x[rem-D]).   f >= D*(2L+1) -> 0.
+// ---------------------------------------------------------------------------------------------
+template <int D, int L, bool FAST>
+NCW_DEV float freq_feature(const float (&x)[D], int f) {
+    if (f < D) {
+        float v = x[0];
+#pragma unroll
+        for (int i = 1; i < D; ++i) v = (f == i) ? x[i] : v;
+        return v;
+    }
+    if (f >= D * (2 * L + 1)) return 0.f;
+    const int j = f - D;
+    const int k = j / (2 * D);
+    const int rem = j - k * 2 * D;
+    const bool is_cos = rem >= D;
+    const int comp = is_cos ? rem - D : rem;
+    float v = x[0];
+#pragma unroll
+    for (int i = 1; i < D; ++i) v = (comp == i) ? x[i] : v;
+    const float arg = v * (float)(1 << k);
+    if (FAST) {
+        const float rev = arg * 0.15915494309189535f;  // revolutions
+        return is_cos ? __builtin_amdgcn_cosf(rev) : __builtin_amdgcn_sinf(rev);
+    }
+    return is_cos ? cosf(arg) : sinf(arg);
+}
+
+// derivative of feature f w.r.t. its source component; comp returned through `comp`
+template <int D, int L, bool FAST>
+NCW_DEV float freq_feature_deriv(const float (&x)[D], int f, int& comp) {
+    if (f < D) {
+        comp = f;
+        return 1.f;
+    }
+    if (f >= D * (2 * L + 1)) {
+        comp = 0;
+        return 0.f;
+    }
+    const int j = f - D;
+    const int k = j / (2 * D);
+    const int rem = j - k * 2 * D;
+    const bool is_cos = rem >= D;
+    comp = is_cos ? rem - D : rem;
+    float v = x[0];
+#pragma unroll
+    for (int i = 1; i < D; ++i) v = (comp == i) ? x[i] : v;
+    const float fr = (float)(1 << k);
+    const float arg = v * fr;
+    if (FAST) {
+        const float rev = arg * 0.15915494309189535f;
+        return is_cos ? -fr * __builtin_amdgcn_sinf(rev) : fr * __builtin_amdgcn_cosf(rev);
+    }
+    return is_cos ? -fr * sinf(arg) : fr * cosf(arg);
+}
+
+template <int RB, int D, int L, bool FAST>
+NCW_DEV void freq_encode(CVec<RB>& out, const float (&x)[D], int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f0 = 32 * rb + ncw_feat_of(r, 0);
+            if (f0 >= D * (2 * L + 1)) {
+                out.v[rb][r] = 0.f;
+            } else {
+                out.v[rb][r] = freq_feature<D, L, FAST>(x, f0 + 4 * h);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stash: fragment-native layout  [tile32][rb][g = r>>2][lane][4]  (each lane stores 4 consecutive
+// features of its point: 8 B bf16 / 16 B f32 per lane, 512 B / 1 KiB per wave-instruction).
+// ---------------------------------------------------------------------------------------------
+template <int RB>
+NCW_DEV void stash_store(float* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
+    f32x4* p = reinterpret_cast<f32x4*>(base) + (tile * RB * 4) * 64 + lane;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 t;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) t[c4] = c.v[rb][4 * g + c4];
+            p[(rb * 4 + g) * 64] = t;
+        }
+}
+template <int RB>
+NCW_DEV void stash_store(__bf16* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
+    bf16x4* p = reinterpret_cast<bf16x4*>(base) + (tile * RB * 4) * 64 + lane;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 t;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) t[c4] = (__bf16)c.v[rb][4 * g + c4];
+            p[(rb * 4 + g) * 64] = t;
+        }
+}
+template <int RB>
+NCW_DEV void stash_load(CVec<RB>& c, const float* __restrict__ base, size_t tile, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(base) + (tile * RB * 4) * 64 + lane;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 t = p[(rb * 4 + g) * 64];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) c.v[rb][4 * g + c4] = t[c4];
+        }
+}
+template <int RB>
+NCW_DEV void stash_load(CVec<RB>& c, const __bf16* __restrict__ base, size_t tile, int lane) {
+    const bf16x4* p = reinterpret_cast<const bf16x4*>(base) + (tile * RB * 4) * 64 + lane;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 t = p[(rb * 4 + g) * 64];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) c.v[rb][4 * g + c4] = (float)t[c4];
+        }
+}
+
+// sum of a per-lane value over the two halves of a point (lanes p and p+32)
+NCW_DEV float half_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+#define NCW_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return (int)e__;             \
+    } while (0)

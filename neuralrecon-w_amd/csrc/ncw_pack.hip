@@ -1,0 +1,160 @@
+// Weight packing / gradient unpacking kernels (descriptor-table driven: ONE launch per step packs
+// every Linear of every network).  See ncw_common.h for the fragment order.
+//
+// Replaces: nn.utils.weight_norm reparametrisation W = g v/|v| (models/neuconw.py:104-105,
+// 256-257) and its autograd backward; the skip-layer 1/sqrt(2) (neuconw.py:273) is folded in here.
+#include "../../include/neuconw_hip.h"
+#include "ncw_common.h"
+
+// element index inside a packed [32*rb_out x 32*rb_in] matrix of logical entry (o, k)
+__device__ __forceinline__ size_t packed_index(int o, int k, int rb_out, int prec) {
+    const int ro = o >> 5, i = o & 31;
+    const int rb = k >> 5, kk = k & 31;
+    const int h = (kk >> 2) & 1;
+    const int r = (kk & 3) + 4 * (kk >> 3);
+    const int lane = i + 32 * h;
+    if (prec == NCW_PREC_F32) return ((size_t)(rb * 16 + r) * rb_out + ro) * 64 + lane;
+    const int t = r >> 3, e = r & 7;
+    return (((size_t)(2 * rb + t) * rb_out + ro) * 64 + lane) * 8 + e;
+}
+
+__device__ __forceinline__ int find_desc(const int32_t* __restrict__ prefix, int n, int row) {
+    int lo = 0, hi = n;  // prefix[lo] <= row < prefix[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= row) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const NcwPackDesc* __restrict__ descs,
+                                                   const int32_t* __restrict__ prefix, int n) {
+    __shared__ float sm[4];
+    const int d = find_desc(prefix, n, blockIdx.x);
+    const NcwPackDesc D = descs[d];
+    const int i = blockIdx.x - prefix[d];  // row within the descriptor
+    const int row = D.row0 + i;
+    const float* srow = D.src + (size_t)row * D.ld;
+    float coef = D.scale;
+    if (D.g != nullptr) {
+        float ss = 0.f;
+        for (int c = threadIdx.x; c < D.ld; c += 256) ss += srow[c] * srow[c];
+        ss = block_sum_256(ss, sm);
+        coef *= D.g[row] / sqrtf(ss);
+    }
+    const int o_log = D.drow0 + i;
+    for (int s = 0; s < D.nseg; ++s) {
+        const NcwSeg sg = D.seg[s];
+        for (int c = threadIdx.x; c < sg.ncols; c += 256) {
+            const float v = srow[sg.col0 + c] * coef;
+            const int k_log = sg.dcol0 + c;
+            const int o = D.transpose ? k_log : o_log;
+            const int k = D.transpose ? o_log : k_log;
+            const size_t idx = packed_index(o, k, D.rb_out, D.prec);
+            if (D.prec == NCW_PREC_F32) reinterpret_cast<float*>(D.dst_w)[idx] = v;
+            else reinterpret_cast<__bf16*>(D.dst_w)[idx] = (__bf16)v;
+        }
+    }
+    if (D.dst_b != nullptr && D.bias != nullptr && threadIdx.x == 0) {
+        // packed bias [rb][h][16]: feature f = 32 rb + (r&3) + 8 (r>>2) + 4 h
+        const int f = o_log, rb = f >> 5, kk = f & 31;
+        const int h = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+        D.dst_b[(rb * 2 + h) * 16 + r] = D.bias[row];
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_kernel(const NcwUnpackDesc* __restrict__ descs,
+                                                     const int32_t* __restrict__ prefix, int n) {
+    __shared__ float sm[4];
+    const int d = find_desc(prefix, n, blockIdx.x);
+    const NcwUnpackDesc D = descs[d];
+    const int i = blockIdx.x - prefix[d];
+    const int row = D.row0 + i;
+    const float* drow = D.dw + (size_t)(D.drow0 + i) * D.ldw;
+    const float* vrow = D.src + (size_t)row * D.ld;
+    float* out = D.d_src + (size_t)row * D.ld;
+    if (D.g == nullptr) {
+        for (int s = 0; s < D.nseg; ++s) {
+            const NcwSeg sg = D.seg[s];
+            for (int c = threadIdx.x; c < sg.ncols; c += 256) {
+                const float gval = drow[sg.dcol0 + c] * D.scale;
+                float* o = out + sg.col0 + c;
+                *o = D.accumulate ? *o + gval : gval;
+            }
+        }
+    } else {
+        // weight-norm backward on the full source row (segments cover the whole row)
+        float ss = 0.f, dot = 0.f;
+        for (int s = 0; s < D.nseg; ++s) {
+            const NcwSeg sg = D.seg[s];
+            for (int c = threadIdx.x; c < sg.ncols; c += 256) {
+                const float v = vrow[sg.col0 + c];
+                ss += v * v;
+                dot += drow[sg.dcol0 + c] * D.scale * v;
+            }
+        }
+        ss = block_sum_256(ss, sm);
+        dot = block_sum_256(dot, sm);
+        const float inv = 1.f / sqrtf(ss);
+        const float gbar = dot * inv;  // sum(Wbar * v_hat)
+        const float gg = D.g[row];
+        for (int s = 0; s < D.nseg; ++s) {
+            const NcwSeg sg = D.seg[s];
+            for (int c = threadIdx.x; c < sg.ncols; c += 256) {
+                const float v = vrow[sg.col0 + c];
+                const float gval = gg * inv * (drow[sg.dcol0 + c] * D.scale - gbar * v * inv);
+                float* o = out + sg.col0 + c;
+                *o = D.accumulate ? *o + gval : gval;
+            }
+        }
+        if (threadIdx.x == 0 && D.d_g != nullptr) D.d_g[row] = D.accumulate ? D.d_g[row] + gbar : gbar;
+    }
+    if (threadIdx.x == 0 && D.d_bias != nullptr && D.db != nullptr) {
+        const float b = D.db[D.drow0 + i];
+        D.d_bias[row] = D.accumulate ? D.d_bias[row] + b : b;
+    }
+}
+
+extern "C" int ncw_pack_weights(const NcwPackDesc* descs, const int32_t* row_prefix, int n, int total_rows,
+                                void* stream) {
+    if (n <= 0 || total_rows <= 0) return 0;
+    hipLaunchKernelGGL(pack_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, descs, row_prefix, n);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ncw_unpack_grads(const NcwUnpackDesc* descs, const int32_t* row_prefix, int n, int total_rows,
+                                void* stream) {
+    if (n <= 0 || total_rows <= 0) return 0;
+    hipLaunchKernelGGL(unpack_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, descs, row_prefix, n);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ncw_abi_version(void) { return 1; }
+
+extern "C" int ncw_device_info(char* buf, int buflen) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
+        if (buf && buflen > 0) buf[0] = 0;
+        return 0;
+    }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
+    if (buf && buflen > 0) {
+        int i = 0;
+        for (; i < buflen - 1 && p.gcnArchName[i]; ++i) buf[i] = p.gcnArchName[i];
+        buf[i] = 0;
+    }
+    return p.multiProcessorCount;
+}

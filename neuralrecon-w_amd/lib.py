@@ -1,0 +1,107 @@
+"""ctypes binding of libneuconw_hip.so (C ABI declared in include/neuconw_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this
+module raises -- a GPU box must run the hand-written HIP kernels or nothing.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libneuconw_hip.so")
+
+PREC_F32 = 0
+PREC_BF16 = 1
+MAX_LAYERS = 12
+MAX_SEGS = 4
+ABI_VERSION = 1
+
+
+class NcwSeg(C.Structure):
+    _fields_ = [("col0", C.c_int32), ("ncols", C.c_int32), ("dcol0", C.c_int32), ("_pad", C.c_int32)]
+
+
+class NcwPackDesc(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("g", C.c_void_p), ("bias", C.c_void_p), ("dst_w", C.c_void_p), ("dst_b", C.c_void_p),
+        ("ld", C.c_int32), ("row0", C.c_int32), ("nrows", C.c_int32), ("drow0", C.c_int32),
+        ("rb_out", C.c_int32), ("rb_in", C.c_int32), ("transpose", C.c_int32), ("prec", C.c_int32),
+        ("scale", C.c_float), ("nseg", C.c_int32), ("seg", NcwSeg * MAX_SEGS),
+    ]
+
+
+class NcwUnpackDesc(C.Structure):
+    _fields_ = [
+        ("dw", C.c_void_p), ("db", C.c_void_p), ("src", C.c_void_p), ("g", C.c_void_p),
+        ("d_src", C.c_void_p), ("d_g", C.c_void_p), ("d_bias", C.c_void_p),
+        ("ld", C.c_int32), ("ldw", C.c_int32), ("row0", C.c_int32), ("nrows", C.c_int32), ("drow0", C.c_int32),
+        ("scale", C.c_float), ("accumulate", C.c_int32), ("nseg", C.c_int32), ("seg", NcwSeg * MAX_SEGS),
+    ]
+
+
+class NcwSdfNet(C.Structure):
+    _fields_ = [
+        ("w", C.c_void_p * MAX_LAYERS), ("b", C.c_void_p * MAX_LAYERS), ("wt", C.c_void_p * MAX_LAYERS),
+        ("w_feat", C.c_void_p), ("b_feat", C.c_void_p), ("wt_feat", C.c_void_p),
+        ("n_layers", C.c_int32), ("skip_layer", C.c_int32), ("rb", C.c_int32), ("multires", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
+_PROTOS = {
+    "ncw_abi_version": (C.c_int, []),
+    "ncw_device_info": (C.c_int, [C.c_char_p, C.c_int]),
+    "ncw_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ncw_unpack_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ncw_sdf_infer": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+class NeuconwHipError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names every entry point include/neuconw_hip.h declares (used by the CPU-side ABI test)."""
+    return sorted(_PROTOS)
+
+
+def get_lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise NeuconwHipError(
+            "libneuconw_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU / PyTorch fallback for the hot path." % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.ncw_abi_version()
+    if v != ABI_VERSION:
+        raise NeuconwHipError("libneuconw_hip.so ABI %d != binding ABI %d: rebuild" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise NeuconwHipError("%s failed with code %d" % (what, code))
+
+
+def stream_ptr(device=None):
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_contiguous(), "non-contiguous tensor handed to the C ABI"
+    return C.c_void_p(t.data_ptr())

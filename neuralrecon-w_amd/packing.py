@@ -1,0 +1,183 @@
+"""Host-side weight-pack plans: which nn.Linear goes where in the MFMA-fragment-ordered arenas.
+
+A plan owns (per precision)
+  * a zero-initialised weight arena (packed matrices, bf16 or f32) and a bias arena (f32),
+  * the device descriptor table consumed by ncw_pack_weights (ONE launch re-packs every layer),
+  * a dense f32 gradient arena + descriptor table for ncw_unpack_grads (weight-norm backward).
+Padding is written once (zeros) and never touched again.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _elem_size(prec):
+    return 4 if prec == L.PREC_F32 else 2
+
+
+class PackPlan:
+    def __init__(self, device, prec):
+        self.device = torch.device(device)
+        self.prec = prec
+        self._w_bytes = 0
+        self._b_elems = 0
+        self._g_elems = 0
+        self._mats = []   # (byte offset, rb_out, rb_in)
+        self._biases = []  # (elem offset, rb_out)
+        self._dense = []  # (elem offset, rows, cols)  dense gradient matrices (forward orientation)
+        self._dense_b = []
+        self._pack = []   # python-side descriptor dicts
+        self._unpack = []
+        self.finalized = False
+
+    # ---- allocation -----------------------------------------------------------------------
+    def new_matrix(self, rb_out, rb_in):
+        off = self._w_bytes
+        self._w_bytes += rb_out * rb_in * 1024 * _elem_size(self.prec)
+        self._w_bytes = (self._w_bytes + 255) & ~255
+        self._mats.append((off, rb_out, rb_in))
+        return len(self._mats) - 1
+
+    def new_bias(self, rb_out):
+        off = self._b_elems
+        self._b_elems += rb_out * 32
+        self._biases.append((off, rb_out))
+        return len(self._biases) - 1
+
+    def new_dense_grad(self, rb_out, rb_in, with_bias=True):
+        off = self._g_elems
+        self._g_elems += rb_out * 32 * rb_in * 32
+        self._dense.append((off, rb_out * 32, rb_in * 32))
+        boff = None
+        if with_bias:
+            boff = self._g_elems
+            self._g_elems += rb_out * 32
+        self._dense_b.append(boff)
+        return len(self._dense) - 1
+
+    # ---- descriptors ----------------------------------------------------------------------
+    def add_pack(self, weight, g, bias, mat, bias_slot, segs, row0=0, nrows=None, drow0=0, transpose=False,
+                 scale=1.0):
+        """weight: [out, in] parameter (weight_v when g is given).  segs: [(col0, ncols, dcol0)]."""
+        nrows = weight.shape[0] - row0 if nrows is None else nrows
+        self._pack.append(dict(weight=weight, g=g, bias=bias, mat=mat, bias_slot=bias_slot, segs=list(segs),
+                               row0=row0, nrows=nrows, drow0=drow0, transpose=bool(transpose), scale=float(scale)))
+
+    def add_unpack(self, weight, g, bias, dense, segs, row0=0, nrows=None, drow0=0, scale=1.0):
+        nrows = weight.shape[0] - row0 if nrows is None else nrows
+        self._unpack.append(dict(weight=weight, g=g, bias=bias, dense=dense, segs=list(segs), row0=row0,
+                                 nrows=nrows, drow0=drow0, scale=float(scale)))
+
+    # ---- finalisation ---------------------------------------------------------------------
+    def finalize(self):
+        dev = self.device
+        self.w_arena = torch.zeros(max(self._w_bytes, 256), dtype=torch.uint8, device=dev)
+        self.b_arena = torch.zeros(max(self._b_elems, 32), dtype=torch.float32, device=dev)
+        self.g_arena = torch.zeros(max(self._g_elems, 32), dtype=torch.float32, device=dev)
+        self.finalized = True
+        self._build_pack_table()
+        return self
+
+    def mat_ptr(self, mat):
+        return self.w_arena.data_ptr() + self._mats[mat][0]
+
+    def bias_ptr(self, slot):
+        return self.b_arena.data_ptr() + 4 * self._biases[slot][0]
+
+    def dense_ptr(self, d):
+        return self.g_arena.data_ptr() + 4 * self._dense[d][0]
+
+    def dense_bias_ptr(self, d):
+        off = self._dense_b[d]
+        return 0 if off is None else self.g_arena.data_ptr() + 4 * off
+
+    def dense_view(self, d):
+        off, r, c = self._dense[d]
+        return self.g_arena[off:off + r * c].view(r, c)
+
+    def dense_ld(self, d):
+        return self._dense[d][2]
+
+    def param_key(self):
+        return tuple(p["weight"].data_ptr() for p in self._pack)
+
+    def _table(self, structs):
+        n = len(structs)
+        arr = (type(structs[0]) * n)(*structs)
+        raw = bytes(arr)
+        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        return t
+
+    def _build_pack_table(self):
+        descs, prefix = [], [0]
+        for p in self._pack:
+            d = L.NcwPackDesc()
+            w = p["weight"]
+            assert w.dtype == torch.float32 and w.is_contiguous() and w.device == self.device, "fp32 contiguous params on the plan's device required"
+            d.src = w.data_ptr()
+            d.g = p["g"].data_ptr() if p["g"] is not None else 0
+            d.bias = p["bias"].data_ptr() if (p["bias"] is not None and p["bias_slot"] is not None) else 0
+            off, rb_out, rb_in = self._mats[p["mat"]]
+            d.dst_w = self.w_arena.data_ptr() + off
+            d.dst_b = self.bias_ptr(p["bias_slot"]) if p["bias_slot"] is not None else 0
+            d.ld = w.shape[1]
+            d.row0, d.nrows, d.drow0 = p["row0"], p["nrows"], p["drow0"]
+            d.rb_out, d.rb_in = rb_out, rb_in
+            d.transpose = 1 if p["transpose"] else 0
+            d.prec = self.prec
+            d.scale = p["scale"]
+            d.nseg = len(p["segs"])
+            assert d.nseg <= L.MAX_SEGS
+            for i, (c0, nc, dc0) in enumerate(p["segs"]):
+                d.seg[i].col0, d.seg[i].ncols, d.seg[i].dcol0 = c0, nc, dc0
+                lim_in = 32 * (rb_out if p["transpose"] else rb_in)
+                assert dc0 + nc <= lim_in, "segment exceeds packed matrix"
+            lim_out = 32 * (rb_in if p["transpose"] else rb_out)
+            assert p["drow0"] + p["nrows"] <= lim_out, "rows exceed packed matrix"
+            descs.append(d)
+            prefix.append(prefix[-1] + p["nrows"])
+        self._pack_tab = self._table(descs)
+        self._pack_prefix = torch.tensor(prefix, dtype=torch.int32, device=self.device)
+        self._pack_rows = prefix[-1]
+        self._pack_n = len(descs)
+        self._key = self.param_key()
+
+    def pack(self):
+        """(Re)pack all weights on the current stream."""
+        if self.param_key() != self._key:  # parameter storage moved (e.g. .to(), load): rebuild
+            self._build_pack_table()
+        lib = L.get_lib()
+        L.check(lib.ncw_pack_weights(L.ptr(self._pack_tab), L.ptr(self._pack_prefix), self._pack_n,
+                                     self._pack_rows, L.stream_ptr(self.device)), "ncw_pack_weights")
+
+    def unpack_grads(self, accumulate_into):
+        """accumulate_into: dict id(param) -> grad tensor (same shape, fp32, contiguous).  Writes the
+        parameter gradients from the dense gradient arena."""
+        descs, prefix = [], [0]
+        for u in self._unpack:
+            d = L.NcwUnpackDesc()
+            w = u["weight"]
+            d.dw = self.dense_ptr(u["dense"])
+            d.db = self.dense_bias_ptr(u["dense"]) if u["bias"] is not None else 0
+            d.src = w.data_ptr()
+            d.g = u["g"].data_ptr() if u["g"] is not None else 0
+            d.d_src = accumulate_into[id(w)].data_ptr()
+            d.d_g = accumulate_into[id(u["g"])].data_ptr() if u["g"] is not None else 0
+            d.d_bias = accumulate_into[id(u["bias"])].data_ptr() if u["bias"] is not None else 0
+            d.ld, d.ldw = w.shape[1], self.dense_ld(u["dense"])
+            d.row0, d.nrows, d.drow0 = u["row0"], u["nrows"], u["drow0"]
+            d.scale = u["scale"]
+            d.accumulate = 0
+            d.nseg = len(u["segs"])
+            for i, (c0, nc, dc0) in enumerate(u["segs"]):
+                d.seg[i].col0, d.seg[i].ncols, d.seg[i].dcol0 = c0, nc, dc0
+            descs.append(d)
+            prefix.append(prefix[-1] + u["nrows"])
+        tab = self._table(descs)
+        pre = torch.tensor(prefix, dtype=torch.int32, device=self.device)
+        lib = L.get_lib()
+        L.check(lib.ncw_unpack_grads(L.ptr(tab), L.ptr(pre), len(descs), prefix[-1], L.stream_ptr(self.device)),
+                "ncw_unpack_grads")
+        return tab, pre  # keep alive until the stream has consumed them
