@@ -116,6 +116,83 @@ typedef struct NcwSdfNet {
 /* a-2 `sdf(x)` (neuconw.py:281-282): x [n,3] f32 -> sdf [n] f32.  No grad, last layer 1 row. */
 int ncw_sdf_infer(const NcwSdfNet* net, int prec, const float* x, int64_t n, float* sdf, void* stream);
 
+/* Same network evaluated at ray samples x = o[r] + d[r] * z[r,i]  (renderer.py:519-522, 350-352):
+ * rays_o, rays_d [R,3], z [R,n] -> sdf [R,n].  Fuses the point generation into the MLP prologue. */
+int ncw_sdf_infer_rays(const NcwSdfNet* net, int prec, const float* rays_o, const float* rays_d, const float* z,
+                       int R, int n, float* sdf, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-ray sampler kernels (one wavefront per ray).  All arrays f32, row-major [R, n].
+ * ---------------------------------------------------------------------------------------- */
+/* renderer.py:488-514: coarse z (+ optional whole-ray jitter rand_shift[R]), inverse-depth outside
+ * samples (+ optional stratified jitter rand_out[R,O]), sample_dist.  rand_* may be NULL. */
+int ncw_sample_coarse(const float* near, const float* far, const float* s_near, const float* s_far, int R,
+                      int n_samples, int n_outside, const float* rand_shift, const float* rand_out,
+                      float* z, float* z_out, float* sample_dist, void* stream);
+/* renderer.py:257-341 (up_sample) + :15-48 (sample_pdf, det=True): -> z_new [R, n_new] */
+int ncw_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int R, int n,
+                 float inv_s, int n_new, float* z_new, void* stream);
+/* renderer.py:343-363, :566, :835-836: stable sort of cat([a,b]) per ray, optional payload
+ * (pa/pb/pout may be NULL). */
+int ncw_sort_merge(const float* a, int na, const float* b, int nb, const float* pa, const float* pb, int R,
+                   float* out, float* pout, void* stream);
+/* renderer.py:549-565 boundary samples: zb [R, nb] (unsorted; feed to ncw_sort_merge) */
+int ncw_boundary(const float* near, const float* far, const float* z, int n, int R, int nb, float* zb,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Compositor: renderer.py:205-216 (background alpha) + :586-783 (render_core after the networks).
+ * HOST structs of device pointers.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct NcwCompositeIn {
+    const float* rays_o;       /* [R,3] unit-sphere units                         */
+    const float* rays_d;       /* [R,3]                                           */
+    const float* z;            /* [R,S] sorted inside samples                     */
+    const float* z_feed;       /* [R,S+O] sort(cat(z, z_out)) or NULL (no bg)     */
+    const float* sample_dist;  /* [R]                                             */
+    const float* sdf;          /* [R,S]                                           */
+    const float* grad;         /* [R,S,3] d sdf / d x                             */
+    const float* rgb;          /* [R,S,3]                                         */
+    const float* density;      /* [R,S+O] raw NeRF density or NULL                */
+    const float* bg_rgb;       /* [R,S+O,3] or NULL                               */
+    const float* inv_s;        /* [1] device scalar exp(10 variance)              */
+    const float* background_rgb; /* [3] or NULL                                   */
+    float cos_anneal;
+    int32_t R, S, O, has_bg, trim_sphere;
+} NcwCompositeIn;
+
+typedef struct NcwCompositeOut {
+    float* color;        /* [R,3] */
+    float* color_sphere; /* [R,3] */
+    float* color_bg;     /* [R,3] */
+    float* weights;      /* [R,S+O] */
+    float* weights_sum;  /* [R]   */
+    float* cdf;          /* [R,S] prev_cdf */
+    float* inside;       /* [R,S] */
+    float* depth;        /* [R]   */
+    float* normals;      /* [R,3] */
+    float* eik;          /* [R,2] per-ray (sum relax*(|g|-1)^2, sum relax): eikonal partials */
+    float* mid_z;        /* [R,S] */
+    float* dists;        /* [R,S] */
+    float* bg_alpha;     /* [R,S+O] or NULL when !has_bg */
+} NcwCompositeOut;
+
+typedef struct NcwCompositeGrad {
+    const float* d_color;       /* [R,3] upstream */
+    const float* d_weights_sum; /* [R]            */
+    const float* d_depth;       /* [R]            */
+    const float* d_eik_num;     /* [R]            */
+    float* d_sdf;      /* [R,S]     */
+    float* d_grad;     /* [R,S,3]   */
+    float* d_rgb;      /* [R,S,3]   */
+    float* d_density;  /* [R,S+O]   */
+    float* d_bg_rgb;   /* [R,S+O,3] */
+    float* d_inv_s;    /* [1], accumulated with atomics: zero it first */
+} NcwCompositeGrad;
+
+int ncw_composite_fwd(const NcwCompositeIn* in, const NcwCompositeOut* out, void* stream);
+int ncw_composite_bwd(const NcwCompositeIn* in, const NcwCompositeGrad* g, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

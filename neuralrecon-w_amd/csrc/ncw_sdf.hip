@@ -22,8 +22,28 @@ NCW_DEV void softplus_act(Act<P, RB>& act, CVec<RB>& acc) {
     to_act(act, acc);
 }
 
+// Where a wave's 32 points come from: an explicit [n,3] array, or ray samples o + d z.
+struct PointSrc {
+    const float* x;       // [n,3] or null
+    const float* rays_o;  // [R,3]
+    const float* rays_d;  // [R,3]
+    const float* z;       // [R,per_ray]
+    int per_ray;
+};
+NCW_DEV void load_point(const PointSrc& s, int64_t p, float (&xs)[3]) {
+    if (s.x) {
+        xs[0] = s.x[p * 3 + 0]; xs[1] = s.x[p * 3 + 1]; xs[2] = s.x[p * 3 + 2];
+    } else {
+        const int64_t r = p / s.per_ray;
+        const float zz = s.z[p];
+        xs[0] = s.rays_o[r * 3 + 0] + s.rays_d[r * 3 + 0] * zz;
+        xs[1] = s.rays_o[r * 3 + 1] + s.rays_d[r * 3 + 1] * zz;
+        xs[2] = s.rays_o[r * 3 + 2] + s.rays_d[r * 3 + 2] * zz;
+    }
+}
+
 template <class P, int RB>
-__global__ __launch_bounds__(256) void sdf_infer_kernel(NcwSdfNet net, const float* __restrict__ x, int64_t n,
+__global__ __launch_bounds__(256) void sdf_infer_kernel(NcwSdfNet net, PointSrc src, int64_t n,
                                                         float* __restrict__ sdf) {
     typedef typename P::welem WE;
     const int lane = ncw_lane();
@@ -32,7 +52,9 @@ __global__ __launch_bounds__(256) void sdf_infer_kernel(NcwSdfNet net, const flo
     if (tile * 32 >= n) return;
     const bool valid = p < n;
     if (!valid) p = n - 1;
-    float xs[3] = {x[p * 3 + 0] * net.scale, x[p * 3 + 1] * net.scale, x[p * 3 + 2] * net.scale};
+    float xs[3];
+    load_point(src, p, xs);
+    xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
 
     CVec<2> gam;
     freq_encode<2, 3, 6, Fast<P>::v>(gam, xs, lane);
@@ -59,27 +81,39 @@ __global__ __launch_bounds__(256) void sdf_infer_kernel(NcwSdfNet net, const flo
 }
 
 template <class P, int RB>
-static int launch_sdf_infer(const NcwSdfNet* net, const float* x, int64_t n, float* sdf, hipStream_t st) {
+static int launch_sdf_infer(const NcwSdfNet* net, const PointSrc& src, int64_t n, float* sdf, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
     const int64_t blocks = (tiles + 3) / 4;
-    hipLaunchKernelGGL((sdf_infer_kernel<P, RB>), dim3((unsigned)blocks), dim3(256), 0, st, *net, x, n, sdf);
+    hipLaunchKernelGGL((sdf_infer_kernel<P, RB>), dim3((unsigned)blocks), dim3(256), 0, st, *net, src, n, sdf);
     NCW_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int ncw_sdf_infer(const NcwSdfNet* net, int prec, const float* x, int64_t n, float* sdf, void* stream) {
+static int sdf_infer_dispatch(const NcwSdfNet* net, int prec, const PointSrc& src, int64_t n, float* sdf, void* stream) {
     if (!net || n < 0 || net->multires != 6 || net->n_layers < 2 || net->n_layers > NCW_MAX_LAYERS) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-#define NCW_DISPATCH(RBV)                                                                      \
-    if (net->rb == RBV) {                                                                      \
-        if (prec == NCW_PREC_F32) return launch_sdf_infer<PrecF32, RBV>(net, x, n, sdf, st);   \
-        if (prec == NCW_PREC_BF16) return launch_sdf_infer<PrecBF16, RBV>(net, x, n, sdf, st); \
-        return NCW_E_BADARG;                                                                   \
+#define NCW_DISPATCH(RBV)                                                                        \
+    if (net->rb == RBV) {                                                                        \
+        if (prec == NCW_PREC_F32) return launch_sdf_infer<PrecF32, RBV>(net, src, n, sdf, st);   \
+        if (prec == NCW_PREC_BF16) return launch_sdf_infer<PrecBF16, RBV>(net, src, n, sdf, st); \
+        return NCW_E_BADARG;                                                                     \
     }
     NCW_DISPATCH(2)
     NCW_DISPATCH(8)
     NCW_DISPATCH(16)
 #undef NCW_DISPATCH
     return NCW_E_UNSUPPORTED;
+}
+
+extern "C" int ncw_sdf_infer(const NcwSdfNet* net, int prec, const float* x, int64_t n, float* sdf, void* stream) {
+    PointSrc src{x, nullptr, nullptr, nullptr, 1};
+    return sdf_infer_dispatch(net, prec, src, n, sdf, stream);
+}
+
+extern "C" int ncw_sdf_infer_rays(const NcwSdfNet* net, int prec, const float* rays_o, const float* rays_d,
+                                  const float* z, int R, int n, float* sdf, void* stream) {
+    if (R < 0 || n <= 0) return NCW_E_BADARG;
+    PointSrc src{nullptr, rays_o, rays_d, z, n};
+    return sdf_infer_dispatch(net, prec, src, (int64_t)R * n, sdf, stream);
 }

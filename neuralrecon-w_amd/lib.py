@@ -47,7 +47,37 @@ class NcwSdfNet(C.Structure):
     ]
 
 
+def _ptr_struct(name, fields_ptr, fields_other=()):
+    return type(name, (C.Structure,), {"_fields_": [(f, C.c_void_p) for f in fields_ptr] + list(fields_other)})
+
+
+NcwCompositeIn = _ptr_struct(
+    "NcwCompositeIn",
+    ["rays_o", "rays_d", "z", "z_feed", "sample_dist", "sdf", "grad", "rgb", "density", "bg_rgb", "inv_s",
+     "background_rgb"],
+    [("cos_anneal", C.c_float), ("R", C.c_int32), ("S", C.c_int32), ("O", C.c_int32), ("has_bg", C.c_int32),
+     ("trim_sphere", C.c_int32)],
+)
+NcwCompositeOut = _ptr_struct(
+    "NcwCompositeOut",
+    ["color", "color_sphere", "color_bg", "weights", "weights_sum", "cdf", "inside", "depth", "normals", "eik",
+     "mid_z", "dists", "bg_alpha"],
+)
+NcwCompositeGrad = _ptr_struct(
+    "NcwCompositeGrad",
+    ["d_color", "d_weights_sum", "d_depth", "d_eik_num", "d_sdf", "d_grad", "d_rgb", "d_density", "d_bg_rgb",
+     "d_inv_s"],
+)
+
+_VP = C.c_void_p
 _PROTOS = {
+    "ncw_sdf_infer_rays": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, _VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP]),
+    "ncw_sample_coarse": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "ncw_upsample": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_float, C.c_int, _VP, _VP]),
+    "ncw_sort_merge": (C.c_int, [_VP, C.c_int, _VP, C.c_int, _VP, _VP, C.c_int, _VP, _VP, _VP]),
+    "ncw_boundary": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP]),
+    "ncw_composite_fwd": (C.c_int, [C.POINTER(NcwCompositeIn), C.POINTER(NcwCompositeOut), _VP]),
+    "ncw_composite_bwd": (C.c_int, [C.POINTER(NcwCompositeIn), C.POINTER(NcwCompositeGrad), _VP]),
     "ncw_abi_version": (C.c_int, []),
     "ncw_device_info": (C.c_int, [C.c_char_p, C.c_int]),
     "ncw_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -61,7 +61,7 @@ def test_cfg1_render_core_and_grads():
     rays = m["rays"]
     a = sd["embedding_a.weight"][m["ts"]]
     zf, _ = torch.sort(torch.cat([m["z"], m["z_out"]], -1), -1)
-    bg_rgb, bg_alpha = O.render_core_outside(sd, rays[:, 0:3], rays[:, 3:6], zf, m["sample_dist"], a)
+    bg_rgb, bg_alpha, _ = O.render_core_outside(sd, rays[:, 0:3], rays[:, 3:6], zf, m["sample_dist"], a)
     assert rel_err(bg_alpha, m["bg_alpha"]) < TOL
     rc = O.render_core(sd, cfg, rays[:, 0:3], rays[:, 3:6], m["z"], m["sample_dist"], a, 0.3, bg_alpha, bg_rgb,
                        torch.zeros(1, 3))
