@@ -122,6 +122,69 @@ int ncw_sdf_infer_rays(const NcwSdfNet* net, int prec, const float* rays_o, cons
                        int R, int n, float* sdf, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Point source shared by the fused MLP kernels: explicit points or ray samples (the point
+ * generation of renderer.py:586-597 / :176-186 is fused into the MLP prologue).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct NcwPoints {
+    const float* x;            /* mode 0: [n,3] explicit points                              */
+    const float* rays_o;       /* modes 1,2: [R,3]                                           */
+    const float* rays_d;       /* modes 1,2: [R,3]                                           */
+    const float* z;            /* modes 1,2: [R,per_ray]                                     */
+    const float* sample_dist;  /* mode 2: [R]                                                */
+    int32_t per_ray;
+    int32_t mode;              /* 0: x;  1: o + d z;  2: section mid-point o + d (z_i + dist_i/2) */
+} NcwPoints;
+
+/* Activation stash of the SDF net in fragment-native layout [tile32][blocks][4][64 lanes][4]
+ * (element = f32 for prec 0, bf16 for prec 1).  HOST struct of device pointers.
+ * Written by ncw_sdf_fwd (gamma, h, s, t, feat), ncw_color_bwd (dfeat) and ncw_sdf_bwd
+ * (qbar, zbar, zsdf, one); consumed by ncw_sdf_bwd and ncw_wgrad. */
+typedef struct NcwSdfStash {
+    void* gamma;                 /* encoding, 2 blocks                                        */
+    void* h[NCW_MAX_LAYERS];     /* h[l], l>=1: input of layer l = Softplus(z_{l-1}), rb blocks */
+    void* s[NCW_MAX_LAYERS];     /* s[l] = Softplus'(z_l), l <= L-2                            */
+    void* t[NCW_MAX_LAYERS];     /* t[l] = a_l * s[l] (adjoint pass), l <= L-2                 */
+    void* feat;                  /* feature vector z_{L-1}[1:], rb blocks                      */
+    void* dfeat;                 /* upstream d(feat), rb blocks                                */
+    void* qbar[NCW_MAX_LAYERS];  /* qbar[0]: 2 blocks (J_gamma nbar); qbar[l]: rb blocks       */
+    void* zbar[NCW_MAX_LAYERS];  /* zbar[l] = dL/dz_l, l <= L-2                                */
+    void* zsdf;                  /* 1 block: feature 0 = d_sdf                                 */
+    void* one;                   /* 1 block: feature 0 = 1                                     */
+} NcwSdfStash;
+
+/* a-2/a-5 forward of the SDF net WITH its analytic input gradient (neuconw.py:263-296):
+ * sdf [n], grad [n,3] (= d sdf / d x), plus the stash for the backward.  One launch. */
+int ncw_sdf_fwd(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t n, float* sdf, float* grad,
+                const NcwSdfStash* stash, void* stream);
+/* First- and second-order backward (SURVEY 8a-2 "parameter-gradient specification"): consumes
+ * d_sdf [n], d_grad [n,3] and stash->dfeat; fills stash->qbar/zbar/zsdf/one for ncw_wgrad. */
+int ncw_sdf_bwd(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_sdf,
+                const float* d_grad, const NcwSdfStash* stash, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight-gradient GEMMs: dense[32*rbx, ld] (f32, forward orientation) += X^T Y over all points,
+ * X, Y in stash layout; optional dbias[32*rbx] += column sums of X.  Batched: one launch runs a
+ * device table of products (split-K + f32 atomics).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct NcwWgradDesc {
+    const void* x;     /* stash, rbx blocks  (output-feature side)  */
+    const void* y;     /* stash, rby blocks  (input-feature side)   */
+    float* dense;      /* [32*rbx, ld] (+ column offset already applied) */
+    float* dbias;      /* [32*rbx] or NULL                           */
+    int32_t rbx, rby, ld, _pad;
+} NcwWgradDesc;
+/* descs: DEVICE array; wg_prefix: device int32[n_desc+1] exclusive prefix of
+ * ceil(rbx/4)*ceil(rby/4)*ksplit workgroups per product; total_wgs = wg_prefix[n_desc]. */
+int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
+              int prec, int64_t n_points, void* stream);
+
+/* Layout converters between row-major f32 [n, F] and the stash layout (rb = ceil(F/32) blocks,
+ * element type by prec).  Used at the module boundary (NeuconW.forward returning feature vectors,
+ * tests); padded lanes / features are written as zero. */
+int ncw_stash_from_rows(int prec, const float* rows, int64_t n, int F, int rb, void* stash, void* stream);
+int ncw_stash_to_rows(int prec, const void* stash, int64_t n, int F, int rb, float* rows, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-ray sampler kernels (one wavefront per ray).  All arrays f32, row-major [R, n].
  * ---------------------------------------------------------------------------------------- */
 /* renderer.py:488-514: coarse z (+ optional whole-ray jitter rand_shift[R]), inverse-depth outside

@@ -105,14 +105,16 @@ NCW_DEV void to_act(Act<PrecBF16, RB>& a, const CVec<RB>& c) {
 // packed fragment order at `wp` (see ncw_pack.hip).  K_REAL = number of real (non-padding) input
 // features: k-steps that only touch padding are skipped at compile time.
 // ---------------------------------------------------------------------------------------------
-template <int RB_IN, int RB_OUT, int K_REAL>
+// RB_STRIDE = number of out-blocks of the packed matrix (>= RB_OUT: only the first RB_OUT blocks
+// are computed, e.g. the h-part of the transposed skip layer).
+template <int RB_IN, int RB_OUT, int K_REAL, int RB_STRIDE = RB_OUT>
 NCW_DEV void mma(CVec<RB_OUT>& acc, const Act<PrecF32, RB_IN>& in, const float* __restrict__ wp, int lane) {
 #pragma unroll
     for (int rb = 0; rb < RB_IN; ++rb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (32 * rb + ncw_feat_of(r, 0) >= K_REAL) continue;  // h=1 feature is even larger
-            const float* w = wp + ((size_t)(rb * 16 + r) * RB_OUT) * 64 + lane;
+            const float* w = wp + ((size_t)(rb * 16 + r) * RB_STRIDE) * 64 + lane;
 #pragma unroll
             for (int ro = 0; ro < RB_OUT; ++ro) {
                 float a = w[ro * 64];
@@ -121,12 +123,12 @@ NCW_DEV void mma(CVec<RB_OUT>& acc, const Act<PrecF32, RB_IN>& in, const float* 
         }
     }
 }
-template <int RB_IN, int RB_OUT, int K_REAL>
+template <int RB_IN, int RB_OUT, int K_REAL, int RB_STRIDE = RB_OUT>
 NCW_DEV void mma(CVec<RB_OUT>& acc, const Act<PrecBF16, RB_IN>& in, const __bf16* __restrict__ wp, int lane) {
 #pragma unroll
     for (int s = 0; s < 2 * RB_IN; ++s) {
         if (16 * s >= K_REAL) continue;
-        const bf16x8* w = reinterpret_cast<const bf16x8*>(wp) + ((size_t)s * RB_OUT) * 64 + lane;
+        const bf16x8* w = reinterpret_cast<const bf16x8*>(wp) + ((size_t)s * RB_STRIDE) * 64 + lane;
 #pragma unroll
         for (int ro = 0; ro < RB_OUT; ++ro) {
             bf16x8 a = w[ro * 64];

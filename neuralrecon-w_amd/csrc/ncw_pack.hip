@@ -141,6 +141,58 @@ extern "C" int ncw_unpack_grads(const NcwUnpackDesc* descs, const int32_t* row_p
     return 0;
 }
 
+// ---- stash <-> row-major converters ---------------------------------------------------------------
+template <class SE, bool TO_ROWS>
+__global__ void stash_rows_kernel(SE* stash, float* rows, int64_t n, int F, int rb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile * 32 >= n) return;
+    const int64_t p = tile * 32 + (lane & 31);
+    const int h = lane >> 5;
+    for (int b = 0; b < rb; ++b)
+        for (int g = 0; g < 4; ++g) {
+            SE* s = stash + ((((size_t)tile * rb + b) * 4 + g) * 64 + lane) * 4;
+            for (int c = 0; c < 4; ++c) {
+                const int f = b * 32 + 8 * g + 4 * h + c;
+                if (TO_ROWS) {
+                    if (p < n && f < F) rows[p * F + f] = (float)s[c];
+                } else {
+                    s[c] = (p < n && f < F) ? (SE)rows[p * F + f] : (SE)0.f;
+                }
+            }
+        }
+}
+
+extern "C" int ncw_stash_from_rows(int prec, const float* rows, int64_t n, int F, int rb, void* stash, void* stream) {
+    if (n <= 0) return 0;
+    if (F > 32 * rb) return NCW_E_BADARG;
+    const int64_t tiles = (n + 31) / 32;
+    dim3 grid((unsigned)((tiles + 3) / 4));
+    if (prec == NCW_PREC_F32)
+        hipLaunchKernelGGL((stash_rows_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, (float*)stash,
+                           const_cast<float*>(rows), n, F, rb);
+    else
+        hipLaunchKernelGGL((stash_rows_kernel<__bf16, false>), grid, dim3(256), 0, (hipStream_t)stream, (__bf16*)stash,
+                           const_cast<float*>(rows), n, F, rb);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ncw_stash_to_rows(int prec, const void* stash, int64_t n, int F, int rb, float* rows, void* stream) {
+    if (n <= 0) return 0;
+    if (F > 32 * rb) return NCW_E_BADARG;
+    const int64_t tiles = (n + 31) / 32;
+    dim3 grid((unsigned)((tiles + 3) / 4));
+    if (prec == NCW_PREC_F32)
+        hipLaunchKernelGGL((stash_rows_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                           (float*)const_cast<void*>(stash), rows, n, F, rb);
+    else
+        hipLaunchKernelGGL((stash_rows_kernel<__bf16, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                           (__bf16*)const_cast<void*>(stash), rows, n, F, rb);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int ncw_abi_version(void) { return 1; }
 
 extern "C" int ncw_device_info(char* buf, int buflen) {

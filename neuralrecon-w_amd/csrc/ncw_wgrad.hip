@@ -1,0 +1,167 @@
+// Weight-gradient GEMMs:  dense[i][j] += sum_points X[p][i] * Y[p][j]   (+ dbias[i] += sum_p X[p][i])
+// for every Linear of every network, batched in ONE launch from a device descriptor table.
+//
+// X, Y are activation stashes in fragment-native layout [tile32][rb][g][lane][4] (point per lane).
+// The reduction index of these GEMMs is the POINT, so both operands must be transposed to
+// "feature per lane, points along K"; that happens once per chunk through LDS (XT[f][p]), after
+// which A and B fragments are plain 16-byte (bf16) / 4-byte (f32) LDS reads, conflict-free by row
+// padding.  A workgroup owns a 128x128 output quadrant (4 waves x 2x2 blocks of 32x32) for one
+// K-slice of the points; K-slices combine with f32 atomics (16 slices x 256 KB per product, tiny).
+//
+// Replaces the autograd-generated `mm` / `addmm` backward GEMMs of every F.linear on the path
+// (models/neuconw.py:269-278,130-170; models/nerf.py:156-182) including the second-order products
+// t_l qbar_l^T of SURVEY 8a-2.
+#include "ncw_mlp.h"
+
+template <class P> struct WgT;
+template <> struct WgT<PrecBF16> {
+    static constexpr int CH = 64;       // points per chunk
+    static constexpr int LDT = 64 + 8;  // row stride in elements (144 B: 16-B aligned, conflict-free b128)
+};
+template <> struct WgT<PrecF32> {
+    static constexpr int CH = 32;
+    static constexpr int LDT = 32 + 1;
+};
+
+__device__ __forceinline__ int wg_find(const int32_t* __restrict__ prefix, int n, int v) {
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= v) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// stage `nb` feature blocks (starting at block b0 of an rb-block stash) of the chunk's tiles into T[f][p]
+template <class P>
+NCW_DEV void stage_transposed(typename P::selem* T, const typename P::selem* __restrict__ src, int rb, int b0, int nb,
+                              int64_t tile0, int ntile, int tid) {
+    typedef typename P::selem SE;
+    constexpr int LDT = WgT<P>::LDT;
+    const int items = ntile * nb * 4;  // (tile, block, g) triples, one wave-load each
+    const int wave = tid >> 6, lane = tid & 63;
+    const int p = lane & 31, h = lane >> 5;
+    for (int it = wave; it < items; it += 4) {
+        const int g = it & 3;
+        const int b = (it >> 2) % nb;
+        const int tp = (it >> 2) / nb;
+        const SE* s = src + ((((size_t)(tile0 + tp) * rb + (b0 + b)) * 4 + g) * 64 + lane) * 4;
+        SE v[4];
+        if (sizeof(SE) == 4) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(s);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (SE)t[c];
+        } else {
+            bf16x4 t = *reinterpret_cast<const bf16x4*>(s);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (SE)t[c];
+        }
+        const int f = b * 32 + 8 * g + 4 * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) T[(f + c) * LDT + tp * 32 + p] = v[c];
+    }
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void wgrad_kernel(const NcwWgradDesc* __restrict__ descs,
+                                                    const int32_t* __restrict__ prefix, int n_desc, int ksplit,
+                                                    int64_t ntiles) {
+    typedef typename P::selem SE;
+    constexpr int CH = WgT<P>::CH, LDT = WgT<P>::LDT;
+    __shared__ __attribute__((aligned(16))) SE XT[128 * LDT];
+    __shared__ __attribute__((aligned(16))) SE YT[128 * LDT];
+    const int d = wg_find(prefix, n_desc, blockIdx.x);
+    const NcwWgradDesc D = descs[d];
+    const int local = blockIdx.x - prefix[d];
+    const int quad = local / ksplit, ks = local - quad * ksplit;
+    const int nqj = (D.rby + 3) >> 2;
+    const int qi = quad / nqj, qj = quad - qi * nqj;
+    const int nbi = min(4, D.rbx - 4 * qi), nbj = min(4, D.rby - 4 * qj);
+    const int64_t tpk = (ntiles + ksplit - 1) / ksplit;
+    const int64_t t_begin = (int64_t)ks * tpk, t_end = min(t_begin + tpk, ntiles);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wi = wave >> 1, wj = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = (D.dbias != nullptr) && (qj == 0) && (tid < 32 * nbi);
+    const bool act_i0 = 2 * wi < nbi, act_i1 = 2 * wi + 1 < nbi, act_j0 = 2 * wj < nbj, act_j1 = 2 * wj + 1 < nbj;
+    const int fi = lane & 31, kh = lane >> 5;
+    for (int64_t t0 = t_begin; t0 < t_end; t0 += CH / 32) {
+        const int ntile = (int)min((int64_t)(CH / 32), t_end - t0);
+        __syncthreads();
+        stage_transposed<P>(XT, (const SE*)D.x, D.rbx, 4 * qi, nbi, t0, ntile, tid);
+        stage_transposed<P>(YT, (const SE*)D.y, D.rby, 4 * qj, nbj, t0, ntile, tid);
+        __syncthreads();
+        const int npts = ntile * 32;
+        if (do_bias) {
+            float s = 0.f;
+            for (int q = 0; q < npts; ++q) s += (float)XT[tid * LDT + q];
+            bsum += s;
+        }
+        if (act_i0 && act_j0) {
+            if (P::id == NCW_PREC_BF16) {
+                for (int kk = 0; kk < npts / 16; ++kk) {
+                    const int ko = kk * 16 + 8 * kh;
+                    bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&XT[((2 * wi) * 32 + fi) * LDT + ko]);
+                    bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&YT[((2 * wj) * 32 + fi) * LDT + ko]);
+                    bf16x8 a1 = a0, b1 = b0;
+                    if (act_i1) a1 = *reinterpret_cast<const bf16x8*>(&XT[((2 * wi + 1) * 32 + fi) * LDT + ko]);
+                    if (act_j1) b1 = *reinterpret_cast<const bf16x8*>(&YT[((2 * wj + 1) * 32 + fi) * LDT + ko]);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                    if (act_j1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                    if (act_i1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                    if (act_i1 && act_j1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            } else {
+                for (int kk = 0; kk < npts / 2; ++kk) {
+                    const int ko = kk * 2 + kh;
+                    float a0 = (float)XT[((2 * wi) * 32 + fi) * LDT + ko];
+                    float b0 = (float)YT[((2 * wj) * 32 + fi) * LDT + ko];
+                    float a1 = a0, b1 = b0;
+                    if (act_i1) a1 = (float)XT[((2 * wi + 1) * 32 + fi) * LDT + ko];
+                    if (act_j1) b1 = (float)YT[((2 * wj + 1) * 32 + fi) * LDT + ko];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    if (act_j1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    if (act_i1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    if (act_i1 && act_j1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue: f32 atomics into the dense gradient (row = X feature, col = Y feature) ------------
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ib = 2 * wi + a, jb = 2 * wj + b;
+            if (ib >= nbi || jb >= nbj) continue;
+            const int col = (4 * qj + jb) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (4 * qi + ib) * 32 + ncw_feat_of(r, lane >> 5);
+                atomicAdd(&D.dense[(size_t)row * D.ld + col], acc[a][b][r]);
+            }
+        }
+    if (do_bias) atomicAdd(&D.dbias[4 * qi * 32 + tid], bsum);
+}
+
+extern "C" int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
+                         int prec, int64_t n_points, void* stream) {
+    if (n_desc <= 0 || total_wgs <= 0 || n_points <= 0) return 0;
+    if (ksplit < 1) return NCW_E_BADARG;
+    const int64_t ntiles = (n_points + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (prec == NCW_PREC_BF16)
+        hipLaunchKernelGGL(wgrad_kernel<PrecBF16>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+    else if (prec == NCW_PREC_F32)
+        hipLaunchKernelGGL(wgrad_kernel<PrecF32>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+    else return NCW_E_BADARG;
+    NCW_CHECK_LAUNCH();
+    return 0;
+}

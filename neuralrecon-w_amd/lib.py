@@ -47,6 +47,23 @@ class NcwSdfNet(C.Structure):
     ]
 
 
+class NcwPoints(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("z", C.c_void_p),
+                ("sample_dist", C.c_void_p), ("per_ray", C.c_int32), ("mode", C.c_int32)]
+
+
+class NcwSdfStash(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("h", C.c_void_p * MAX_LAYERS), ("s", C.c_void_p * MAX_LAYERS),
+                ("t", C.c_void_p * MAX_LAYERS), ("feat", C.c_void_p), ("dfeat", C.c_void_p),
+                ("qbar", C.c_void_p * MAX_LAYERS), ("zbar", C.c_void_p * MAX_LAYERS), ("zsdf", C.c_void_p),
+                ("one", C.c_void_p)]
+
+
+class NcwWgradDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dense", C.c_void_p), ("dbias", C.c_void_p),
+                ("rbx", C.c_int32), ("rby", C.c_int32), ("ld", C.c_int32), ("_pad", C.c_int32)]
+
+
 def _ptr_struct(name, fields_ptr, fields_other=()):
     return type(name, (C.Structure,), {"_fields_": [(f, C.c_void_p) for f in fields_ptr] + list(fields_other)})
 
@@ -71,6 +88,13 @@ NcwCompositeGrad = _ptr_struct(
 
 _VP = C.c_void_p
 _PROTOS = {
+    "ncw_sdf_fwd": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p, C.c_void_p,
+                              C.POINTER(NcwSdfStash), C.c_void_p]),
+    "ncw_sdf_bwd": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p, C.c_void_p,
+                              C.POINTER(NcwSdfStash), C.c_void_p]),
+    "ncw_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "ncw_stash_from_rows": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ncw_stash_to_rows": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ncw_sdf_infer_rays": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, _VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP]),
     "ncw_sample_coarse": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP]),
     "ncw_upsample": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_float, C.c_int, _VP, _VP]),

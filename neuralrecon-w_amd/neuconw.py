@@ -12,6 +12,26 @@ from torch import nn
 
 from . import lib as L
 from .packing import PackPlan
+from .stash import StashArena, WgradBatch
+
+
+def points_struct(x=None, rays_o=None, rays_d=None, z=None, sample_dist=None, mode=0):
+    """Build the NcwPoints host struct (keeps the tensors alive on the returned object)."""
+    p = L.NcwPoints()
+    keep = []
+
+    def _p(t):
+        if t is None:
+            return 0
+        t = t.contiguous().float()
+        keep.append(t)
+        return t.data_ptr()
+
+    p.x, p.rays_o, p.rays_d, p.z, p.sample_dist = _p(x), _p(rays_o), _p(rays_d), _p(z), _p(sample_dist)
+    p.per_ray = int(z.shape[1]) if z is not None else 1
+    p.mode = mode
+    p._keep = keep
+    return p
 
 
 class WNLinear(nn.Module):
@@ -182,3 +202,62 @@ class SDFNetwork(nn.Module):
         L.check(lib.ncw_sdf_infer(plan.net, prec, L.ptr(xf), xf.shape[0], L.ptr(out), L.stream_ptr(x.device)),
                 "ncw_sdf_infer")
         return out.reshape(-1, 1)
+
+    # ---- training path: forward with input gradient, backward, weight gradients ---------------------
+    def fwd_stash(self, pts, n, prec):
+        """ncw_sdf_fwd: returns (sdf [n], grad [n,3], ctx).  ctx carries the activation stash."""
+        dev = self.lin0.bias.device
+        plan = self.packed(prec)
+        RB, Lm = self.d_hidden // 32, self.n_lin
+        ar = StashArena(dev, prec, n)
+        ids = dict(gamma=ar.new(2), feat=ar.new(RB), dfeat=ar.new(RB), zsdf=ar.new(1), one=ar.new(1))
+        ids["h"] = {l: ar.new(RB) for l in range(1, Lm)}
+        ids["s"] = {l: ar.new(RB) for l in range(Lm - 1)}
+        ids["t"] = {l: ar.new(RB) for l in range(Lm - 1)}
+        ids["qbar"] = {l: ar.new(2 if l == 0 else RB) for l in range(Lm)}
+        ids["zbar"] = {l: ar.new(RB) for l in range(Lm - 1)}
+        ar.allocate()
+        st = L.NcwSdfStash()
+        st.gamma, st.feat, st.dfeat = ar.ptr(ids["gamma"]), ar.ptr(ids["feat"]), ar.ptr(ids["dfeat"])
+        st.zsdf, st.one = ar.ptr(ids["zsdf"]), ar.ptr(ids["one"])
+        for k in ("h", "s", "t", "qbar", "zbar"):
+            for l, i in ids[k].items():
+                getattr(st, k)[l] = ar.ptr(i)
+        sdf = torch.empty(n, device=dev, dtype=torch.float32)
+        grad = torch.empty(n, 3, device=dev, dtype=torch.float32)
+        L.check(L.get_lib().ncw_sdf_fwd(plan.net, prec, pts, n, L.ptr(sdf), L.ptr(grad), st, L.stream_ptr(dev)),
+                "ncw_sdf_fwd")
+        ctx = dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan)
+        return sdf, grad, ctx
+
+    def bwd_stash(self, ctx, d_sdf, d_grad):
+        """ncw_sdf_bwd: consumes d_sdf [n], d_grad [n,3] and ctx's dfeat stash."""
+        dev = self.lin0.bias.device
+        d_sdf = d_sdf.contiguous().float()
+        d_grad = d_grad.contiguous().float()
+        L.check(L.get_lib().ncw_sdf_bwd(ctx["plan"].net, ctx["prec"], ctx["pts"], ctx["n"], L.ptr(d_sdf),
+                                        L.ptr(d_grad), ctx["stash"], L.stream_ptr(dev)), "ncw_sdf_bwd")
+        ctx["_keep_bwd"] = (d_sdf, d_grad)
+
+    def add_wgrads(self, ctx, batch):
+        """Queue every weight-gradient product of the SDF net (forward + adjoint terms) on `batch`."""
+        plan, ar, ids = ctx["plan"], ctx["arena"], ctx["ids"]
+        RB, Lm = self.d_hidden // 32, self.n_lin
+        skip = self.skip_in[0] if self.skip_in else -1
+        P = ar.ptr
+        for l in range(Lm - 1):
+            dn = plan.slots[l][3]
+            ld = plan.dense_ld(dn)
+            y_f, rby = (P(ids["gamma"]), 2) if l == 0 else (P(ids["h"][l]), RB)
+            batch.add(P(ids["zbar"][l]), RB, y_f, rby, plan.dense_ptr(dn), ld, plan.dense_bias_ptr(dn))
+            batch.add(P(ids["t"][l]), RB, P(ids["qbar"][l]), rby, plan.dense_ptr(dn), ld)
+            if l == skip:
+                off = 4 * 32 * RB
+                batch.add(P(ids["zbar"][l]), RB, P(ids["gamma"]), 2, plan.dense_ptr(dn) + off, ld)
+                batch.add(P(ids["t"][l]), RB, P(ids["qbar"][0]), 2, plan.dense_ptr(dn) + off, ld)
+        s = plan.slots[Lm - 1]
+        dn, dnf = s[3], s[7]
+        hl = P(ids["h"][Lm - 1])
+        batch.add(P(ids["dfeat"]), RB, hl, RB, plan.dense_ptr(dnf), plan.dense_ld(dnf), plan.dense_bias_ptr(dnf))
+        batch.add(P(ids["zsdf"]), 1, hl, RB, plan.dense_ptr(dn), plan.dense_ld(dn), plan.dense_bias_ptr(dn))
+        batch.add(P(ids["one"]), 1, P(ids["qbar"][Lm - 1]), RB, plan.dense_ptr(dn), plan.dense_ld(dn))

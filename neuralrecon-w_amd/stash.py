@@ -1,0 +1,84 @@
+"""Activation-stash arenas and batched weight-gradient launches (host side)."""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+class StashArena:
+    """One device buffer carved into stash vectors ([tile32][rb][4][64][4] elements each)."""
+
+    def __init__(self, device, prec, n_points):
+        self.device = torch.device(device)
+        self.prec = prec
+        self.n = int(n_points)
+        self.tiles = (self.n + 31) // 32
+        self.esize = 4 if prec == L.PREC_F32 else 2
+        self._off = []
+        self._bytes = 0
+        self.buf = None
+
+    def new(self, rb):
+        off = self._bytes
+        self._bytes += self.tiles * rb * 1024 * self.esize
+        self._bytes = (self._bytes + 255) & ~255
+        self._off.append((off, rb))
+        return len(self._off) - 1
+
+    def allocate(self, zero=False):
+        fn = torch.zeros if zero else torch.empty
+        self.buf = fn(max(self._bytes, 256), dtype=torch.uint8, device=self.device)
+        return self
+
+    def ptr(self, i):
+        return self.buf.data_ptr() + self._off[i][0]
+
+    def rb(self, i):
+        return self._off[i][1]
+
+    # ---- layout converters (tests / module boundary) -------------------------------------------
+    def to_rows(self, i, F):
+        out = torch.empty(self.n, F, device=self.device, dtype=torch.float32)
+        L.check(L.get_lib().ncw_stash_to_rows(self.prec, self.ptr(i), self.n, F, self.rb(i), L.ptr(out),
+                                              L.stream_ptr(self.device)), "ncw_stash_to_rows")
+        return out
+
+    def from_rows(self, i, rows):
+        rows = rows.contiguous().float()
+        assert rows.shape[0] == self.n
+        L.check(L.get_lib().ncw_stash_from_rows(self.prec, L.ptr(rows), self.n, rows.shape[1], self.rb(i),
+                                                self.ptr(i), L.stream_ptr(self.device)), "ncw_stash_from_rows")
+
+
+class WgradBatch:
+    """Collects (X, Y, dense) weight-gradient products and runs them in one ncw_wgrad launch."""
+
+    def __init__(self, device, prec, n_points):
+        self.device = torch.device(device)
+        self.prec = prec
+        self.n = int(n_points)
+        self.items = []
+
+    def add(self, x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr=0):
+        self.items.append((x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr))
+
+    def run(self):
+        if not self.items or self.n == 0:
+            return
+        tiles = (self.n + 31) // 32
+        chunk_tiles = 2 if self.prec == L.PREC_BF16 else 1
+        ksplit = max(1, min(16, tiles // (8 * chunk_tiles)))
+        descs, prefix = [], [0]
+        for (x, rbx, y, rby, dense, ld, db) in self.items:
+            d = L.NcwWgradDesc()
+            d.x, d.y, d.dense, d.dbias = x, y, dense, db
+            d.rbx, d.rby, d.ld = rbx, rby, ld
+            descs.append(d)
+            prefix.append(prefix[-1] + ((rbx + 3) // 4) * ((rby + 3) // 4) * ksplit)
+        arr = (L.NcwWgradDesc * len(descs))(*descs)
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        pre = torch.tensor(prefix, dtype=torch.int32, device=self.device)
+        L.check(L.get_lib().ncw_wgrad(L.ptr(tab), L.ptr(pre), len(descs), prefix[-1], ksplit, self.prec, self.n,
+                                      L.stream_ptr(self.device)), "ncw_wgrad")
+        self._keep = (tab, pre)
