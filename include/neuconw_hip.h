@@ -162,6 +162,81 @@ int ncw_sdf_bwd(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t n,
                 const float* d_grad, const NcwSdfStash* stash, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Colour network -- RenderingNetwork, models/neuconw.py:59-170 (encode_apperence, mode "idr").
+ *   f  = xyz_encoding_final(feat)                       [rbf x rbf], no activation
+ *   e0 = relu(static_linear_0([f | gamma4(dir) | a]))   K = [rbf blocks | AUX1 (3 blocks)]
+ *   e_i= relu(static_linear_i(e_{i-1}))                 [rbh x rbh]
+ *   x0 = relu(lin0([points | normals | e]))             K = [rbh blocks | AUX2 (1 block: pts, normals)]
+ *   x_l= relu(lin_l(x_{l-1})) ... rgb = sigmoid(lin_last(x))
+ * ---------------------------------------------------------------------------------------- */
+typedef struct NcwColorNet {
+    const void* w_f; const void* wt_f; const float* b_f;
+    const void* w_e[4]; const void* wt_e[4]; const float* b_e[4];
+    const void* w_l[8]; const void* wt_l[8]; const float* b_l[8];
+    int32_t n_head;  /* static_head_layers                       */
+    int32_t n_lin;   /* trunk Linear count (n_layers + 1)        */
+    int32_t rbf, rbh, rbc, n_a;
+} NcwColorNet;
+
+typedef struct NcwColorStash {
+    void* aux1;      /* 3 blocks */
+    void* aux2;      /* 1 block  */
+    void* f;         /* rbf      */
+    void* e[4];      /* rbh, post-relu head activations */
+    void* x[8];      /* rbc, post-relu trunk activations x[0..n_lin-2] */
+    void* zf;        /* rbf : dL/d f (pre-activation of xyz_encoding_final) */
+    void* ze[4];     /* rbh */
+    void* zx[8];     /* rbc */
+    void* zo;        /* 1 block: dL/d(pre-sigmoid rgb), features 0..2 */
+} NcwColorStash;
+
+/* normals [n,3] (the SDF gradient), a [R or n, n_a] appearance rows indexed by the point's ray,
+ * feat: stash (rbf blocks) written by ncw_sdf_fwd  ->  rgb [n,3]. */
+int ncw_color_fwd(const NcwColorNet* net, int prec, const NcwPoints* pts, int64_t n, const float* normals,
+                  const float* a, const void* feat_stash, float* rgb, const NcwColorStash* stash, void* stream);
+/* d_rgb [n,3] -> d_grad[n,3] += d(normals), d_a [R,n_a] += (atomics; zero it first), dfeat stash (rbf),
+ * and the z-stashes for ncw_wgrad. */
+int ncw_color_bwd(const NcwColorNet* net, int prec, const NcwPoints* pts, int64_t n, const float* rgb,
+                  const float* d_rgb, float* d_grad, float* d_a, void* dfeat_stash, const NcwColorStash* stash,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Background NeRF -- models/nerf.py:86-183 (use_viewdirs, encode_appearance) evaluated on the
+ * inverted-sphere points of renderer.py:176-186 (fused into the prologue).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct NcwNerfNet {
+    const void* w_p[8]; const void* wt_p[8]; const float* b_p[8];
+    const void* w_alpha; const void* wt_alpha; const float* b_alpha;
+    const void* w_feat; const void* wt_feat; const float* b_feat;
+    const void* w_a[4]; const void* wt_a[4]; const float* b_a[4];
+    const void* w_rgb; const void* wt_rgb; const float* b_rgb;
+    int32_t D;       /* trunk depth (8)                                         */
+    int32_t skip;    /* layer index after whose ReLU gamma(p) is concatenated    */
+    int32_t rbn, rbh, n_head, n_a;
+} NcwNerfNet;
+
+typedef struct NcwNerfStash {
+    void* gp;        /* 3 blocks: gamma_10(p4) (84)    */
+    void* aux1;      /* 3 blocks                        */
+    void* h[9];      /* h[i], i=1..D: post-relu trunk   */
+    void* featn;     /* rbn: feature_linear output      */
+    void* e[4];      /* rbh                             */
+    void* zp[8];     /* rbn: dL/dz of trunk layer i     */
+    void* zalpha;    /* 1 block: feature 0 = d density  */
+    void* zfeat;     /* rbn                             */
+    void* ze[4];     /* rbh                             */
+    void* zrgb;      /* 1 block: features 0..2          */
+} NcwNerfStash;
+
+/* pts: mode 2 on z_feed (section mid-points, inverted-sphere reparametrisation applied inside), or
+ * x4 != NULL: explicit [n,4] points with pts->rays_d / a indexed per point (NeRF.forward API).
+ * -> density [n] (raw), rgb [n,3] (raw, no sigmoid). */
+int ncw_nerf_fwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, const float* x4, int64_t n, const float* a,
+                 float* density, float* rgb, const NcwNerfStash* stash, void* stream);
+int ncw_nerf_bwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_density,
+                 const float* d_rgb, float* d_a, const NcwNerfStash* stash, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Weight-gradient GEMMs: dense[32*rbx, ld] (f32, forward orientation) += X^T Y over all points,
  * X, Y in stash layout; optional dbias[32*rbx] += column sums of X.  Batched: one launch runs a
  * device table of products (split-K + f32 atomics).

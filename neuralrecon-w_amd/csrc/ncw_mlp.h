@@ -104,3 +104,49 @@ NCW_DEV void cvec_copy(CVec<RB>& d, const CVec<RB>& s) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks__), dim3(256), 0, st, __VA_ARGS__);        \
         NCW_CHECK_LAUNCH();                                                                         \
     } while (0)
+
+// ---- auxiliary input blocks shared by the colour net and the background NeRF ------------------------
+// AUX1 (3 blocks, 96): [gamma_4(view dir) (27) | appearance embedding a (n_a <= 69) | 0...]
+//   (models/neuconw.py:131-139, models/nerf.py:159-160,173)
+template <bool FAST>
+NCW_DEV void build_aux1(CVec<3>& aux, const float (&dir)[3], const float* __restrict__ a_row, int n_a, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * rb + ncw_feat_of(r, 0) + 4 * h;
+            float v;
+            if (32 * rb + ncw_feat_of(r, 0) + 4 < 27) {  // both halves inside the direction encoding
+                v = freq_feature<3, 4, FAST>(dir, f);
+            } else if (32 * rb + ncw_feat_of(r, 0) >= 27) {  // both halves in the embedding / padding
+                v = (f - 27 < n_a) ? a_row[f - 27] : 0.f;
+            } else {
+                v = (f < 27) ? freq_feature<3, 4, FAST>(dir, f) : ((f - 27 < n_a) ? a_row[f - 27] : 0.f);
+            }
+            aux.v[rb][r] = v;
+        }
+}
+
+// d_a[ray][j] += sum over the wave's points of the AUX1-part adjoint (features 27 .. 27+n_a)
+NCW_DEV void accumulate_d_a(const CVec<3>& q, float* __restrict__ d_a, int64_t ray, int n_a, bool valid, int lane) {
+    const int h = lane >> 5;
+    const int64_t r0 = __shfl(ray, 0, 64);
+    const bool uniform = __all((ray == r0) ? 1 : 0);
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (32 * rb + ncw_feat_of(r, 0) + 4 < 27) continue;
+            const int f = 32 * rb + ncw_feat_of(r, 0) + 4 * h;
+            const int j = f - 27;
+            float v = valid ? q.v[rb][r] : 0.f;
+            if (uniform) {
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o, 64);
+                if ((lane & 31) == 0 && j >= 0 && j < n_a) atomicAdd(d_a + ray * n_a + j, v);
+            } else {
+                if (valid && j >= 0 && j < n_a) atomicAdd(d_a + ray * n_a + j, v);
+            }
+        }
+}

@@ -64,6 +64,36 @@ class NcwWgradDesc(C.Structure):
                 ("rbx", C.c_int32), ("rby", C.c_int32), ("ld", C.c_int32), ("_pad", C.c_int32)]
 
 
+class NcwColorNet(C.Structure):
+    _fields_ = [("w_f", C.c_void_p), ("wt_f", C.c_void_p), ("b_f", C.c_void_p),
+                ("w_e", C.c_void_p * 4), ("wt_e", C.c_void_p * 4), ("b_e", C.c_void_p * 4),
+                ("w_l", C.c_void_p * 8), ("wt_l", C.c_void_p * 8), ("b_l", C.c_void_p * 8),
+                ("n_head", C.c_int32), ("n_lin", C.c_int32), ("rbf", C.c_int32), ("rbh", C.c_int32),
+                ("rbc", C.c_int32), ("n_a", C.c_int32)]
+
+
+class NcwColorStash(C.Structure):
+    _fields_ = [("aux1", C.c_void_p), ("aux2", C.c_void_p), ("f", C.c_void_p), ("e", C.c_void_p * 4),
+                ("x", C.c_void_p * 8), ("zf", C.c_void_p), ("ze", C.c_void_p * 4), ("zx", C.c_void_p * 8),
+                ("zo", C.c_void_p)]
+
+
+class NcwNerfNet(C.Structure):
+    _fields_ = [("w_p", C.c_void_p * 8), ("wt_p", C.c_void_p * 8), ("b_p", C.c_void_p * 8),
+                ("w_alpha", C.c_void_p), ("wt_alpha", C.c_void_p), ("b_alpha", C.c_void_p),
+                ("w_feat", C.c_void_p), ("wt_feat", C.c_void_p), ("b_feat", C.c_void_p),
+                ("w_a", C.c_void_p * 4), ("wt_a", C.c_void_p * 4), ("b_a", C.c_void_p * 4),
+                ("w_rgb", C.c_void_p), ("wt_rgb", C.c_void_p), ("b_rgb", C.c_void_p),
+                ("D", C.c_int32), ("skip", C.c_int32), ("rbn", C.c_int32), ("rbh", C.c_int32),
+                ("n_head", C.c_int32), ("n_a", C.c_int32)]
+
+
+class NcwNerfStash(C.Structure):
+    _fields_ = [("gp", C.c_void_p), ("aux1", C.c_void_p), ("h", C.c_void_p * 9), ("featn", C.c_void_p),
+                ("e", C.c_void_p * 4), ("zp", C.c_void_p * 8), ("zalpha", C.c_void_p), ("zfeat", C.c_void_p),
+                ("ze", C.c_void_p * 4), ("zrgb", C.c_void_p)]
+
+
 def _ptr_struct(name, fields_ptr, fields_other=()):
     return type(name, (C.Structure,), {"_fields_": [(f, C.c_void_p) for f in fields_ptr] + list(fields_other)})
 
@@ -88,6 +118,15 @@ NcwCompositeGrad = _ptr_struct(
 
 _VP = C.c_void_p
 _PROTOS = {
+    "ncw_color_fwd": (C.c_int, [C.POINTER(NcwColorNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NcwColorStash), C.c_void_p]),
+    "ncw_color_bwd": (C.c_int, [C.POINTER(NcwColorNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NcwColorStash),
+                                C.c_void_p]),
+    "ncw_nerf_fwd": (C.c_int, [C.POINTER(NcwNerfNet), C.c_int, C.POINTER(NcwPoints), C.c_void_p, C.c_int64,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NcwNerfStash), C.c_void_p]),
+    "ncw_nerf_bwd": (C.c_int, [C.POINTER(NcwNerfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.POINTER(NcwNerfStash), C.c_void_p]),
     "ncw_sdf_fwd": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p, C.c_void_p,
                               C.POINTER(NcwSdfStash), C.c_void_p]),
     "ncw_sdf_bwd": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p, C.c_void_p,

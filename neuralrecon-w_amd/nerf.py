@@ -1,0 +1,167 @@
+"""Host-side mirror of the reference's models/nerf.py NeRF (background network): same ctor,
+same state_dict keys; compute in libneuconw_hip.so (ncw_nerf_fwd / ncw_nerf_bwd)."""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import lib as L
+from .neuconw import _PackedNet, _wvb, default_prec, points_struct
+from .packing import PackPlan
+from .stash import StashArena
+
+
+class NeRF(_PackedNet):
+    """models/nerf.py:86-183 with use_viewdirs=True, encode_appearance=True, d_in=4 (inverted
+    sphere), multires=10, multires_view=4 -- the configuration neuconw_system.py:90-103 builds."""
+
+    def __init__(self, D=8, W=256, d_in=3, d_in_view=3, multires=0, multires_view=0, output_ch=4, skips=[4],
+                 in_channels_a=48, in_channels_dir=27, encode_appearance=False, use_viewdirs=False):
+        super().__init__()
+        if not (use_viewdirs and encode_appearance and d_in == 4 and d_in_view == 3 and multires == 10
+                and multires_view == 4):
+            raise NotImplementedError("HIP NeRF kernels implement the background configuration of "
+                                      "lightning_modules/neuconw_system.py:90-103 only")
+        if W not in (64, 256) or D < 2 or D > 8 or len(skips) != 1 or not (0 <= skips[0] < D - 1) or in_channels_a > 69:
+            raise NotImplementedError("W in {64,256}, 2<=D<=8, one skip, n_a<=69")
+        self.D, self.W, self.skips = D, W, list(skips)
+        self.in_channels_a, self.in_channels_dir = in_channels_a, in_channels_dir
+        self.input_ch, self.input_ch_view = 4 + 4 * 2 * multires, 3 + 3 * 2 * multires_view
+        self.encode_appearance, self.use_viewdirs = encode_appearance, use_viewdirs
+        # same construction order as the reference (nerf.py:127-154)
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(self.input_ch, W)]
+            + [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + self.input_ch, W) for i in range(D - 1)])
+        od = OrderedDict([("static_linear_0", nn.Linear(W + in_channels_dir + in_channels_a, W // 2))])
+        for i in range(1, D // 2):
+            od["static_linear_%d" % i] = nn.Linear(W // 2, W // 2)
+        self.apperence_encoding = nn.Sequential(od)
+        self.views_linears = nn.ModuleList([nn.Linear(self.input_ch_view + W, W // 2)])  # dead (nerf.py:143,175-179)
+        self.feature_linear = nn.Linear(W, W)
+        self.alpha_linear = nn.Linear(W, 1)
+        self.rgb_linear = nn.Linear(W // 2, 3)
+        self._init_plans()
+
+    @property
+    def n_head(self):
+        return len(self.apperence_encoding)
+
+    def _build_plan(self, prec, dev):
+        RBN, RBH, W, A, E = self.W // 32, self.W // 64, self.W, self.in_channels_a, self.input_ch
+        plan = PackPlan(dev, prec)
+        net = L.NcwNerfNet()
+        sl = {}
+
+        def full(name, mod, rb_out, rb_in, segs):
+            v, g, b = _wvb(mod)
+            m, bs, mt = plan.new_matrix(rb_out, rb_in), plan.new_bias(rb_out), plan.new_matrix(rb_in, rb_out)
+            dn = plan.new_dense_grad(rb_out, rb_in)
+            plan.add_pack(v, g, b, m, bs, segs)
+            plan.add_pack(v, g, None, mt, None, segs, transpose=True)
+            plan.add_unpack(v, g, b, dn, segs)
+            sl[name] = (m, bs, mt, dn)
+
+        full("p0", self.pts_linears[0], RBN, 3, [(0, E, 0)])
+        for i in range(1, self.D):
+            if i == self.skips[0] + 1:  # input = cat([gamma(p), h])  (nerf.py:166-167)
+                full("p%d" % i, self.pts_linears[i], RBN, RBN + 3, [(E, W, 0), (0, E, 32 * RBN)])
+            else:
+                full("p%d" % i, self.pts_linears[i], RBN, RBN, [(0, W, 0)])
+        full("alpha", self.alpha_linear, 1, RBN, [(0, W, 0)])
+        full("feat", self.feature_linear, RBN, RBN, [(0, W, 0)])
+        full("a0", self.apperence_encoding[0], RBH, RBN + 3, [(0, W, 0), (W, 27 + A, 32 * RBN)])
+        for i in range(1, self.n_head):
+            full("a%d" % i, self.apperence_encoding[i], RBH, RBH, [(0, W // 2, 0)])
+        full("rgb", self.rgb_linear, 1, RBH, [(0, W // 2, 0)])
+        plan.finalize()
+
+        def trip(name):
+            s = sl[name]
+            return plan.mat_ptr(s[0]), plan.bias_ptr(s[1]), plan.mat_ptr(s[2])
+
+        for i in range(self.D):
+            net.w_p[i], net.b_p[i], net.wt_p[i] = trip("p%d" % i)
+        net.w_alpha, net.b_alpha, net.wt_alpha = trip("alpha")
+        net.w_feat, net.b_feat, net.wt_feat = trip("feat")
+        for i in range(self.n_head):
+            net.w_a[i], net.b_a[i], net.wt_a[i] = trip("a%d" % i)
+        net.w_rgb, net.b_rgb, net.wt_rgb = trip("rgb")
+        net.D, net.skip, net.rbn, net.rbh, net.n_head, net.n_a = self.D, self.skips[0], RBN, RBH, self.n_head, A
+        plan.net, plan.slots = net, sl
+        return plan
+
+    def fwd_stash(self, pts, n, prec, a, x4=None):
+        dev = self._first_param().device
+        plan = self.packed(prec)
+        RBN, RBH = self.W // 32, self.W // 64
+        ar = StashArena(dev, prec, n)
+        ids = dict(gp=ar.new(3), aux1=ar.new(3), featn=ar.new(RBN), zalpha=ar.new(1), zfeat=ar.new(RBN),
+                   zrgb=ar.new(1))
+        ids["h"] = {i: ar.new(RBN) for i in range(1, self.D + 1)}
+        ids["zp"] = [ar.new(RBN) for _ in range(self.D)]
+        ids["e"] = [ar.new(RBH) for _ in range(self.n_head)]
+        ids["ze"] = [ar.new(RBH) for _ in range(self.n_head)]
+        ar.allocate()
+        st = L.NcwNerfStash()
+        for k in ("gp", "aux1", "featn", "zalpha", "zfeat", "zrgb"):
+            setattr(st, k, ar.ptr(ids[k]))
+        for i, v in ids["h"].items():
+            st.h[i] = ar.ptr(v)
+        for k in ("zp", "e", "ze"):
+            for i, v in enumerate(ids[k]):
+                getattr(st, k)[i] = ar.ptr(v)
+        density = torch.empty(n, device=dev, dtype=torch.float32)
+        rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
+        a = a.contiguous().float()
+        x4c = x4.contiguous().float() if x4 is not None else None
+        L.check(L.get_lib().ncw_nerf_fwd(plan.net, prec, pts, L.ptr(x4c), n, L.ptr(a), L.ptr(density), L.ptr(rgb), st,
+                                         L.stream_ptr(dev)), "ncw_nerf_fwd")
+        return density, rgb, dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, keep=(a, x4c))
+
+    def bwd_stash(self, ctx, d_density, d_rgb, d_a):
+        dev = self._first_param().device
+        d_density = d_density.contiguous().float()
+        d_rgb = d_rgb.contiguous().float()
+        L.check(L.get_lib().ncw_nerf_bwd(ctx["plan"].net, ctx["prec"], ctx["pts"], ctx["n"], L.ptr(d_density),
+                                         L.ptr(d_rgb), L.ptr(d_a), ctx["stash"], L.stream_ptr(dev)), "ncw_nerf_bwd")
+        ctx["_keep_bwd"] = (d_density, d_rgb)
+
+    def add_wgrads(self, ctx, batch):
+        plan, ar, ids, sl = ctx["plan"], ctx["arena"], ctx["ids"], ctx["plan"].slots
+        RBN, RBH = self.W // 32, self.W // 64
+        P = ar.ptr
+
+        def dn(name):
+            d = sl[name][3]
+            return plan.dense_ptr(d), plan.dense_ld(d), plan.dense_bias_ptr(d)
+
+        dp, ld, db = dn("p0")
+        batch.add(P(ids["zp"][0]), RBN, P(ids["gp"]), 3, dp, ld, db)
+        for i in range(1, self.D):
+            dp, ld, db = dn("p%d" % i)
+            batch.add(P(ids["zp"][i]), RBN, P(ids["h"][i]), RBN, dp, ld, db)
+            if i == self.skips[0] + 1:
+                batch.add(P(ids["zp"][i]), RBN, P(ids["gp"]), 3, dp + 4 * 32 * RBN, ld)
+        hD = P(ids["h"][self.D])
+        dp, ld, db = dn("alpha")
+        batch.add(P(ids["zalpha"]), 1, hD, RBN, dp, ld, db)
+        dp, ld, db = dn("feat")
+        batch.add(P(ids["zfeat"]), RBN, hD, RBN, dp, ld, db)
+        dp, ld, db = dn("a0")
+        batch.add(P(ids["ze"][0]), RBH, P(ids["featn"]), RBN, dp, ld, db)
+        batch.add(P(ids["ze"][0]), RBH, P(ids["aux1"]), 3, dp + 4 * 32 * RBN, ld)
+        for i in range(1, self.n_head):
+            dp, ld, db = dn("a%d" % i)
+            batch.add(P(ids["ze"][i]), RBH, P(ids["e"][i - 1]), RBH, dp, ld, db)
+        dp, ld, db = dn("rgb")
+        batch.add(P(ids["zrgb"]), 1, P(ids["e"][self.n_head - 1]), RBH, dp, ld, db)
+
+    @torch.no_grad()
+    def forward(self, input_pts, input_views, embedding_a, prec=None):
+        """NeRF.forward(pts4 [N,4], views [N,3], a [N,A]) -> (alpha [N,1], rgb [N,3])  (nerf.py:156-182);
+        inference entry point -- training goes through NeuconWRenderer.render."""
+        prec = default_prec() if prec is None else prec
+        n = input_pts.shape[0]
+        pts = points_struct(x=input_pts[:, :3].contiguous(), rays_d=input_views.contiguous().float())
+        density, rgb, _ = self.fwd_stash(pts, n, prec, embedding_a, x4=input_pts)
+        return density.reshape(n, 1), rgb

@@ -261,3 +261,221 @@ class SDFNetwork(nn.Module):
         batch.add(P(ids["dfeat"]), RB, hl, RB, plan.dense_ptr(dnf), plan.dense_ld(dnf), plan.dense_bias_ptr(dnf))
         batch.add(P(ids["zsdf"]), 1, hl, RB, plan.dense_ptr(dn), plan.dense_ld(dn), plan.dense_bias_ptr(dn))
         batch.add(P(ids["one"]), 1, P(ids["qbar"][Lm - 1]), RB, plan.dense_ptr(dn), plan.dense_ld(dn))
+
+
+class _PackedNet(nn.Module):
+    """Shared plan/pack caching for the parameter-holder modules."""
+
+    def _init_plans(self):
+        self._plans = {}
+
+    def _param_version(self):
+        return tuple(p._version for p in self.parameters())
+
+    def _first_param(self):
+        return next(self.parameters())
+
+    def plan(self, prec):
+        dev = self._first_param().device
+        key = (prec, str(dev))
+        p = self._plans.get(key)
+        if p is None:
+            p = self._build_plan(prec, dev)
+            p.packed_version = None
+            self._plans[key] = p
+        return p
+
+    def packed(self, prec):
+        plan = self.plan(prec)
+        ver = (self._param_version(), plan.param_key())
+        if plan.packed_version != ver:
+            plan.pack()
+            plan.packed_version = (self._param_version(), plan.param_key())
+        return plan
+
+
+class RenderingNetwork(_PackedNet):
+    """models/neuconw.py:59-170, `encode_apperence=True`, mode "idr" (the only shipped configuration)."""
+
+    def __init__(self, d_feature, mode, d_in, d_out, d_hidden, n_layers, head_channels=128, in_channels_dir_a=48,
+                 static_head_layers=2, weight_norm=True, multires_view=4, squeeze_out=True, encode_apperence=True):
+        super().__init__()
+        if mode != "idr" or not encode_apperence or d_in != 9 or d_out != 3 or multires_view != 4 or not weight_norm \
+                or not squeeze_out:
+            raise NotImplementedError("HIP colour kernels implement mode='idr', encode_apperence=True, d_in=9, d_out=3")
+        if (d_feature // 32, head_channels // 32, d_hidden // 32) not in ((2, 1, 2), (2, 4, 8), (8, 4, 8), (16, 4, 8)) \
+                or d_feature % 32 or head_channels % 32 or d_hidden % 32:
+            raise NotImplementedError("unsupported colour-net widths %s" % ((d_feature, head_channels, d_hidden),))
+        if in_channels_dir_a > 69 or static_head_layers > 4 or n_layers > 7:
+            raise NotImplementedError("n_a <= 69, static_head_layers <= 4, n_layers <= 7")
+        self.d_feature, self.head_channels, self.d_hidden = d_feature, head_channels, d_hidden
+        self.n_a, self.n_head, self.mode = in_channels_dir_a, static_head_layers, mode
+        dims = [d_in + head_channels - 3] + [d_hidden for _ in range(n_layers)] + [d_out]
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):  # same order / RNG use as the reference (:99-107)
+            setattr(self, "lin" + str(l), WNLinear(nn.Linear(dims[l], dims[l + 1])))
+        from collections import OrderedDict
+
+        od = OrderedDict()
+        od["static_linear_0"] = PlainLinear(nn.Linear(d_feature + in_channels_dir_a + 27, head_channels))
+        for i in range(1, static_head_layers):
+            od["static_linear_%d" % i] = PlainLinear(nn.Linear(head_channels, head_channels))
+        self.static_encoding = nn.Sequential(od)
+        self.xyz_encoding_final = PlainLinear(nn.Linear(d_feature, d_feature))
+        self._init_plans()
+
+    @property
+    def n_lin(self):
+        return self.num_layers - 1
+
+    def _build_plan(self, prec, dev):
+        RBF, RBH, RBC = self.d_feature // 32, self.head_channels // 32, self.d_hidden // 32
+        W, HC, A = self.d_feature, self.head_channels, self.n_a
+        plan = PackPlan(dev, prec)
+        net = L.NcwColorNet()
+        sl = {}
+
+        def full(name, mod, rb_out, rb_in, segs):
+            v, g, b = _wvb(mod)
+            m, bs, mt = plan.new_matrix(rb_out, rb_in), plan.new_bias(rb_out), plan.new_matrix(rb_in, rb_out)
+            dn = plan.new_dense_grad(rb_out, rb_in)
+            plan.add_pack(v, g, b, m, bs, segs)
+            plan.add_pack(v, g, None, mt, None, segs, transpose=True)
+            plan.add_unpack(v, g, b, dn, segs)
+            sl[name] = (m, bs, mt, dn)
+
+        full("f", self.xyz_encoding_final, RBF, RBF, [(0, W, 0)])
+        full("e0", self.static_encoding[0], RBH, RBF + 3, [(0, W, 0), (W, 27 + A, 32 * RBF)])
+        for i in range(1, self.n_head):
+            full("e%d" % i, self.static_encoding[i], RBH, RBH, [(0, HC, 0)])
+        full("l0", self.lin0, RBC, RBH + 1, [(6, HC, 0), (0, 6, 32 * RBH)])
+        for l in range(1, self.n_lin - 1):
+            full("l%d" % l, getattr(self, "lin%d" % l), RBC, RBC, [(0, self.d_hidden, 0)])
+        full("l%d" % (self.n_lin - 1), getattr(self, "lin%d" % (self.n_lin - 1)), 1, RBC, [(0, self.d_hidden, 0)])
+        plan.finalize()
+        net.w_f, net.b_f, net.wt_f = plan.mat_ptr(sl["f"][0]), plan.bias_ptr(sl["f"][1]), plan.mat_ptr(sl["f"][2])
+        for i in range(self.n_head):
+            s = sl["e%d" % i]
+            net.w_e[i], net.b_e[i], net.wt_e[i] = plan.mat_ptr(s[0]), plan.bias_ptr(s[1]), plan.mat_ptr(s[2])
+        for l in range(self.n_lin):
+            s = sl["l%d" % l]
+            net.w_l[l], net.b_l[l], net.wt_l[l] = plan.mat_ptr(s[0]), plan.bias_ptr(s[1]), plan.mat_ptr(s[2])
+        net.n_head, net.n_lin, net.rbf, net.rbh, net.rbc, net.n_a = self.n_head, self.n_lin, RBF, RBH, RBC, A
+        plan.net, plan.slots = net, sl
+        return plan
+
+    def fwd_stash(self, pts, n, prec, normals, a, feat_ptr):
+        dev = self._first_param().device
+        plan = self.packed(prec)
+        RBF, RBH, RBC = self.d_feature // 32, self.head_channels // 32, self.d_hidden // 32
+        ar = StashArena(dev, prec, n)
+        ids = dict(aux1=ar.new(3), aux2=ar.new(1), f=ar.new(RBF), zf=ar.new(RBF), zo=ar.new(1))
+        ids["e"] = [ar.new(RBH) for _ in range(self.n_head)]
+        ids["ze"] = [ar.new(RBH) for _ in range(self.n_head)]
+        ids["x"] = [ar.new(RBC) for _ in range(self.n_lin - 1)]
+        ids["zx"] = [ar.new(RBC) for _ in range(self.n_lin - 1)]
+        ar.allocate()
+        st = L.NcwColorStash()
+        for k in ("aux1", "aux2", "f", "zf", "zo"):
+            setattr(st, k, ar.ptr(ids[k]))
+        for k in ("e", "ze", "x", "zx"):
+            for i, v in enumerate(ids[k]):
+                getattr(st, k)[i] = ar.ptr(v)
+        rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
+        normals = normals.contiguous().float()
+        a = a.contiguous().float()
+        L.check(L.get_lib().ncw_color_fwd(plan.net, prec, pts, n, L.ptr(normals), L.ptr(a), feat_ptr, L.ptr(rgb), st,
+                                          L.stream_ptr(dev)), "ncw_color_fwd")
+        return rgb, dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, rgb=rgb, feat_ptr=feat_ptr,
+                         keep=(normals, a))
+
+    def bwd_stash(self, ctx, d_rgb, d_grad, d_a, dfeat_ptr):
+        """d_grad [n,3] is updated in place (+= d normals); d_a [R,n_a] accumulates (atomics)."""
+        dev = self._first_param().device
+        d_rgb = d_rgb.contiguous().float()
+        assert d_grad.is_contiguous() and d_a.is_contiguous()
+        L.check(L.get_lib().ncw_color_bwd(ctx["plan"].net, ctx["prec"], ctx["pts"], ctx["n"], L.ptr(ctx["rgb"]),
+                                          L.ptr(d_rgb), L.ptr(d_grad), L.ptr(d_a), dfeat_ptr, ctx["stash"],
+                                          L.stream_ptr(dev)), "ncw_color_bwd")
+        ctx["_keep_bwd"] = d_rgb
+
+    def add_wgrads(self, ctx, batch):
+        plan, ar, ids, sl = ctx["plan"], ctx["arena"], ctx["ids"], ctx["plan"].slots
+        RBF, RBH, RBC = self.d_feature // 32, self.head_channels // 32, self.d_hidden // 32
+        P = ar.ptr
+
+        def dn(name):
+            d = sl[name][3]
+            return plan.dense_ptr(d), plan.dense_ld(d), plan.dense_bias_ptr(d)
+
+        dp, ld, db = dn("f")
+        batch.add(P(ids["zf"]), RBF, ctx["feat_ptr"], RBF, dp, ld, db)
+        dp, ld, db = dn("e0")
+        batch.add(P(ids["ze"][0]), RBH, P(ids["f"]), RBF, dp, ld, db)
+        batch.add(P(ids["ze"][0]), RBH, P(ids["aux1"]), 3, dp + 4 * 32 * RBF, ld)
+        for i in range(1, self.n_head):
+            dp, ld, db = dn("e%d" % i)
+            batch.add(P(ids["ze"][i]), RBH, P(ids["e"][i - 1]), RBH, dp, ld, db)
+        dp, ld, db = dn("l0")
+        batch.add(P(ids["zx"][0]), RBC, P(ids["e"][self.n_head - 1]), RBH, dp, ld, db)
+        batch.add(P(ids["zx"][0]), RBC, P(ids["aux2"]), 1, dp + 4 * 32 * RBH, ld)
+        for l in range(1, self.n_lin - 1):
+            dp, ld, db = dn("l%d" % l)
+            batch.add(P(ids["zx"][l]), RBC, P(ids["x"][l - 1]), RBC, dp, ld, db)
+        dp, ld, db = dn("l%d" % (self.n_lin - 1))
+        batch.add(P(ids["zo"]), 1, P(ids["x"][self.n_lin - 2]), RBC, dp, ld, db)
+
+
+class SingleVarianceNetwork(nn.Module):
+    """models/neuconw.py:173-179: inv_s = exp(10 * variance)."""
+
+    def __init__(self, init_val):
+        super().__init__()
+        self.register_parameter("variance", nn.Parameter(torch.tensor(float(init_val))))
+
+    def inv_s(self):
+        return torch.exp(self.variance * 10.0).clamp(1e-6, 1e6).reshape(1)
+
+    def forward(self, x):
+        return torch.ones([len(x), 1], device=x.device) * torch.exp(self.variance * 10.0)
+
+
+class NeuconW(nn.Module):
+    """models/neuconw.py:299-376.  Same ctor, same state_dict keys (incl. the dead
+    `xyz_encoding_final = nn.Linear(512, 512)`, :319)."""
+
+    def __init__(self, sdfNet_config, colorNet_config, SNet_config, in_channels_a, encode_a):
+        super().__init__()
+        self.sdfNet_config, self.colorNet_config, self.SNet_config = sdfNet_config, colorNet_config, SNet_config
+        self.in_channels_a, self.encode_a = in_channels_a, encode_a
+        self.sdf_net = SDFNetwork(**sdfNet_config)
+        self.xyz_encoding_final = nn.Linear(512, 512)  # never used, never receives a gradient (reference :319)
+        self.deviation_network = SingleVarianceNetwork(**SNet_config)
+        self.color_net = RenderingNetwork(**colorNet_config, in_channels_dir_a=in_channels_a,
+                                          encode_apperence=encode_a)
+
+    def sdf(self, input_xyz, prec=None):
+        return self.sdf_net.sdf(input_xyz, prec)
+
+    @torch.no_grad()
+    def gradient(self, x, prec=None):
+        prec = default_prec() if prec is None else prec
+        xf = x.reshape(-1, 3).float().contiguous()
+        _, grad, _ = self.sdf_net.fwd_stash(points_struct(x=xf), xf.shape[0], prec)
+        return grad
+
+    @torch.no_grad()
+    def forward(self, x, prec=None):
+        """x [R,S,3+3+A] -> (rgb [R,S,3], inv_s [1,1], sdf [R,S], grad [R,S,3]) -- inference
+        (renderer.rgb(), visualisation).  The differentiable training path is NeuconWRenderer.render."""
+        prec = default_prec() if prec is None else prec
+        R, S, _ = x.shape
+        n = R * S
+        xyz = x[..., 0:3].reshape(n, 3).float().contiguous()
+        dirs = x[..., 3:6].reshape(n, 3).float().contiguous()
+        a = x[..., 6:].reshape(n, -1).float().contiguous()
+        pts = points_struct(x=xyz, rays_d=dirs)
+        sdf, grad, sctx = self.sdf_net.fwd_stash(pts, n, prec)
+        rgb, _ = self.color_net.fwd_stash(pts, n, prec, grad, a, sctx["arena"].ptr(sctx["ids"]["feat"]))
+        inv_s = self.deviation_network.inv_s().reshape(1, 1)
+        return rgb.reshape(R, S, 3), inv_s, sdf.reshape(R, S), grad.reshape(R, S, 3)

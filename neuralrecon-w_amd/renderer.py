@@ -1,0 +1,296 @@
+"""Host-side mirror of the reference's rendering/renderer.py `NeuconWRenderer`: same constructor
+keywords, same `render()` output dictionary, same helper methods (`sdf`, `rgb`, `get_octree`) and
+mutable attributes -- the body runs the hand-written gfx950 kernels of libneuconw_hip.so.
+
+Only per-RAY glue (ray normalisation, the embedding lookup, the BCE / depth terms on [R]-sized
+tensors) stays in torch; everything per ray-SAMPLE (sampling, the three MLPs forward and backward,
+compositing) is HIP.  Autograd sees ONE node (`_RenderFn`) whose backward launches the fused
+backward kernels and returns the gradients of every parameter.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import yaml
+
+from . import lib as L
+from . import rayops
+from .neuconw import default_prec, points_struct
+from .stash import WgradBatch
+
+SKY_LABEL_ID = 2  # datasets/mask_utils.py: get_label_id_mapping()["sky"]
+LABEL_IDS = {"sky": 2}
+
+
+def _label_id(name):
+    if name in LABEL_IDS:
+        return LABEL_IDS[name]
+    raise NotImplementedError("label '%s': only the ADE20K ids used by the shipped configs are built in; "
+                              "extend neuralrecon_w_amd.renderer.LABEL_IDS" % name)
+
+
+class _RenderFn(torch.autograd.Function):
+    """render_core_outside + render_core (renderer.py:157-228, 570-783) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, rdr, rays_o, rays_d, z, z_out, sample_dist, cos_anneal, background_rgb, a_embedded, variance,
+                *params):
+        prec = rdr.prec
+        neuconw, nerf = rdr.neuconw, rdr.nerf
+        R, S = z.shape
+        dev = z.device
+        inv_s = torch.exp(variance.detach() * 10.0).clamp(1e-6, 1e6).reshape(1).float()
+        a_det = a_embedded.detach().contiguous().float()
+        use_bg = rdr.render_bg and rdr.n_outside > 0 and z_out is not None
+        z_feed = density = bg_rgb = nctx = None
+        if use_bg:
+            z_feed, _ = rayops.sort_merge(z, z_out)
+            pts_bg = points_struct(rays_o=rays_o, rays_d=rays_d, z=z_feed, sample_dist=sample_dist, mode=2)
+            M = z_feed.shape[1]
+            density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det)
+            density, bg_rgb = density.view(R, M), bg_rgb.view(R, M, 3)
+        pts_in = points_struct(rays_o=rays_o, rays_d=rays_d, z=z, sample_dist=sample_dist, mode=2)
+        sdf, grad, sctx = neuconw.sdf_net.fwd_stash(pts_in, R * S, prec)
+        feat_ptr = sctx["arena"].ptr(sctx["ids"]["feat"])
+        rgb, cctx = neuconw.color_net.fwd_stash(pts_in, R * S, prec, grad, a_det, feat_ptr)
+        comp = rayops.CompositeCtx(rays_o, rays_d, z, sample_dist, sdf.view(R, S), grad.view(R, S, 3),
+                                   rgb.view(R, S, 3), inv_s, cos_anneal, z_feed, density, bg_rgb, background_rgb,
+                                   rdr.trim_sphere)
+        o = comp.forward()
+        ctx.rdr, ctx.comp, ctx.sctx, ctx.cctx, ctx.nctx = rdr, comp, sctx, cctx, nctx
+        ctx.inv_s, ctx.n_params, ctx.use_bg = inv_s, len(params), use_bg
+        ctx.a_shape = a_embedded.shape
+        ctx.variance = variance
+        ctx.params = params
+        extras = (o["color_sphere"], o["color_bg"], o["weights"], o["cdf"], o["inside"], o["normals"],
+                  sdf.view(R, S), grad.view(R, S, 3), o["mid_z"], o["dists"], o["eik"][:, 1].contiguous(), inv_s)
+        ctx.mark_non_differentiable(*extras)
+        return (o["color"], o["weights_sum"], o["depth"], o["eik"][:, 0].contiguous()) + extras
+
+    @staticmethod
+    def backward(ctx, d_color, d_wsum, d_depth, d_eik, *unused):
+        rdr, comp, sctx, cctx, nctx = ctx.rdr, ctx.comp, ctx.sctx, ctx.cctx, ctx.nctx
+        neuconw, nerf = rdr.neuconw, rdr.nerf
+        prec = rdr.prec
+        dev = ctx.inv_s.device
+        g = comp.backward(d_color, d_wsum, d_depth, d_eik)
+        R, S = comp.R, comp.S
+        d_a = torch.zeros(ctx.a_shape, device=dev, dtype=torch.float32)
+        d_grad = g["d_grad"].view(R * S, 3)
+        dfeat_ptr = sctx["arena"].ptr(sctx["ids"]["dfeat"])
+        neuconw.color_net.bwd_stash(cctx, g["d_rgb"].view(R * S, 3), d_grad, d_a, dfeat_ptr)
+        neuconw.sdf_net.bwd_stash(sctx, g["d_sdf"].view(R * S), d_grad)
+        plans = [sctx["plan"], cctx["plan"]]
+        b_in = WgradBatch(dev, prec, R * S)
+        neuconw.sdf_net.add_wgrads(sctx, b_in)
+        neuconw.color_net.add_wgrads(cctx, b_in)
+        b_bg = None
+        if ctx.use_bg:
+            M = comp.S + comp.O
+            nerf.bwd_stash(nctx, g["d_density"].view(R * M), g["d_bg_rgb"].view(R * M, 3), d_a)
+            plans.append(nctx["plan"])
+            b_bg = WgradBatch(dev, prec, R * M)
+            nerf.add_wgrads(nctx, b_bg)
+        for p in plans:
+            p.g_arena.zero_()
+        b_in.run()
+        if b_bg is not None:
+            b_bg.run()
+        # parameter gradients: one flat buffer, views per parameter (order of ctx.params)
+        sizes = [p.numel() for p in ctx.params]
+        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        views, off = {}, 0
+        out = []
+        for p, n in zip(ctx.params, sizes):
+            v = flat[off:off + n].view(p.shape)
+            views[id(p)] = v
+            out.append(v)
+            off += n
+        keep = [pl.unpack_grads(views) for pl in plans]
+        ctx._keep = (keep, b_in, b_bg)
+        inv_s = ctx.inv_s
+        live = ((inv_s > 1e-6) & (inv_s < 1e6)).float()
+        d_var = (g["d_inv_s"] * 10.0 * inv_s * live).reshape(ctx.variance.shape)
+        if not ctx.use_bg:  # background parameters were passed but unused
+            pass
+        return (None, None, None, None, None, None, None, None, d_a, d_var) + tuple(out)
+
+
+class NeuconWRenderer:
+    def __init__(self, nerf, neuconw, embeddings, n_samples, n_importance, n_outside, up_sample_steps, perturb,
+                 origin, radius, s_val_base=0, spc_options=None, sample_range=None, boundary_samples=None,
+                 nerf_far_override=False, render_bg=True, trim_sphere=True, save_sample=False,
+                 save_step_sample=False, mesh_mask_list=None, floor_normal=False, depth_loss=False,
+                 floor_labels=None, prec=None):
+        self.nerf, self.neuconw, self.embeddings = nerf, neuconw, embeddings
+        self.n_samples, self.n_importance, self.n_outside = n_samples, n_importance, n_outside
+        self.up_sample_steps, self.perturb, self.s_val_base = up_sample_steps, perturb, s_val_base
+        self.boundary_samples, self.nerf_far_override = boundary_samples, nerf_far_override
+        self.octree_data, self.sample_range, self.fine_octree_data = None, sample_range, None
+        spc_options = spc_options or {}
+        if self.nerf_far_override:  # same coupling as the reference (renderer.py:96-99)
+            self.recontruct_path = spc_options["recontruct_path"]
+            self.min_track_length = spc_options["min_track_length"]
+            self.voxel_size = spc_options["voxel_size"]
+        self.sfm_to_gt = torch.eye(4)
+        scene_config_path = os.path.join(spc_options.get("recontruct_path", ""), "config.yaml")
+        if os.path.isfile(scene_config_path):  # renderer.py:103-112
+            with open(scene_config_path, "r") as f:
+                scene_config = yaml.load(f, Loader=yaml.FullLoader)
+            origin, radius = scene_config["origin"], scene_config["radius"]
+            self.sfm_to_gt = torch.from_numpy(np.array(scene_config["sfm2gt"]))
+        self.origin = torch.from_numpy(np.array(origin, dtype=np.float64))
+        self.radius = radius
+        self.render_bg, self.floor_normal, self.floor_labels = render_bg, floor_normal, floor_labels
+        self.depth_loss, self.save_sample, self.trim_sphere = depth_loss, save_sample, trim_sphere
+        self.mesh_mask_list = mesh_mask_list
+        self.save_step_sample = save_step_sample
+        if floor_normal:
+            raise NotImplementedError("floor_normal loss is not on the HIP path (all scene yamls ship FLOOR_NORMAL: False)")
+        if save_sample or save_step_sample:
+            raise NotImplementedError("debug PLY dumps (open3d) are out of scope")
+        self.prec = default_prec() if prec is None else prec
+
+    # ---- sampler (renderer.py:458-568, under no_grad) -------------------------------------------
+    def _sdf_rays(self, rays_o, rays_d, z):
+        R, n = z.shape
+        out = torch.empty(R, n, device=z.device, dtype=torch.float32)
+        plan = self.neuconw.sdf_net.packed(self.prec)
+        L.check(L.get_lib().ncw_sdf_infer_rays(plan.net, self.prec, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), R, n,
+                                               L.ptr(out), L.stream_ptr(z.device)), "ncw_sdf_infer_rays")
+        return out
+
+    def up_sample(self, rays_o, rays_d, z_vals, sdf, n_importance, inv_s, step=0):
+        return rayops.upsample(rays_o, rays_d, z_vals, sdf, n_importance, inv_s)
+
+    def cat_z_vals(self, rays_o, rays_d, z_vals, new_z_vals, sdf, last=False):
+        if last:
+            return rayops.sort_merge(z_vals, new_z_vals)[0], sdf
+        new_sdf = self._sdf_rays(rays_o, rays_d, new_z_vals.contiguous())
+        return rayops.sort_merge(z_vals, new_z_vals, sdf, new_sdf)
+
+    @torch.no_grad()
+    def sparse_sampler(self, rays_o, rays_d, near, far, perturb, _rand=None):
+        dev = rays_o.device
+        R = rays_o.shape[0]
+        rays_o, rays_d = rays_o.contiguous().float(), rays_d.contiguous().float()
+        if self.nerf_far_override:
+            if self.octree_data is None:
+                self.octree_data = self.get_octree(dev)
+            near, far, _ = self.get_near_far_octree(self.octree_data, rays_o, rays_d, near, far)
+        s_near, s_far = near, far
+        if self.fine_octree_data is not None:
+            s_near, s_far, _ = self.get_near_far_sdf(self.fine_octree_data, rays_o, rays_d, near, far)
+        n_out = self.n_outside if (self.render_bg and self.n_outside > 0) else 0
+        rs = ro = None
+        if perturb > 0:
+            if _rand is not None:
+                rs, ro = _rand
+            else:  # same draw order as renderer.py:499,506-508
+                rs = torch.rand([R, 1], device=dev)
+                ro = torch.rand([R, n_out], device=dev) if n_out > 0 else None
+        z, z_out, sample_dist = rayops.sample_coarse(near, far, s_near, s_far, self.n_samples, n_out, rs, ro)
+        n_samples = self.n_samples
+        if self.n_importance > 0:
+            sdf = self._sdf_rays(rays_o, rays_d, z)
+            for i in range(self.up_sample_steps):
+                z_new = rayops.upsample(rays_o, rays_d, z, sdf, self.n_importance // self.up_sample_steps,
+                                        64 * 2 ** (self.s_val_base + i))
+                z, sdf = self.cat_z_vals(rays_o, rays_d, z, z_new, sdf, last=(i + 1 == self.up_sample_steps))
+            n_samples = self.n_samples + self.n_importance
+        if self.fine_octree_data is not None and self.boundary_samples and self.boundary_samples > 0:
+            zb = rayops.boundary(near, far, z, self.boundary_samples)
+            z, _ = rayops.sort_merge(zb, z)
+        return n_samples, z, z_out, sample_dist
+
+    # ---- voxel guidance (renderer.py:137-155, 380-456): see voxel.py ---------------------------------
+    def get_octree(self, device):
+        from . import voxel
+
+        return voxel.octree_from_sfm(self.recontruct_path, self.min_track_length, self.voxel_size, device)
+
+    def get_near_far_octree(self, octree_data, rays_o, rays_d, near, far):
+        from . import voxel
+
+        o_sfm = (rays_o * self.radius).view(-1, 3) + self.origin.to(rays_o.device).float()
+        vn, vf = voxel.get_near_far(o_sfm, rays_d, octree_data)
+        hit = vn > 0
+        near = torch.where(hit, vn / self.radius, near)
+        far = torch.where(hit, (vf + self.voxel_size) / self.radius, far)
+        return near, far, hit
+
+    def get_near_far_sdf(self, octree_data, rays_o, rays_d, near, far):
+        from . import voxel
+
+        o_sfm = (rays_o * self.radius).view(-1, 3) + self.origin.to(rays_o.device).float()
+        surf, _ = voxel.get_near_far(o_sfm, rays_d, octree_data)
+        miss = surf <= 0
+        rng = self.sample_range * octree_data["voxel_size"]
+        v_near = torch.where(miss, near, (surf - rng) / self.radius)
+        v_far = torch.where(miss, far, (surf + rng) / self.radius)
+        return v_near, v_far, ~miss
+
+    # ---- render (renderer.py:785-916) ---------------------------------------------------------------
+    def _params(self):
+        ps = list(self.neuconw.sdf_net.parameters()) + list(self.neuconw.color_net.parameters())
+        nf = self.nerf
+        ps += [p for n, p in nf.named_parameters() if not n.startswith("views_linears")]
+        return ps
+
+    def render(self, rays, ts, label, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0, _rand=None):
+        device = rays.device
+        if not rays.is_cuda:
+            raise L.NeuconwHipError("NeuconWRenderer.render: rays are not on a GPU; the hot path has no CPU fallback")
+        if self.origin.device != device:
+            self.origin = self.origin.to(device).float()
+            self.sfm_to_gt = self.sfm_to_gt.to(device).float()
+        rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
+        near, far = rays[:, 6:7], rays[:, 7:8]
+        if rays.size(1) >= 10:
+            depth_gt, depth_weight = rays[:, 8], rays[:, 9]
+        else:
+            depth_gt = depth_weight = torch.zeros_like(near).squeeze(-1)
+        rays_o = ((rays_o - self.origin).float() / self.radius).float().contiguous()
+        rays_d = rays_d.float().contiguous()
+        near = (near / self.radius).float()
+        far = (far / self.radius).float()
+        depth_gt = (depth_gt / self.radius).float()
+        a_embedded = self.embeddings["a"](ts)
+        perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
+        n_samples, z_vals, z_vals_outside, sample_dist = self.sparse_sampler(rays_o, rays_d, near, far, perturb, _rand)
+        bgc = background_rgb.reshape(-1)[:3] if background_rgb is not None else None
+        outs = _RenderFn.apply(self, rays_o, rays_d, z_vals, z_vals_outside, sample_dist, float(cos_anneal_ratio), bgc,
+                               a_embedded, self.neuconw.deviation_network.variance, *self._params())
+        (color, wsum, depth, eik_num, color_sphere, color_bg, weights, cdf, inside, normals, sdf, gradients, mid_z,
+         dists, eik_den, inv_s) = outs
+        weights_sum = wsum.unsqueeze(-1)
+        gradient_error = eik_num.sum() / (eik_den.sum() + 1e-5)  # renderer.py:763-765 (batch-global scalar)
+        if self.mesh_mask_list is not None:  # renderer.py:869-877
+            mask = torch.ones_like(near)
+            for name in self.mesh_mask_list:
+                mask[_label_id(name) == label] = 0
+            mask_error = F.binary_cross_entropy(weights_sum.clip(1e-3, 1.0 - 1e-3), mask, reduction="none")
+        else:
+            mask_error = torch.zeros_like(weights_sum)
+        if self.depth_loss and torch.sum(depth_weight > 0) > 0:  # renderer.py:892-897
+            sfm_depth_loss = (((depth - depth_gt) ** 2) * depth_weight)[depth_weight > 0]
+        else:
+            sfm_depth_loss = torch.zeros_like(depth)
+        return {
+            "color": color, "color_sphere": color_sphere, "color_bg": color_bg, "s_val": (1.0 / inv_s).reshape(1, 1),
+            "cdf_fine": cdf, "gradients": gradients, "mask_error": mask_error, "weights": weights,
+            "weights_sum": weights_sum, "weights_max": torch.max(weights, dim=-1, keepdim=True)[0],
+            "gradient_error": torch.ones(1, device=device) * gradient_error, "inside_sphere": inside,
+            "depth": depth, "floor_normal_error": torch.zeros_like(normals), "floor_y_error": torch.zeros_like(normals),
+            "sfm_depth_loss": sfm_depth_loss,
+        }
+
+    # ---- helpers used by NeuconWSystem / extract_mesh (renderer.py:947-961) ---------------------------
+    def sdf(self, pts):
+        return self.neuconw.sdf(pts, self.prec)
+
+    def rgb(self, pts, rays_d, a_embedded):
+        num_points = pts.shape[0]
+        rgb, _, _, _ = self.neuconw(torch.cat([pts, rays_d, a_embedded], -1), self.prec)
+        return rgb.reshape(num_points, 3)
