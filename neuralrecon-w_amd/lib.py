@@ -150,6 +150,28 @@ _PROTOS = {
 
 _lib = None
 
+# Optional per-entry-point HIP-event timing (bench.py's roofline leg): when PROFILE is a dict, every
+# C-ABI call is bracketed by events recorded on torch's current stream (the stream the kernel is
+# launched on) and appended to PROFILE[name].
+PROFILE = None
+
+
+def _wrap_timed(name, fn):
+    def call(*args):
+        if PROFILE is None:
+            return fn(*args)
+        import torch
+
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*args)
+        e1.record()
+        PROFILE.setdefault(name, []).append((e0, e1))
+        return r
+
+    return call
+
+
 
 class NeuconwHipError(RuntimeError):
     pass
@@ -170,15 +192,18 @@ def get_lib():
             "There is no CPU / PyTorch fallback for the hot path." % LIB_PATH
         )
     lib = C.CDLL(LIB_PATH)
+    ns = type("NcwLib", (), {})()
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale: fail loudly
         fn.restype = res
         fn.argtypes = args
+        setattr(ns, name, _wrap_timed(name, fn))
     v = lib.ncw_abi_version()
     if v != ABI_VERSION:
         raise NeuconwHipError("libneuconw_hip.so ABI %d != binding ABI %d: rebuild" % (v, ABI_VERSION))
-    _lib = lib
-    return lib
+    ns._cdll = lib
+    _lib = ns
+    return ns
 
 
 def check(code, what):
