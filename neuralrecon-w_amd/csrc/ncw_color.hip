@@ -17,78 +17,109 @@ NCW_DEV void build_aux2(CVec<1>& aux, const float (&x)[3], const float (&nrm)[3]
 }
 
 template <class P, int RBF, int RBH, int RBC>
-__global__ __launch_bounds__(256) void color_fwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
-                                                        const float* __restrict__ normals, const float* __restrict__ a,
-                                                        const void* __restrict__ feat_stash, float* __restrict__ rgb,
-                                                        NcwColorStash st) {
+struct ColShapes {
+    static constexpr int SLOT = RingSlot<RBC>::bytes;
+    static constexpr int FCB_F = ncw_first_chunk_bytes<P, RBF, 32 * RBF, RBF, SLOT>();
+    static constexpr int FCB_E0 = ncw_first_chunk_bytes<P, RBF + 3, 32 * RBF + 96, RBH, SLOT>();
+    static constexpr int FCB_E = ncw_first_chunk_bytes<P, RBH, 32 * RBH, RBH, SLOT>();
+    static constexpr int FCB_L0 = ncw_first_chunk_bytes<P, RBH + 1, 32 * RBH + 6, RBC, SLOT>();
+    static constexpr int FCB_L = ncw_first_chunk_bytes<P, RBC, 32 * RBC, RBC, SLOT>();
+    static constexpr int FCB_LAST = ncw_first_chunk_bytes<P, RBC, 32 * RBC, 1, SLOT>();
+    static constexpr int FCB_TLAST = ncw_first_chunk_bytes<P, 1, 3, RBC, SLOT>();
+    static constexpr int FCB_TL0 = ncw_first_chunk_bytes<P, RBC, 32 * RBC, RBH + 1, SLOT>();
+    static constexpr int FCB_TE0 = ncw_first_chunk_bytes<P, RBH, 32 * RBH, RBF + 3, SLOT>();
+};
+
+template <class P, int RBF, int RBH, int RBC>
+__global__ __launch_bounds__(64 * NCW_WG_WAVES) void color_fwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
+                                                                      const float* __restrict__ normals,
+                                                                      const float* __restrict__ a,
+                                                                      const void* __restrict__ feat_stash,
+                                                                      float* __restrict__ rgb, NcwColorStash st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
+    typedef ColShapes<P, RBF, RBH, RBC> SH;
+    NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
+    ring_prologue(ring, net.w_f, SH::FCB_F);
     int64_t tile, p, ray;
     bool valid;
-    if (!tile_setup(n, tile, p, valid, lane)) return;
+    tile_setup(n, tile, p, valid, lane);
     float xs[3];
     load_point(src, p, xs, ray);
     const float dir[3] = {src.rays_d[ray * 3 + 0], src.rays_d[ray * 3 + 1], src.rays_d[ray * 3 + 2]};
     const float nrm[3] = {normals[p * 3 + 0], normals[p * 3 + 1], normals[p * 3 + 2]};
 
-    CVec<3> aux1;
-    build_aux1<Fast<P>::v>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
-    stash_store<3>((SE*)st.aux1, tile, aux1, lane);
     Act<P, 3> aux1a;
-    to_act(aux1a, aux1);
-    CVec<1> aux2;
-    build_aux2(aux2, xs, nrm, lane);
-    stash_store<1>((SE*)st.aux2, tile, aux2, lane);
-    Act<P, 1> aux2a;
-    to_act(aux2a, aux2);
-
-    // f = xyz_encoding_final(feat)   (no activation, neuconw.py:128,136)
-    Act<P, RBF> fa;
     {
-        CVec<RBF> ft;
-        stash_load<RBF>(ft, (const SE*)feat_stash, tile, lane);
+        CVec<3> aux1;
+        build_aux1<Fast<P>::v>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
+        stash_store<3>((SE*)st.aux1, tile, aux1, lane);
+        to_act(aux1a, aux1);
+    }
+    Act<P, 1> aux2a;
+    {
+        CVec<1> aux2;
+        build_aux2(aux2, xs, nrm, lane);
+        stash_store<1>((SE*)st.aux2, tile, aux2, lane);
+        to_act(aux2a, aux2);
+    }
+    // f = xyz_encoding_final(feat)   (no activation, neuconw.py:128,136)
+    Act<P, RBF + 3> cat1;
+    {
         Act<P, RBF> fin;
-        to_act(fin, ft);
+#pragma unroll
+        for (int rb = 0; rb < RBF; ++rb) {
+            f32x16 v;
+            stash_load_block(v, (const SE*)feat_stash, tile, RBF, rb, lane);
+            to_act_block<RBF>(fin, rb, v);
+        }
         CVec<RBF> f;
         load_bias(f, net.b_f, lane);
-        mma<RBF, RBF, 32 * RBF>(f, fin, (const WE*)net.w_f, lane);
+        mma_stream<RBF, RBF, 32 * RBF, SH::SLOT>(f, fin, ring, (const WE*)net.w_f, net.w_e[0], SH::FCB_E0, lane);
         stash_store<RBF>((SE*)st.f, tile, f, lane);
+        Act<P, RBF> fa;
         to_act(fa, f);
+        act_concat<RBF, 3>(cat1, fa, aux1a);
     }
     // appearance head (neuconw.py:111-127,137-140)
     Act<P, RBH> ea;
     {
         CVec<RBH> e;
         load_bias(e, net.b_e[0], lane);
-        const WE* w = (const WE*)net.w_e[0];
-        mma<RBF, RBH, 32 * RBF>(e, fa, w, lane);
-        mma<3, RBH, 96>(e, aux1a, w + ncw_packed_elems(RBH, RBF), lane);
+        const void* wn = net.n_head > 1 ? net.w_e[1] : net.w_l[0];
+        const int nb = net.n_head > 1 ? SH::FCB_E : SH::FCB_L0;
+        mma_stream<RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e[0], wn, nb, lane);
         relu_epilogue<P, RBH>(ea, e, (SE*)st.e[0], tile, lane);
         for (int i = 1; i < net.n_head; ++i) {
             load_bias(e, net.b_e[i], lane);
-            mma<RBH, RBH, 32 * RBH>(e, ea, (const WE*)net.w_e[i], lane);
+            const void* wn2 = i + 1 < net.n_head ? net.w_e[i + 1] : net.w_l[0];
+            const int nb2 = i + 1 < net.n_head ? SH::FCB_E : SH::FCB_L0;
+            mma_stream<RBH, RBH, 32 * RBH, SH::SLOT>(e, ea, ring, (const WE*)net.w_e[i], wn2, nb2, lane);
             relu_epilogue<P, RBH>(ea, e, (SE*)st.e[i], tile, lane);
         }
     }
     // trunk (neuconw.py:158-166)
     Act<P, RBC> xa;
     CVec<RBC> x;
+    const int last = net.n_lin - 1;
     {
+        Act<P, RBH + 1> cat2;
+        act_concat<RBH, 1>(cat2, ea, aux2a);
         load_bias(x, net.b_l[0], lane);
-        const WE* w = (const WE*)net.w_l[0];
-        mma<RBH, RBC, 32 * RBH>(x, ea, w, lane);
-        mma<1, RBC, 6>(x, aux2a, w + ncw_packed_elems(RBC, RBH), lane);
+        mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l[1],
+                                                          1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
         relu_epilogue<P, RBC>(xa, x, (SE*)st.x[0], tile, lane);
     }
-    for (int l = 1; l < net.n_lin - 1; ++l) {
+    for (int l = 1; l < last; ++l) {
         load_bias(x, net.b_l[l], lane);
-        mma<RBC, RBC, 32 * RBC>(x, xa, (const WE*)net.w_l[l], lane);
+        mma_stream<RBC, RBC, 32 * RBC, SH::SLOT>(x, xa, ring, (const WE*)net.w_l[l], net.w_l[l + 1],
+                                                  l + 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
         relu_epilogue<P, RBC>(xa, x, (SE*)st.x[l], tile, lane);
     }
     CVec<1> o;
-    load_bias(o, net.b_l[net.n_lin - 1], lane);
-    mma<RBC, 1, 32 * RBC>(o, xa, (const WE*)net.w_l[net.n_lin - 1], lane);
+    load_bias(o, net.b_l[last], lane);
+    mma_stream<RBC, 1, 32 * RBC, SH::SLOT>(o, xa, ring, (const WE*)net.w_l[last], nullptr, 0, lane);
     if (valid && lane < 32) {  // features 0,1,2 <-> registers 0,1,2 of half 0; sigmoid (neuconw.py:168-169)
         rgb[p * 3 + 0] = sigmoidf_<Fast<P>::v>(o.v[0][0]);
         rgb[p * 3 + 1] = sigmoidf_<Fast<P>::v>(o.v[0][1]);
@@ -97,18 +128,22 @@ __global__ __launch_bounds__(256) void color_fwd_kernel(NcwColorNet net, NcwPoin
 }
 
 template <class P, int RBF, int RBH, int RBC>
-__global__ __launch_bounds__(256) void color_bwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
-                                                        const float* __restrict__ rgb, const float* __restrict__ d_rgb,
-                                                        float* __restrict__ d_grad, float* __restrict__ d_a,
-                                                        void* __restrict__ dfeat_stash, NcwColorStash st) {
+__global__ __launch_bounds__(64 * NCW_WG_WAVES) void color_bwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
+                                                                      const float* __restrict__ rgb,
+                                                                      const float* __restrict__ d_rgb,
+                                                                      float* __restrict__ d_grad, float* __restrict__ d_a,
+                                                                      void* __restrict__ dfeat_stash, NcwColorStash st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
+    typedef ColShapes<P, RBF, RBH, RBC> SH;
+    NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
+    const int last = net.n_lin - 1;
+    ring_prologue(ring, net.wt_l[last], SH::FCB_TLAST);
     int64_t tile, p, ray;
     bool valid;
-    if (!tile_setup(n, tile, p, valid, lane)) return;
-    float xs[3];
-    load_point(src, p, xs, ray);
+    tile_setup(n, tile, p, valid, lane);
+    ray = (src.mode == 0) ? p : p / src.per_ray;
     const float vm = valid ? 1.f : 0.f;
 
     CVec<1> zo;
@@ -125,24 +160,23 @@ __global__ __launch_bounds__(256) void color_bwd_kernel(NcwColorNet net, NcwPoin
     to_act(zoa, zo);
     CVec<RBC> u;
     cvec_zero(u);
-    mma<1, RBC, 3>(u, zoa, (const WE*)net.wt_l[net.n_lin - 1], lane);
-    for (int l = net.n_lin - 2; l >= 1; --l) {
-        relu_backward<P, RBC>(u, (const SE*)st.x[l], tile, lane);
-        stash_store<RBC>((SE*)st.zx[l], tile, u, lane);
-        Act<P, RBC> za;
-        to_act(za, u);
+    mma_stream<1, RBC, 3, SH::SLOT>(u, zoa, ring, (const WE*)net.wt_l[last], net.wt_l[last - 1],
+                                    last - 1 == 0 ? SH::FCB_TL0 : SH::FCB_L, lane);
+    Act<P, RBC> za;
+    for (int l = last - 1; l >= 1; --l) {
+        relu_backward<P, RBC>(za, u, (const SE*)st.x[l], (SE*)st.zx[l], tile, lane);
         cvec_zero(u);
-        mma<RBC, RBC, 32 * RBC>(u, za, (const WE*)net.wt_l[l], lane);
+        mma_stream<RBC, RBC, 32 * RBC, SH::SLOT>(u, za, ring, (const WE*)net.wt_l[l], net.wt_l[l - 1],
+                                                  l - 1 == 0 ? SH::FCB_TL0 : SH::FCB_L, lane);
     }
     CVec<RBH> ue;
     {
-        relu_backward<P, RBC>(u, (const SE*)st.x[0], tile, lane);
-        stash_store<RBC>((SE*)st.zx[0], tile, u, lane);
-        Act<P, RBC> za;
-        to_act(za, u);
+        relu_backward<P, RBC>(za, u, (const SE*)st.x[0], (SE*)st.zx[0], tile, lane);
         CVec<RBH + 1> q;
         cvec_zero(q);
-        mma<RBC, RBH + 1, 32 * RBC>(q, za, (const WE*)net.wt_l[0], lane);
+        const void* wn = net.n_head > 1 ? net.wt_e[net.n_head - 1] : net.wt_e[0];
+        const int nb = net.n_head > 1 ? SH::FCB_E : SH::FCB_TE0;
+        mma_stream<RBC, RBH + 1, 32 * RBC, SH::SLOT>(q, za, ring, (const WE*)net.wt_l[0], wn, nb, lane);
 #pragma unroll
         for (int rb = 0; rb < RBH; ++rb) ue.v[rb] = q.v[rb];
         // d normals = AUX2 features 3,4,5: f=3 <-> (r=3,h=0); f=4 <-> (r=0,h=1); f=5 <-> (r=1,h=1)
@@ -154,22 +188,18 @@ __global__ __launch_bounds__(256) void color_bwd_kernel(NcwColorNet net, NcwPoin
             }
         }
     }
+    Act<P, RBH> zea;
     for (int i = net.n_head - 1; i >= 1; --i) {
-        relu_backward<P, RBH>(ue, (const SE*)st.e[i], tile, lane);
-        stash_store<RBH>((SE*)st.ze[i], tile, ue, lane);
-        Act<P, RBH> za;
-        to_act(za, ue);
+        relu_backward<P, RBH>(zea, ue, (const SE*)st.e[i], (SE*)st.ze[i], tile, lane);
         cvec_zero(ue);
-        mma<RBH, RBH, 32 * RBH>(ue, za, (const WE*)net.wt_e[i], lane);
+        mma_stream<RBH, RBH, 32 * RBH, SH::SLOT>(ue, zea, ring, (const WE*)net.wt_e[i], net.wt_e[i - 1],
+                                                  i - 1 == 0 ? SH::FCB_TE0 : SH::FCB_E, lane);
     }
     {
-        relu_backward<P, RBH>(ue, (const SE*)st.e[0], tile, lane);
-        stash_store<RBH>((SE*)st.ze[0], tile, ue, lane);
-        Act<P, RBH> za;
-        to_act(za, ue);
+        relu_backward<P, RBH>(zea, ue, (const SE*)st.e[0], (SE*)st.ze[0], tile, lane);
         CVec<RBF + 3> q;
         cvec_zero(q);
-        mma<RBH, RBF + 3, 32 * RBH>(q, za, (const WE*)net.wt_e[0], lane);
+        mma_stream<RBH, RBF + 3, 32 * RBH, SH::SLOT>(q, zea, ring, (const WE*)net.wt_e[0], net.wt_f, SH::FCB_F, lane);
         CVec<3> qa;
         qa.v[0] = q.v[RBF]; qa.v[1] = q.v[RBF + 1]; qa.v[2] = q.v[RBF + 2];
         accumulate_d_a(qa, d_a, ray, net.n_a, valid, lane);
@@ -181,7 +211,7 @@ __global__ __launch_bounds__(256) void color_bwd_kernel(NcwColorNet net, NcwPoin
         to_act(zfa, zf);
         CVec<RBF> df;
         cvec_zero(df);
-        mma<RBF, RBF, 32 * RBF>(df, zfa, (const WE*)net.wt_f, lane);
+        mma_stream<RBF, RBF, 32 * RBF, SH::SLOT>(df, zfa, ring, (const WE*)net.wt_f, nullptr, 0, lane);
         stash_store<RBF>((SE*)dfeat_stash, tile, df, lane);
     }
 }

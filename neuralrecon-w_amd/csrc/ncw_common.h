@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -33,9 +34,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NCW_PREC_BF16 1
 
 #define NCW_DEV __device__ __forceinline__
+#define NCW_HD __host__ __device__ __forceinline__
 
 // feature index (within a 32-block) of C-layout register r on half h
-NCW_DEV constexpr int ncw_feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+NCW_HD constexpr int ncw_feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 NCW_DEV int ncw_lane() { return threadIdx.x & 63; }
 
@@ -137,8 +139,140 @@ NCW_DEV void mma(CVec<RB_OUT>& acc, const Act<PrecBF16, RB_IN>& in, const __bf16
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight streaming through LDS (all fused MLP kernels).
+//
+// The waves of a workgroup run the same layer sequence in lockstep; every packed matrix is streamed
+// L2 -> LDS once per WORKGROUP (not once per wave) in chunks of whole in-blocks with
+// `global_load_lds_dwordx4` (LDS-DMA: no VGPR round trip; the fragment order of the packed matrix IS
+// the lane-linear order the DMA writes, so A fragments are conflict-free ds_read_b128 / b32).
+// Two slots: chunk c+1 (or the first chunk of the NEXT matrix, handed in by the caller) is in flight
+// while chunk c is consumed; one __syncthreads() per chunk (hipcc emits the s_waitcnt vmcnt(0) that
+// retires the DMA in front of the s_barrier).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) void ncw_gvoid;
+typedef __attribute__((address_space(3))) void ncw_lvoid;
+
+struct WRing {
+    char* slot[2];
+    int cur;
+    int slot_bytes;
+};
+
+// cooperative DMA of `bytes` (multiple of 16) from gsrc into an LDS slot by all waves of the WG
+NCW_DEV void ring_issue(char* lds_slot, const void* gsrc, int bytes) {
+    const int nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int pieces = (bytes + 1023) >> 10;
+    const char* g0 = reinterpret_cast<const char*>(gsrc) + lane * 16;
+    for (int pc = wave; pc < pieces; pc += nw) {
+        if (pc * 1024 + lane * 16 < bytes)
+            __builtin_amdgcn_global_load_lds((ncw_gvoid*)(g0 + (size_t)pc * 1024), (ncw_lvoid*)(lds_slot + pc * 1024), 16,
+                                             0, 0);
+    }
+}
+
+// A packed matrix is a linear array of k-"units" (f32: one register r = 2 k-values; bf16: one
+// k-step of 16), unit u = in-block * UPB + sub-step, each unit = RB_STRIDE out-blocks x 64 lanes.
+template <class P> struct UnitsPerBlock { static constexpr int v = (P::id == NCW_PREC_F32) ? 16 : 2; };
+template <class P>
+NCW_HD constexpr int ncw_unit_bytes(int rb_stride) {
+    return rb_stride * 64 * ((P::id == NCW_PREC_F32) ? 4 : 16);
+}
+// number of in-blocks that contain real features
+NCW_HD constexpr int ncw_nb_used(int rb_in, int k_real) { return (k_real + 31) / 32 < rb_in ? (k_real + 31) / 32 : rb_in; }
+// units per chunk
+template <class P>
+NCW_HD constexpr int ncw_chunk_units(int rb_stride, int n_units, int slot_bytes) {
+    int g = slot_bytes / ncw_unit_bytes<P>(rb_stride);
+    if (g < 1) g = 1;
+    return g < n_units ? g : n_units;
+}
+// bytes of the first chunk of a matrix (what the previous mma_stream call must prefetch)
+template <class P, int RB_IN, int K_REAL, int RB_STRIDE, int SLOT>
+NCW_HD constexpr int ncw_first_chunk_bytes() {
+    return ncw_chunk_units<P>(RB_STRIDE, ncw_nb_used(RB_IN, K_REAL) * UnitsPerBlock<P>::v, SLOT) *
+           ncw_unit_bytes<P>(RB_STRIDE);
+}
+
+NCW_DEV void ring_prologue(WRing& ring, const void* w_first, int first_bytes) {
+    ring.cur = 0;
+    ring_issue(ring.slot[0], w_first, first_bytes);
+}
+
+// B operand of unit (rb, sub)
+template <int RB_IN>
+NCW_DEV float unit_b(const Act<PrecF32, RB_IN>& in, int rb, int sub) { return in.v[rb][sub]; }
+template <int RB_IN>
+NCW_DEV bf16x8 unit_b(const Act<PrecBF16, RB_IN>& in, int rb, int sub) { return in.f[2 * rb + sub]; }
+
+NCW_DEV f32x16 unit_mfma(float a, float b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+NCW_DEV f32x16 unit_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// first feature touched by unit (rb, sub) on half 0 (the h=1 half is larger): skip test vs K_REAL
+template <class P>
+NCW_HD constexpr int ncw_unit_first_feature(int rb, int sub) {
+    return (P::id == NCW_PREC_F32) ? 32 * rb + ncw_feat_of(sub, 0) : 16 * (2 * rb + sub);
+}
+
+// acc[RB_OUT] += W . in, W streamed through the LDS ring.  ALL threads of the workgroup must call
+// this with identical (uniform) arguments.  w_next/next_bytes: first chunk of the matrix the NEXT
+// mma_stream call will consume (nullptr at the end of the kernel).
+template <int RB_IN, int RB_OUT, int K_REAL, int SLOT, int RB_STRIDE = RB_OUT, class P>
+NCW_DEV void mma_stream(CVec<RB_OUT>& acc, const Act<P, RB_IN>& in, WRing& ring, const typename P::welem* __restrict__ wp,
+                        const void* w_next, int next_bytes, int lane) {
+    constexpr int UPB = UnitsPerBlock<P>::v;
+    constexpr int NU = ncw_nb_used(RB_IN, K_REAL) * UPB;
+    constexpr int UB = ncw_unit_bytes<P>(RB_STRIDE);
+    constexpr int CU = ncw_chunk_units<P>(RB_STRIDE, NU, SLOT);
+    constexpr int NCH = (NU + CU - 1) / CU;
+    typedef typename std::conditional<P::id == NCW_PREC_F32, float, bf16x8>::type Frag;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        __syncthreads();
+        if (c + 1 < NCH) {
+            const int nu = (c + 2) * CU <= NU ? CU : NU - (c + 1) * CU;
+            ring_issue(ring.slot[ring.cur ^ 1], reinterpret_cast<const char*>(wp) + (size_t)(c + 1) * CU * UB, nu * UB);
+        } else if (w_next != nullptr) {
+            ring_issue(ring.slot[ring.cur ^ 1], w_next, next_bytes);
+        }
+        const Frag* lw = reinterpret_cast<const Frag*>(ring.slot[ring.cur]) + lane;
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const int q = c * CU + u;
+            if (q >= NU) continue;
+            const int rb = q / UPB, sub = q % UPB;
+            if (ncw_unit_first_feature<P>(rb, sub) >= K_REAL) continue;
+            const auto b = unit_b<RB_IN>(in, rb, sub);
+            const Frag* w = lw + (size_t)u * RB_STRIDE * 64;
+#pragma unroll
+            for (int ro = 0; ro < RB_OUT; ++ro) acc.v[ro] = unit_mfma(w[ro * 64], b, acc.v[ro]);
+        }
+        ring.cur ^= 1;
+    }
+}
+
+// concatenation of two activation vectors along the feature axis (skip connections: zero cost)
+template <int A, int B>
+NCW_DEV void act_concat(Act<PrecF32, A + B>& o, const Act<PrecF32, A>& x, const Act<PrecF32, B>& y) {
+#pragma unroll
+    for (int i = 0; i < A; ++i) o.v[i] = x.v[i];
+#pragma unroll
+    for (int i = 0; i < B; ++i) o.v[A + i] = y.v[i];
+}
+template <int A, int B>
+NCW_DEV void act_concat(Act<PrecBF16, A + B>& o, const Act<PrecBF16, A>& x, const Act<PrecBF16, B>& y) {
+#pragma unroll
+    for (int i = 0; i < 2 * A; ++i) o.f[i] = x.f[i];
+#pragma unroll
+    for (int i = 0; i < 2 * B; ++i) o.f[2 * A + i] = y.f[i];
+}
+
 // number of packed weight elements of a [32*RB_OUT x 32*RB_IN] matrix
-NCW_DEV constexpr size_t ncw_packed_elems(int rb_out, int rb_in) { return (size_t)rb_out * rb_in * 1024; }
+NCW_HD constexpr size_t ncw_packed_elems(int rb_out, int rb_in) { return (size_t)rb_out * rb_in * 1024; }
 
 // ---------------------------------------------------------------------------------------------
 // bias: packed per out-block as [rb][h][16] f32 (C-layout order)  -> acc initialisation

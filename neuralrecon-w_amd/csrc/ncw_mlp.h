@@ -29,66 +29,96 @@ NCW_DEV void load_point(const NcwPoints& s, int64_t p, float (&xs)[3], int64_t& 
     xs[2] = s.rays_o[r * 3 + 2] + s.rays_d[r * 3 + 2] * zz;
 }
 
-// wave's tile index and the (clamped) point of this lane; returns false if the whole tile is empty
-NCW_DEV bool tile_setup(int64_t n, int64_t& tile, int64_t& p, bool& valid, int lane) {
+// wave's tile index and the (clamped) point of this lane.  Waves whose tile lies beyond n stay in
+// the kernel (they take part in the workgroup barriers of the weight ring) with valid == false; the
+// stash arenas are padded to a whole number of workgroups so their stores land in padding.
+NCW_DEV void tile_setup(int64_t n, int64_t& tile, int64_t& p, bool& valid, int lane) {
     tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (tile * 32 >= n) return false;
     p = tile * 32 + (lane & 31);
     valid = p < n;
     if (!valid) p = n - 1;
-    return true;
+}
+
+// single-block stash store / activation conversion (keeps epilogue register pressure at one block)
+template <class SE>
+NCW_DEV void stash_store_block(SE* __restrict__ base, size_t tile, int RB, int rb, const f32x16& v, int lane) {
+    typedef SE vec4 __attribute__((ext_vector_type(4)));
+    vec4* p = reinterpret_cast<vec4*>(base) + ((tile * RB + rb) * 4) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        vec4 t;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = (SE)v[4 * g + c];
+        p[g * 64] = t;
+    }
+}
+template <class SE>
+NCW_DEV void stash_load_block(f32x16& v, const SE* __restrict__ base, size_t tile, int RB, int rb, int lane) {
+    typedef SE vec4 __attribute__((ext_vector_type(4)));
+    const vec4* p = reinterpret_cast<const vec4*>(base) + ((tile * RB + rb) * 4) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        vec4 t = p[g * 64];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[4 * g + c] = (float)t[c];
+    }
+}
+template <int RB>
+NCW_DEV void to_act_block(Act<PrecF32, RB>& a, int rb, const f32x16& v) { a.v[rb] = v; }
+template <int RB>
+NCW_DEV void to_act_block(Act<PrecBF16, RB>& a, int rb, const f32x16& v) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a.f[2 * rb + t][e] = (__bf16)v[8 * t + e];
 }
 
 // act = Softplus100(acc); optionally stash y (next layer's input) and s = Softplus'
 template <class P, int RB>
 NCW_DEV void softplus_epilogue(Act<P, RB>& act, CVec<RB>& acc, typename P::selem* st_h, typename P::selem* st_s,
                                size_t tile, int lane) {
-    if (st_s) {
-        CVec<RB> sv;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+    for (int rb = 0; rb < RB; ++rb) {
+        f32x16 yv, sv;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float y, s;
-                softplus100<Fast<P>::v>(acc.v[rb][r], y, s);
-                acc.v[rb][r] = y;
-                sv.v[rb][r] = s;
-            }
-        stash_store<RB>(st_s, tile, sv, lane);
-    } else {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float y, s;
-                softplus100<Fast<P>::v>(acc.v[rb][r], y, s);
-                acc.v[rb][r] = y;
-            }
+        for (int r = 0; r < 16; ++r) {
+            float y, s;
+            softplus100<Fast<P>::v>(acc.v[rb][r], y, s);
+            yv[r] = y;
+            sv[r] = s;
+        }
+        if (st_s) stash_store_block(st_s, tile, RB, rb, sv, lane);
+        if (st_h) stash_store_block(st_h, tile, RB, rb, yv, lane);
+        to_act_block<RB>(act, rb, yv);
     }
-    if (st_h) stash_store<RB>(st_h, tile, acc, lane);
-    to_act(act, acc);
 }
 
 // act = relu(acc), optional stash of the post-activation
 template <class P, int RB>
 NCW_DEV void relu_epilogue(Act<P, RB>& act, CVec<RB>& acc, typename P::selem* st, size_t tile, int lane) {
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+    for (int rb = 0; rb < RB; ++rb) {
+        f32x16 yv;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc.v[rb][r] = fmaxf(acc.v[rb][r], 0.f);
-    if (st) stash_store<RB>(st, tile, acc, lane);
-    to_act(act, acc);
+        for (int r = 0; r < 16; ++r) yv[r] = fmaxf(acc.v[rb][r], 0.f);
+        if (st) stash_store_block(st, tile, RB, rb, yv, lane);
+        to_act_block<RB>(act, rb, yv);
+    }
 }
 
-// zbar = ubar * [y > 0]  where y is the stashed post-relu activation
+// zbar = ubar * [y > 0]  where y is the stashed post-relu activation; stores zbar, returns it as Act
 template <class P, int RB>
-NCW_DEV void relu_backward(CVec<RB>& u, const typename P::selem* st_y, size_t tile, int lane) {
-    CVec<RB> y;
-    stash_load<RB>(y, st_y, tile, lane);
+NCW_DEV void relu_backward(Act<P, RB>& za, const CVec<RB>& u, const typename P::selem* st_y, typename P::selem* st_z,
+                           size_t tile, int lane) {
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+    for (int rb = 0; rb < RB; ++rb) {
+        f32x16 y, z;
+        stash_load_block(y, st_y, tile, RB, rb, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) u.v[rb][r] = y.v[rb][r] > 0.f ? u.v[rb][r] : 0.f;
+        for (int r = 0; r < 16; ++r) z[r] = y[r] > 0.f ? u.v[rb][r] : 0.f;
+        stash_store_block(st_z, tile, RB, rb, z, lane);
+        to_act_block<RB>(za, rb, z);
+    }
 }
 
 template <int RB>
@@ -97,13 +127,26 @@ NCW_DEV void cvec_copy(CVec<RB>& d, const CVec<RB>& s) {
     for (int i = 0; i < RB; ++i) d.v[i] = s.v[i];
 }
 
+#define NCW_WG_WAVES 4
 #define NCW_LAUNCH_TILES(kernel, n, st, ...)                                                         \
     do {                                                                                            \
         const int64_t tiles__ = ((n) + 31) / 32;                                                    \
-        const int64_t blocks__ = (tiles__ + 3) / 4;                                                 \
-        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks__), dim3(256), 0, st, __VA_ARGS__);        \
+        const int64_t blocks__ = (tiles__ + NCW_WG_WAVES - 1) / NCW_WG_WAVES;                       \
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks__), dim3(64 * NCW_WG_WAVES), 0, st, __VA_ARGS__); \
         NCW_CHECK_LAUNCH();                                                                         \
     } while (0)
+
+// LDS slot size of the weight ring by network width (two slots per workgroup)
+template <int RB>
+struct RingSlot { static constexpr int bytes = RB >= 8 ? 65536 : 16384; };
+
+#define NCW_RING_DECL(SLOTB)                                              \
+    __shared__ __attribute__((aligned(16))) char ring_mem__[2 * (SLOTB)]; \
+    WRing ring;                                                           \
+    ring.slot[0] = ring_mem__;                                            \
+    ring.slot[1] = ring_mem__ + (SLOTB);                                  \
+    ring.cur = 0;                                                         \
+    ring.slot_bytes = (SLOTB)
 
 // ---- auxiliary input blocks shared by the colour net and the background NeRF ------------------------
 // AUX1 (3 blocks, 96): [gamma_4(view dir) (27) | appearance embedding a (n_a <= 69) | 0...]

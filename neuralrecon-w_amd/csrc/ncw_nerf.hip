@@ -10,16 +10,36 @@ NCW_DEV void inverted_sphere(const float (&x)[3], float (&p4)[4]) {
 }
 
 template <class P, int RBN, int RBH>
-__global__ __launch_bounds__(256) void nerf_fwd_kernel(NcwNerfNet net, NcwPoints src, const float* __restrict__ x4,
-                                                       int64_t n, const float* __restrict__ a,
-                                                       float* __restrict__ density, float* __restrict__ rgb,
-                                                       NcwNerfStash st) {
+struct NerfShapes {
+    static constexpr int SLOT = RingSlot<RBN>::bytes;
+    static constexpr int FCB_P0 = ncw_first_chunk_bytes<P, 3, 84, RBN, SLOT>();
+    static constexpr int FCB_P = ncw_first_chunk_bytes<P, RBN, 32 * RBN, RBN, SLOT>();
+    static constexpr int FCB_PS = ncw_first_chunk_bytes<P, RBN + 3, 32 * RBN + 84, RBN, SLOT>();
+    static constexpr int FCB_ALPHA = ncw_first_chunk_bytes<P, RBN, 32 * RBN, 1, SLOT>();
+    static constexpr int FCB_A0 = ncw_first_chunk_bytes<P, RBN + 3, 32 * RBN + 96, RBH, SLOT>();
+    static constexpr int FCB_A = ncw_first_chunk_bytes<P, RBH, 32 * RBH, RBH, SLOT>();
+    static constexpr int FCB_RGB = ncw_first_chunk_bytes<P, RBH, 32 * RBH, 1, SLOT>();
+    static constexpr int FCB_TRGB = ncw_first_chunk_bytes<P, 1, 3, RBH, SLOT>();
+    static constexpr int FCB_TA0 = ncw_first_chunk_bytes<P, RBH, 32 * RBH, RBN + 3, SLOT>();
+    static constexpr int FCB_TALPHA = ncw_first_chunk_bytes<P, 1, 1, RBN, SLOT>();
+    static constexpr int FCB_TPS = ncw_first_chunk_bytes<P, RBN, 32 * RBN, RBN + 3, SLOT>();
+};
+
+template <class P, int RBN, int RBH>
+__global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet net, NcwPoints src,
+                                                                     const float* __restrict__ x4, int64_t n,
+                                                                     const float* __restrict__ a,
+                                                                     float* __restrict__ density, float* __restrict__ rgb,
+                                                                     NcwNerfStash st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
+    typedef NerfShapes<P, RBN, RBH> SH;
+    NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
+    ring_prologue(ring, net.w_p[0], SH::FCB_P0);
     int64_t tile, p, ray;
     bool valid;
-    if (!tile_setup(n, tile, p, valid, lane)) return;
+    tile_setup(n, tile, p, valid, lane);
     float p4[4];
     if (x4) {
         p4[0] = x4[p * 4 + 0]; p4[1] = x4[p * 4 + 1]; p4[2] = x4[p * 4 + 2]; p4[3] = x4[p * 4 + 3];
@@ -31,60 +51,87 @@ __global__ __launch_bounds__(256) void nerf_fwd_kernel(NcwNerfNet net, NcwPoints
     }
     const float dir[3] = {src.rays_d[ray * 3 + 0], src.rays_d[ray * 3 + 1], src.rays_d[ray * 3 + 2]};
 
-    CVec<3> gp;
-    freq_encode<3, 4, 10, Fast<P>::v>(gp, p4, lane);
-    stash_store<3>((SE*)st.gp, tile, gp, lane);
     Act<P, 3> gpa;
-    to_act(gpa, gp);
-    CVec<3> aux1;
-    build_aux1<Fast<P>::v>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
-    stash_store<3>((SE*)st.aux1, tile, aux1, lane);
+    {
+        CVec<3> gp;
+        freq_encode<3, 4, 10, Fast<P>::v>(gp, p4, lane);
+        stash_store<3>((SE*)st.gp, tile, gp, lane);
+        to_act(gpa, gp);
+    }
     Act<P, 3> aux1a;
-    to_act(aux1a, aux1);
-
+    {
+        CVec<3> aux1;
+        build_aux1<Fast<P>::v>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
+        stash_store<3>((SE*)st.aux1, tile, aux1, lane);
+        to_act(aux1a, aux1);
+    }
+    auto next_trunk = [&](int i, const void*& w, int& bytes) {  // matrix consumed after trunk layer i
+        const int m = i + 1;
+        if (m < net.D) {
+            w = net.w_p[m];
+            bytes = (m == net.skip + 1) ? SH::FCB_PS : SH::FCB_P;
+        } else {
+            w = net.w_alpha;
+            bytes = SH::FCB_ALPHA;
+        }
+    };
+    const void* wn;
+    int nb;
     // trunk (nerf.py:162-167)
     CVec<RBN> acc;
     Act<P, RBN> ha;
     load_bias(acc, net.b_p[0], lane);
-    mma<3, RBN, 84>(acc, gpa, (const WE*)net.w_p[0], lane);
+    next_trunk(0, wn, nb);
+    mma_stream<3, RBN, 84, SH::SLOT>(acc, gpa, ring, (const WE*)net.w_p[0], wn, nb, lane);
     relu_epilogue<P, RBN>(ha, acc, (SE*)st.h[1], tile, lane);
     for (int i = 1; i < net.D; ++i) {
         load_bias(acc, net.b_p[i], lane);
-        const WE* w = (const WE*)net.w_p[i];
-        mma<RBN, RBN, 32 * RBN>(acc, ha, w, lane);
-        if (i == net.skip + 1) mma<3, RBN, 84>(acc, gpa, w + ncw_packed_elems(RBN, RBN), lane);
+        next_trunk(i, wn, nb);
+        if (i == net.skip + 1) {
+            Act<P, RBN + 3> cat;
+            act_concat<RBN, 3>(cat, ha, gpa);
+            mma_stream<RBN + 3, RBN, 32 * RBN + 84, SH::SLOT>(acc, cat, ring, (const WE*)net.w_p[i], wn, nb, lane);
+        } else {
+            mma_stream<RBN, RBN, 32 * RBN, SH::SLOT>(acc, ha, ring, (const WE*)net.w_p[i], wn, nb, lane);
+        }
         relu_epilogue<P, RBN>(ha, acc, (SE*)st.h[i + 1], tile, lane);
     }
     // density + feature (nerf.py:170-171)
     {
         CVec<1> o;
         load_bias(o, net.b_alpha, lane);
-        mma<RBN, 1, 32 * RBN>(o, ha, (const WE*)net.w_alpha, lane);
+        mma_stream<RBN, 1, 32 * RBN, SH::SLOT>(o, ha, ring, (const WE*)net.w_alpha, net.w_feat, SH::FCB_P, lane);
         if (valid && lane < 32) density[p] = o.v[0][0];
     }
-    Act<P, RBN> fa;
-    load_bias(acc, net.b_feat, lane);
-    mma<RBN, RBN, 32 * RBN>(acc, ha, (const WE*)net.w_feat, lane);
-    stash_store<RBN>((SE*)st.featn, tile, acc, lane);
-    to_act(fa, acc);
+    Act<P, RBN + 3> cat1;
+    {
+        load_bias(acc, net.b_feat, lane);
+        mma_stream<RBN, RBN, 32 * RBN, SH::SLOT>(acc, ha, ring, (const WE*)net.w_feat, net.w_a[0], SH::FCB_A0, lane);
+        stash_store<RBN>((SE*)st.featn, tile, acc, lane);
+        Act<P, RBN> fa;
+        to_act(fa, acc);
+        act_concat<RBN, 3>(cat1, fa, aux1a);
+    }
     // appearance head (nerf.py:131-139,173-174)
     CVec<RBH> e;
     Act<P, RBH> ea;
     {
         load_bias(e, net.b_a[0], lane);
-        const WE* w = (const WE*)net.w_a[0];
-        mma<RBN, RBH, 32 * RBN>(e, fa, w, lane);
-        mma<3, RBH, 96>(e, aux1a, w + ncw_packed_elems(RBH, RBN), lane);
+        wn = net.n_head > 1 ? net.w_a[1] : net.w_rgb;
+        nb = net.n_head > 1 ? SH::FCB_A : SH::FCB_RGB;
+        mma_stream<RBN + 3, RBH, 32 * RBN + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_a[0], wn, nb, lane);
         relu_epilogue<P, RBH>(ea, e, (SE*)st.e[0], tile, lane);
     }
     for (int i = 1; i < net.n_head; ++i) {
         load_bias(e, net.b_a[i], lane);
-        mma<RBH, RBH, 32 * RBH>(e, ea, (const WE*)net.w_a[i], lane);
+        wn = i + 1 < net.n_head ? net.w_a[i + 1] : net.w_rgb;
+        nb = i + 1 < net.n_head ? SH::FCB_A : SH::FCB_RGB;
+        mma_stream<RBH, RBH, 32 * RBH, SH::SLOT>(e, ea, ring, (const WE*)net.w_a[i], wn, nb, lane);
         relu_epilogue<P, RBH>(ea, e, (SE*)st.e[i], tile, lane);
     }
     CVec<1> o;
     load_bias(o, net.b_rgb, lane);
-    mma<RBH, 1, 32 * RBH>(o, ea, (const WE*)net.w_rgb, lane);
+    mma_stream<RBH, 1, 32 * RBH, SH::SLOT>(o, ea, ring, (const WE*)net.w_rgb, nullptr, 0, lane);
     if (valid && lane < 32) {  // raw rgb, no sigmoid (nerf.py:181)
         rgb[p * 3 + 0] = o.v[0][0];
         rgb[p * 3 + 1] = o.v[0][1];
@@ -93,16 +140,19 @@ __global__ __launch_bounds__(256) void nerf_fwd_kernel(NcwNerfNet net, NcwPoints
 }
 
 template <class P, int RBN, int RBH>
-__global__ __launch_bounds__(256) void nerf_bwd_kernel(NcwNerfNet net, NcwPoints src, int64_t n,
-                                                       const float* __restrict__ d_density,
-                                                       const float* __restrict__ d_rgb, float* __restrict__ d_a,
-                                                       NcwNerfStash st) {
+__global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_bwd_kernel(NcwNerfNet net, NcwPoints src, int64_t n,
+                                                                     const float* __restrict__ d_density,
+                                                                     const float* __restrict__ d_rgb,
+                                                                     float* __restrict__ d_a, NcwNerfStash st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
+    typedef NerfShapes<P, RBN, RBH> SH;
+    NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
+    ring_prologue(ring, net.wt_rgb, SH::FCB_TRGB);
     int64_t tile, p, ray;
     bool valid;
-    if (!tile_setup(n, tile, p, valid, lane)) return;
+    tile_setup(n, tile, p, valid, lane);
     ray = (src.mode == 0) ? p : p / src.per_ray;
     const float vm = valid ? 1.f : 0.f;
 
@@ -118,24 +168,24 @@ __global__ __launch_bounds__(256) void nerf_bwd_kernel(NcwNerfNet net, NcwPoints
     to_act(zra, zr);
     CVec<RBH> ue;
     cvec_zero(ue);
-    mma<1, RBH, 3>(ue, zra, (const WE*)net.wt_rgb, lane);
+    {
+        const void* wn = net.n_head > 1 ? net.wt_a[net.n_head - 1] : net.wt_a[0];
+        const int nb = net.n_head > 1 ? SH::FCB_A : SH::FCB_TA0;
+        mma_stream<1, RBH, 3, SH::SLOT>(ue, zra, ring, (const WE*)net.wt_rgb, wn, nb, lane);
+    }
+    Act<P, RBH> zea;
     for (int i = net.n_head - 1; i >= 1; --i) {
-        relu_backward<P, RBH>(ue, (const SE*)st.e[i], tile, lane);
-        stash_store<RBH>((SE*)st.ze[i], tile, ue, lane);
-        Act<P, RBH> za;
-        to_act(za, ue);
+        relu_backward<P, RBH>(zea, ue, (const SE*)st.e[i], (SE*)st.ze[i], tile, lane);
         cvec_zero(ue);
-        mma<RBH, RBH, 32 * RBH>(ue, za, (const WE*)net.wt_a[i], lane);
+        mma_stream<RBH, RBH, 32 * RBH, SH::SLOT>(ue, zea, ring, (const WE*)net.wt_a[i], net.wt_a[i - 1],
+                                                  i - 1 == 0 ? SH::FCB_TA0 : SH::FCB_A, lane);
     }
     CVec<RBN> u;
     {
-        relu_backward<P, RBH>(ue, (const SE*)st.e[0], tile, lane);
-        stash_store<RBH>((SE*)st.ze[0], tile, ue, lane);
-        Act<P, RBH> za;
-        to_act(za, ue);
+        relu_backward<P, RBH>(zea, ue, (const SE*)st.e[0], (SE*)st.ze[0], tile, lane);
         CVec<RBN + 3> q;
         cvec_zero(q);
-        mma<RBH, RBN + 3, 32 * RBH>(q, za, (const WE*)net.wt_a[0], lane);
+        mma_stream<RBH, RBN + 3, 32 * RBH, SH::SLOT>(q, zea, ring, (const WE*)net.wt_a[0], net.wt_feat, SH::FCB_P, lane);
         CVec<3> qa;
         qa.v[0] = q.v[RBN]; qa.v[1] = q.v[RBN + 1]; qa.v[2] = q.v[RBN + 2];
         accumulate_d_a(qa, d_a, ray, net.n_a, valid, lane);
@@ -152,18 +202,21 @@ __global__ __launch_bounds__(256) void nerf_bwd_kernel(NcwNerfNet net, NcwPoints
         Act<P, 1> zala;
         to_act(zala, zal);
         cvec_zero(u);
-        mma<RBN, RBN, 32 * RBN>(u, zfa, (const WE*)net.wt_feat, lane);
-        mma<1, RBN, 1>(u, zala, (const WE*)net.wt_alpha, lane);
+        mma_stream<RBN, RBN, 32 * RBN, SH::SLOT>(u, zfa, ring, (const WE*)net.wt_feat, net.wt_alpha, SH::FCB_TALPHA, lane);
+        const int m = net.D - 1;  // first trunk matrix of the reverse sweep (only needed when m > 0)
+        const void* wn = m > 0 ? net.wt_p[m] : nullptr;
+        const int nb = (m == net.skip + 1) ? SH::FCB_TPS : SH::FCB_P;
+        mma_stream<1, RBN, 1, SH::SLOT>(u, zala, ring, (const WE*)net.wt_alpha, wn, nb, lane);
     }
+    Act<P, RBN> za;
     for (int i = net.D - 1; i >= 0; --i) {
-        relu_backward<P, RBN>(u, (const SE*)st.h[i + 1], tile, lane);
-        stash_store<RBN>((SE*)st.zp[i], tile, u, lane);
+        relu_backward<P, RBN>(za, u, (const SE*)st.h[i + 1], (SE*)st.zp[i], tile, lane);
         if (i > 0) {
-            Act<P, RBN> za;
-            to_act(za, u);
             cvec_zero(u);
-            if (i == net.skip + 1) mma<RBN, RBN, 32 * RBN, RBN + 3>(u, za, (const WE*)net.wt_p[i], lane);
-            else mma<RBN, RBN, 32 * RBN>(u, za, (const WE*)net.wt_p[i], lane);
+            const void* wn = (i - 1 > 0) ? net.wt_p[i - 1] : nullptr;
+            const int nb = (i - 1 == net.skip + 1) ? SH::FCB_TPS : SH::FCB_P;
+            if (i == net.skip + 1) mma_stream<RBN, RBN, 32 * RBN, SH::SLOT, RBN + 3>(u, za, ring, (const WE*)net.wt_p[i], wn, nb, lane);
+            else mma_stream<RBN, RBN, 32 * RBN, SH::SLOT>(u, za, ring, (const WE*)net.wt_p[i], wn, nb, lane);
         }
     }
 }

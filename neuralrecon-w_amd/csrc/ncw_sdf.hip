@@ -16,17 +16,50 @@ NCW_DEV NcwPoints points_from_x(const float* x) {
     return s;
 }
 
+// Shapes of the packed SDF matrices as seen by the weight ring (first-chunk sizes for prefetch).
+template <class P, int RB>
+struct SdfShapes {
+    static constexpr int SLOT = RingSlot<RB>::bytes;
+    static constexpr int FCB_W0 = ncw_first_chunk_bytes<P, 2, 39, RB, SLOT>();              // lin0: K = gamma
+    static constexpr int FCB_WH = ncw_first_chunk_bytes<P, RB, 32 * RB, RB, SLOT>();        // hidden
+    static constexpr int FCB_WS = ncw_first_chunk_bytes<P, RB + 2, 32 * RB + 39, RB, SLOT>();  // skip layer
+    static constexpr int FCB_W1 = ncw_first_chunk_bytes<P, RB, 32 * RB, 1, SLOT>();         // sdf row
+    static constexpr int FCB_TL = ncw_first_chunk_bytes<P, 1, 1, RB, SLOT>();               // wt[L-1]
+    static constexpr int FCB_TS = ncw_first_chunk_bytes<P, RB, 32 * RB, RB + 2, SLOT>();    // wt[skip]
+    static constexpr int FCB_T0 = ncw_first_chunk_bytes<P, RB, 32 * RB, 2, SLOT>();         // wt[0]
+};
+
+// z_l = b_l + W_l u_l for a hidden layer l (1 <= l <= L-2), honouring the skip concatenation
+template <class P, int RB>
+NCW_DEV void sdf_hidden_layer(CVec<RB>& acc, const Act<P, RB>& act, const Act<P, 2>& gact, const NcwSdfNet& net, int l,
+                              WRing& ring, const void* w_next, int next_bytes, int lane) {
+    typedef typename P::welem WE;
+    constexpr int SLOT = RingSlot<RB>::bytes;
+    load_bias(acc, net.b[l], lane);
+    if (l == net.skip_layer) {
+        Act<P, RB + 2> cat;
+        act_concat<RB, 2>(cat, act, gact);
+        mma_stream<RB + 2, RB, 32 * RB + 39, SLOT>(acc, cat, ring, (const WE*)net.w[l], w_next, next_bytes, lane);
+    } else {
+        mma_stream<RB, RB, 32 * RB, SLOT>(acc, act, ring, (const WE*)net.w[l], w_next, next_bytes, lane);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // inference
 // ---------------------------------------------------------------------------------------------
 template <class P, int RB>
-__global__ __launch_bounds__(256) void sdf_infer_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
-                                                        float* __restrict__ sdf) {
+__global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_infer_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                      float* __restrict__ sdf) {
     typedef typename P::welem WE;
+    typedef SdfShapes<P, RB> SH;
+    NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
+    const int L = net.n_layers;
+    ring_prologue(ring, net.w[0], SH::FCB_W0);
     int64_t tile, p, ray;
     bool valid;
-    if (!tile_setup(n, tile, p, valid, lane)) return;
+    tile_setup(n, tile, p, valid, lane);
     float xs[3];
     load_point(src, p, xs, ray);
     xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
@@ -38,20 +71,25 @@ __global__ __launch_bounds__(256) void sdf_infer_kernel(NcwSdfNet net, NcwPoints
 
     CVec<RB> acc;
     Act<P, RB> act;
+    auto next_of = [&](int l, const void*& w, int& bytes) {  // matrix consumed after forward layer l
+        const int m = l + 1;
+        w = net.w[m];
+        bytes = (m == L - 1) ? SH::FCB_W1 : (m == net.skip_layer ? SH::FCB_WS : SH::FCB_WH);
+    };
+    const void* wn;
+    int nbts;
     load_bias(acc, net.b[0], lane);
-    mma<2, RB, 39>(acc, gact, (const WE*)net.w[0], lane);
+    next_of(0, wn, nbts);
+    mma_stream<2, RB, 39, SH::SLOT>(acc, gact, ring, (const WE*)net.w[0], wn, nbts, lane);
     softplus_epilogue<P, RB>(act, acc, nullptr, nullptr, 0, lane);
-    const int L = net.n_layers;
     for (int l = 1; l < L - 1; ++l) {
-        load_bias(acc, net.b[l], lane);
-        const WE* w = (const WE*)net.w[l];
-        mma<RB, RB, 32 * RB>(acc, act, w, lane);
-        if (l == net.skip_layer) mma<2, RB, 39>(acc, gact, w + ncw_packed_elems(RB, RB), lane);
+        next_of(l, wn, nbts);
+        sdf_hidden_layer<P, RB>(acc, act, gact, net, l, ring, wn, nbts, lane);
         softplus_epilogue<P, RB>(act, acc, nullptr, nullptr, 0, lane);
     }
     CVec<1> o;
     load_bias(o, net.b[L - 1], lane);
-    mma<RB, 1, 32 * RB>(o, act, (const WE*)net.w[L - 1], lane);
+    mma_stream<RB, 1, 32 * RB, SH::SLOT>(o, act, ring, (const WE*)net.w[L - 1], nullptr, 0, lane);
     if (valid && lane < 32) sdf[p] = o.v[0][0] / net.scale;
 }
 
@@ -59,18 +97,22 @@ __global__ __launch_bounds__(256) void sdf_infer_kernel(NcwSdfNet net, NcwPoints
 // forward + analytic input gradient + stash
 // ---------------------------------------------------------------------------------------------
 template <class P, int RB>
-__global__ __launch_bounds__(256) void sdf_fwd_kernel(NcwSdfNet net, NcwPoints src, int64_t n, float* __restrict__ sdf,
-                                                      float* __restrict__ grad, NcwSdfStash st) {
+__global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                    float* __restrict__ sdf, float* __restrict__ grad,
+                                                                    NcwSdfStash st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
+    typedef SdfShapes<P, RB> SH;
+    NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
+    const int L = net.n_layers;
+    ring_prologue(ring, net.w[0], SH::FCB_W0);
     int64_t tile, p, ray;
     bool valid;
-    if (!tile_setup(n, tile, p, valid, lane)) return;
+    tile_setup(n, tile, p, valid, lane);
     float xs[3];
     load_point(src, p, xs, ray);
     xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
-    const int L = net.n_layers;
 
     CVec<2> gam;
     freq_encode<2, 3, 6, Fast<P>::v>(gam, xs, lane);
@@ -80,26 +122,38 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(NcwSdfNet net, NcwPoints s
 
     CVec<RB> acc;
     Act<P, RB> act;
+    auto next_of = [&](int l, const void*& w, int& bytes) {
+        const int m = l + 1;
+        w = net.w[m];
+        bytes = (m == L - 1) ? SH::FCB_W1 : (m == net.skip_layer ? SH::FCB_WS : SH::FCB_WH);
+    };
+    const void* wn;
+    int nbts;
     load_bias(acc, net.b[0], lane);
-    mma<2, RB, 39>(acc, gact, (const WE*)net.w[0], lane);
+    next_of(0, wn, nbts);
+    mma_stream<2, RB, 39, SH::SLOT>(acc, gact, ring, (const WE*)net.w[0], wn, nbts, lane);
     softplus_epilogue<P, RB>(act, acc, (SE*)st.h[1], (SE*)st.s[0], tile, lane);
     for (int l = 1; l < L - 1; ++l) {
-        load_bias(acc, net.b[l], lane);
-        const WE* w = (const WE*)net.w[l];
-        mma<RB, RB, 32 * RB>(acc, act, w, lane);
-        if (l == net.skip_layer) mma<2, RB, 39>(acc, gact, w + ncw_packed_elems(RB, RB), lane);
+        next_of(l, wn, nbts);
+        sdf_hidden_layer<P, RB>(acc, act, gact, net, l, ring, wn, nbts, lane);
         softplus_epilogue<P, RB>(act, acc, (SE*)st.h[l + 1], (SE*)st.s[l], tile, lane);
     }
     {
         CVec<1> o;
         load_bias(o, net.b[L - 1], lane);
-        mma<RB, 1, 32 * RB>(o, act, (const WE*)net.w[L - 1], lane);
+        mma_stream<RB, 1, 32 * RB, SH::SLOT>(o, act, ring, (const WE*)net.w[L - 1], net.w_feat, SH::FCB_WH, lane);
         if (valid && lane < 32) sdf[p] = o.v[0][0] / net.scale;
         load_bias(acc, net.b_feat, lane);
-        mma<RB, RB, 32 * RB>(acc, act, (const WE*)net.w_feat, lane);
+        mma_stream<RB, RB, 32 * RB, SH::SLOT>(acc, act, ring, (const WE*)net.w_feat, net.wt[L - 1], SH::FCB_TL, lane);
         stash_store<RB>((SE*)st.feat, tile, acc, lane);
     }
     // ---- adjoint pass: a_{L-2} = W_{L-1}[0,:]; t_l = a_l * s_l; a_{l-1} = W_l^T t_l --------------
+    auto adj_next = [&](int l, const void*& w, int& bytes) {  // matrix consumed after adjoint layer l
+        const int m = l - 1;
+        if (m < 0) { w = nullptr; bytes = 0; return; }
+        w = net.wt[m];
+        bytes = (m == 0) ? SH::FCB_T0 : (m == net.skip_layer ? SH::FCB_TS : SH::FCB_WH);
+    };
     CVec<RB> a;
     {
         CVec<1> e0;
@@ -108,34 +162,37 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(NcwSdfNet net, NcwPoints s
         Act<P, 1> e0a;
         to_act(e0a, e0);
         cvec_zero(a);
-        mma<1, RB, 1>(a, e0a, (const WE*)net.wt[L - 1], lane);
+        adj_next(L - 1, wn, nbts);
+        mma_stream<1, RB, 1, SH::SLOT>(a, e0a, ring, (const WE*)net.wt[L - 1], wn, nbts, lane);
     }
     CVec<2> gg;
     cvec_zero(gg);
     for (int l = L - 2; l >= 0; --l) {
-        CVec<RB> sv;
-        stash_load<RB>(sv, (const SE*)st.s[l], tile, lane);
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a.v[rb][r] *= sv.v[rb][r];
-        stash_store<RB>((SE*)st.t[l], tile, a, lane);
         Act<P, RB> ta;
-        to_act(ta, a);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            f32x16 sv;
+            stash_load_block(sv, (const SE*)st.s[l], tile, RB, rb, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] *= a.v[rb][r];
+            stash_store_block((SE*)st.t[l], tile, RB, rb, sv, lane);
+            to_act_block<RB>(ta, rb, sv);
+        }
         const WE* wt = (const WE*)net.wt[l];
+        adj_next(l, wn, nbts);
         if (l == 0) {
-            mma<RB, 2, 32 * RB>(gg, ta, wt, lane);
+            mma_stream<RB, 2, 32 * RB, SH::SLOT>(gg, ta, ring, wt, wn, nbts, lane);
         } else if (l == net.skip_layer) {
             CVec<RB + 2> q;
             cvec_zero(q);
-            mma<RB, RB + 2, 32 * RB>(q, ta, wt, lane);
+            mma_stream<RB, RB + 2, 32 * RB, SH::SLOT>(q, ta, ring, wt, wn, nbts, lane);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) a.v[rb] = q.v[rb];
             gg.v[0] = q.v[RB];
             gg.v[1] = q.v[RB + 1];
         } else {
             cvec_zero(a);
-            mma<RB, RB, 32 * RB>(a, ta, wt, lane);
+            mma_stream<RB, RB, 32 * RB, SH::SLOT>(a, ta, ring, wt, wn, nbts, lane);
         }
     }
     // ---- grad = J_gamma(x)^T g_gamma -----------------------------------------------------------
@@ -163,20 +220,23 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(NcwSdfNet net, NcwPoints s
 // backward (second order)
 // ---------------------------------------------------------------------------------------------
 template <class P, int RB>
-__global__ __launch_bounds__(256) void sdf_bwd_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
-                                                      const float* __restrict__ d_sdf, const float* __restrict__ d_grad,
-                                                      NcwSdfStash st) {
+__global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_bwd_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                    const float* __restrict__ d_sdf,
+                                                                    const float* __restrict__ d_grad, NcwSdfStash st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
+    typedef SdfShapes<P, RB> SH;
+    NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
     const int h = lane >> 5;
+    const int L = net.n_layers;
+    ring_prologue(ring, net.w[0], SH::FCB_W0);
     int64_t tile, p, ray;
     bool valid;
-    if (!tile_setup(n, tile, p, valid, lane)) return;
+    tile_setup(n, tile, p, valid, lane);
     float xs[3];
     load_point(src, p, xs, ray);
     xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
-    const int L = net.n_layers;
     const float vmask = valid ? 1.f : 0.f;  // padded lanes must contribute nothing to weight grads
     float nb[3] = {d_grad[p * 3 + 0] * vmask, d_grad[p * 3 + 1] * vmask, d_grad[p * 3 + 2] * vmask};
     const float dsdf = d_sdf[p] * vmask / net.scale;
@@ -200,32 +260,43 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(NcwSdfNet net, NcwPoints s
     to_act(q0a, q0);
     Act<P, RB> qa;
     CVec<RB> tb;
+    const void* wn;
+    int nbts;
     for (int l = 0; l <= L - 2; ++l) {
         cvec_zero(tb);
         const WE* w = (const WE*)net.w[l];
-        if (l == 0) {
-            mma<2, RB, 39>(tb, q0a, w, lane);
+        if (l + 1 <= L - 2) {
+            wn = net.w[l + 1];
+            nbts = (l + 1 == net.skip_layer) ? SH::FCB_WS : SH::FCB_WH;
         } else {
-            mma<RB, RB, 32 * RB>(tb, qa, w, lane);
-            if (l == net.skip_layer) mma<2, RB, 39>(tb, q0a, w + ncw_packed_elems(RB, RB), lane);
+            wn = net.wt_feat;
+            nbts = SH::FCB_WH;
         }
-        CVec<RB> sv, tv;
-        stash_load<RB>(sv, (const SE*)st.s[l], tile, lane);
-        stash_load<RB>(tv, (const SE*)st.t[l], tile, lane);
-        CVec<RB> z2;
+        if (l == 0) {
+            mma_stream<2, RB, 39, SH::SLOT>(tb, q0a, ring, w, wn, nbts, lane);
+        } else if (l == net.skip_layer) {
+            Act<P, RB + 2> cat;
+            act_concat<RB, 2>(cat, qa, q0a);
+            mma_stream<RB + 2, RB, 32 * RB + 39, SH::SLOT>(tb, cat, ring, w, wn, nbts, lane);
+        } else {
+            mma_stream<RB, RB, 32 * RB, SH::SLOT>(tb, qa, ring, w, wn, nbts, lane);
+        }
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb) {
+            f32x16 sv, tv, z2, ab;
+            stash_load_block(sv, (const SE*)st.s[l], tile, RB, rb, lane);
+            stash_load_block(tv, (const SE*)st.t[l], tile, RB, rb, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float tbar = tb.v[rb][r];
-                const float s = sv.v[rb][r];
                 // a_l phi''(z_l) = 100 t_l (1 - s_l)   (0 above the Softplus threshold where s == 1)
-                z2.v[rb][r] = tbar * 100.f * tv.v[rb][r] * (1.f - s);
-                tb.v[rb][r] = tbar * s;  // abar_l
+                z2[r] = tbar * 100.f * tv[r] * (1.f - sv[r]);
+                ab[r] = tbar * sv[r];  // abar_l
             }
-        stash_store<RB>((SE*)st.zbar[l], tile, z2, lane);    // temporarily zbar2_l
-        stash_store<RB>((SE*)st.qbar[l + 1], tile, tb, lane);  // qbar_{l+1} = abar_l
-        to_act(qa, tb);
+            stash_store_block((SE*)st.zbar[l], tile, RB, rb, z2, lane);      // temporarily zbar2_l
+            stash_store_block((SE*)st.qbar[l + 1], tile, RB, rb, ab, lane);  // qbar_{l+1} = abar_l
+            to_act_block<RB>(qa, rb, ab);
+        }
     }
     // ---- (2) backward of the forward pass, l = L-1 .. 0 -------------------------------------------
     CVec<RB> u;
@@ -240,29 +311,38 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(NcwSdfNet net, NcwPoints s
         stash_store<1>((SE*)st.one, tile, one, lane);
         Act<P, 1> zsa;
         to_act(zsa, zs);
-        CVec<RB> df;
-        stash_load<RB>(df, (const SE*)st.dfeat, tile, lane);
         Act<P, RB> dfa;
-        to_act(dfa, df);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            f32x16 df;
+            stash_load_block(df, (const SE*)st.dfeat, tile, RB, rb, lane);
+            to_act_block<RB>(dfa, rb, df);
+        }
         cvec_zero(u);
-        mma<RB, RB, 32 * RB>(u, dfa, (const WE*)net.wt_feat, lane);
-        mma<1, RB, 1>(u, zsa, (const WE*)net.wt[L - 1], lane);
+        mma_stream<RB, RB, 32 * RB, SH::SLOT>(u, dfa, ring, (const WE*)net.wt_feat, net.wt[L - 1], SH::FCB_TL, lane);
+        const int m = L - 2;  // next: wt[L-2] unless the loop below needs no matrix at all (L-2 == 0)
+        wn = (m > 0) ? net.wt[m] : nullptr;
+        nbts = (m == net.skip_layer) ? SH::FCB_TS : SH::FCB_WH;
+        mma_stream<1, RB, 1, SH::SLOT>(u, zsa, ring, (const WE*)net.wt[L - 1], wn, nbts, lane);
     }
     for (int l = L - 2; l >= 0; --l) {
-        CVec<RB> sv, z2;
-        stash_load<RB>(sv, (const SE*)st.s[l], tile, lane);
-        stash_load<RB>(z2, (const SE*)st.zbar[l], tile, lane);
+        Act<P, RB> za;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb) {
+            f32x16 sv, z2;
+            stash_load_block(sv, (const SE*)st.s[l], tile, RB, rb, lane);
+            stash_load_block(z2, (const SE*)st.zbar[l], tile, RB, rb, lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) u.v[rb][r] = u.v[rb][r] * sv.v[rb][r] + z2.v[rb][r];
-        stash_store<RB>((SE*)st.zbar[l], tile, u, lane);
+            for (int r = 0; r < 16; ++r) z2[r] = u.v[rb][r] * sv[r] + z2[r];
+            stash_store_block((SE*)st.zbar[l], tile, RB, rb, z2, lane);
+            to_act_block<RB>(za, rb, z2);
+        }
         if (l > 0) {
-            Act<P, RB> za;
-            to_act(za, u);
             cvec_zero(u);
-            if (l == net.skip_layer) mma<RB, RB, 32 * RB, RB + 2>(u, za, (const WE*)net.wt[l], lane);
-            else mma<RB, RB, 32 * RB>(u, za, (const WE*)net.wt[l], lane);
+            wn = (l - 1 > 0) ? net.wt[l - 1] : nullptr;
+            nbts = (l - 1 == net.skip_layer) ? SH::FCB_TS : SH::FCB_WH;
+            if (l == net.skip_layer) mma_stream<RB, RB, 32 * RB, SH::SLOT, RB + 2>(u, za, ring, (const WE*)net.wt[l], wn, nbts, lane);
+            else mma_stream<RB, RB, 32 * RB, SH::SLOT>(u, za, ring, (const WE*)net.wt[l], wn, nbts, lane);
         }
     }
 }

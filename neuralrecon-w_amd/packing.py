@@ -152,9 +152,19 @@ class PackPlan:
         L.check(lib.ncw_pack_weights(L.ptr(self._pack_tab), L.ptr(self._pack_prefix), self._pack_n,
                                      self._pack_rows, L.stream_ptr(self.device)), "ncw_pack_weights")
 
-    def unpack_grads(self, accumulate_into):
-        """accumulate_into: dict id(param) -> grad tensor (same shape, fp32, contiguous).  Writes the
-        parameter gradients from the dense gradient arena."""
+    def unpack_grads(self, accumulate_into, accumulate=False):
+        """accumulate_into: dict id(param) -> grad tensor (same shape, fp32, contiguous).  Writes (or,
+        with accumulate=True, adds) the parameter gradients from the dense gradient arena.  The device
+        descriptor table is cached by content, so the steady state does no host->device copy."""
+        key = (bool(accumulate),) + tuple(accumulate_into[id(u["weight"])].data_ptr() for u in self._unpack) \
+            + tuple(u["weight"].data_ptr() for u in self._unpack)
+        cache = self.__dict__.setdefault("_unpack_cache", {})
+        hit = cache.get(key)
+        if hit is not None:
+            tab, pre, n, rows = hit
+            L.check(L.get_lib().ncw_unpack_grads(L.ptr(tab), L.ptr(pre), n, rows, L.stream_ptr(self.device)),
+                    "ncw_unpack_grads")
+            return tab, pre
         descs, prefix = [], [0]
         for u in self._unpack:
             d = L.NcwUnpackDesc()
@@ -169,7 +179,7 @@ class PackPlan:
             d.ld, d.ldw = w.shape[1], self.dense_ld(u["dense"])
             d.row0, d.nrows, d.drow0 = u["row0"], u["nrows"], u["drow0"]
             d.scale = u["scale"]
-            d.accumulate = 0
+            d.accumulate = 1 if accumulate else 0
             d.nseg = len(u["segs"])
             for i, (c0, nc, dc0) in enumerate(u["segs"]):
                 d.seg[i].col0, d.seg[i].ncols, d.seg[i].dcol0 = c0, nc, dc0
@@ -180,4 +190,7 @@ class PackPlan:
         lib = L.get_lib()
         L.check(lib.ncw_unpack_grads(L.ptr(tab), L.ptr(pre), len(descs), prefix[-1], L.stream_ptr(self.device)),
                 "ncw_unpack_grads")
+        if len(cache) > 8:
+            cache.clear()
+        cache[key] = (tab, pre, len(descs), prefix[-1])
         return tab, pre  # keep alive until the stream has consumed them

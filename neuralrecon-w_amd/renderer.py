@@ -97,17 +97,28 @@ class _RenderFn(torch.autograd.Function):
         b_in.run()
         if b_bg is not None:
             b_bg.run()
-        # parameter gradients: one flat buffer, views per parameter (order of ctx.params)
-        sizes = [p.numel() for p in ctx.params]
-        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
-        views, off = {}, 0
-        out = []
-        for p, n in zip(ctx.params, sizes):
-            v = flat[off:off + n].view(p.shape)
-            views[id(p)] = v
-            out.append(v)
-            off += n
-        keep = [pl.unpack_grads(views) for pl in plans]
+        # parameter gradients land in ONE persistent flat fp32 buffer whose views ARE the parameters'
+        # .grad (the DDP all-reduce operand, ddp.py): no per-parameter copies, no per-step allocation.
+        flat, views = rdr._grad_views(ctx.params)
+        fresh = all(p.grad is None for p in ctx.params)
+        ours = (not fresh) and all(p.grad is not None and p.grad.data_ptr() == views[id(p)].data_ptr()
+                                   for p in ctx.params)
+        out = [None] * len(ctx.params)
+        if fresh or ours:
+            keep = [pl.unpack_grads(views, accumulate=ours) for pl in plans]
+            if fresh:
+                for p in ctx.params:
+                    p.grad = views[id(p)]
+        else:  # foreign .grad tensors present: hand the gradients to autograd instead
+            tmp = torch.zeros_like(flat)
+            tviews, off = {}, 0
+            out = []
+            for p in ctx.params:
+                v = tmp[off:off + p.numel()].view(p.shape)
+                tviews[id(p)] = v
+                out.append(v)
+                off += p.numel()
+            keep = [pl.unpack_grads(tviews) for pl in plans]
         ctx._keep = (keep, b_in, b_bg)
         inv_s = ctx.inv_s
         live = ((inv_s > 1e-6) & (inv_s < 1e6)).float()
@@ -230,6 +241,23 @@ class NeuconWRenderer:
         v_near = torch.where(miss, near, (surf - rng) / self.radius)
         v_far = torch.where(miss, far, (surf + rng) / self.radius)
         return v_near, v_far, ~miss
+
+    def _grad_views(self, params):
+        key = tuple(id(p) for p in params)
+        c = self.__dict__.get("_gv")
+        if c is None or c[0] != key or c[1].device != params[0].device:
+            flat = torch.zeros(sum(p.numel() for p in params), device=params[0].device, dtype=torch.float32)
+            views, off = {}, 0
+            for p in params:
+                views[id(p)] = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self._gv = c = (key, flat, views)
+        return c[1], c[2]
+
+    def flat_grad_buffer(self):
+        """The persistent flat gradient buffer of (sdf, colour, background) parameters, or None."""
+        c = self.__dict__.get("_gv")
+        return None if c is None else c[1]
 
     # ---- render (renderer.py:785-916) ---------------------------------------------------------------
     def _params(self):

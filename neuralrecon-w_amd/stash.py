@@ -14,6 +14,8 @@ class StashArena:
         self.prec = prec
         self.n = int(n_points)
         self.tiles = (self.n + 31) // 32
+        # kernels run whole workgroups (<= 8 waves = 8 tiles): pad so surplus waves store into padding
+        self.tiles_alloc = (self.tiles + 7) // 8 * 8
         self.esize = 4 if prec == L.PREC_F32 else 2
         self._off = []
         self._bytes = 0
@@ -21,7 +23,7 @@ class StashArena:
 
     def new(self, rb):
         off = self._bytes
-        self._bytes += self.tiles * rb * 1024 * self.esize
+        self._bytes += self.tiles_alloc * rb * 1024 * self.esize
         self._bytes = (self._bytes + 255) & ~255
         self._off.append((off, rb))
         return len(self._off) - 1
@@ -63,12 +65,21 @@ class WgradBatch:
     def add(self, x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr=0):
         self.items.append((x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr))
 
+    _cache = {}  # content-addressed device tables: (items, prec, n) -> (table, prefix, n_desc, wgs, ksplit)
+
     def run(self):
         if not self.items or self.n == 0:
             return
         tiles = (self.n + 31) // 32
         chunk_tiles = 2 if self.prec == L.PREC_BF16 else 1
         ksplit = max(1, min(16, tiles // (8 * chunk_tiles)))
+        key = (tuple(self.items), self.prec, self.n, str(self.device))
+        hit = WgradBatch._cache.get(key)
+        if hit is not None:
+            tab, pre, nd, wgs, ks = hit
+            L.check(L.get_lib().ncw_wgrad(L.ptr(tab), L.ptr(pre), nd, wgs, ks, self.prec, self.n,
+                                          L.stream_ptr(self.device)), "ncw_wgrad")
+            return
         descs, prefix = [], [0]
         for (x, rbx, y, rby, dense, ld, db) in self.items:
             d = L.NcwWgradDesc()
@@ -81,4 +92,6 @@ class WgradBatch:
         pre = torch.tensor(prefix, dtype=torch.int32, device=self.device)
         L.check(L.get_lib().ncw_wgrad(L.ptr(tab), L.ptr(pre), len(descs), prefix[-1], ksplit, self.prec, self.n,
                                       L.stream_ptr(self.device)), "ncw_wgrad")
-        self._keep = (tab, pre)
+        if len(WgradBatch._cache) > 16:
+            WgradBatch._cache.clear()
+        WgradBatch._cache[key] = (tab, pre, len(descs), prefix[-1], ksplit)
