@@ -151,6 +151,175 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const NcwWgradDesc* __restri
     if (do_bias) atomicAdd(&D.dbias[4 * qi * 32 + tid], bsum);
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 fast path: no scatter-transpose.  The stash bytes of a chunk are copied VERBATIM into LDS (8-byte
+// rows of "4 features of one point", padded 288-byte rows -> conflict-free) and the MFMA operands
+// "8 points of one feature" are produced by the hardware transpose read ds_read_b64_tr_b16:
+//   within a 16-lane group, out[lane i][j] = src[lane 4j + i/4][i % 4]      (probed on gfx950,
+//   scripts/probes/tr16_probe.hip), so with source lane s pointing at (point p0 + s/4, features
+//   f0 + 4 (s%4) ..+3) lane i receives feature f0 + i of points p0..p0+3.
+// Workgroup tile = 128 (X features) x 256 (Y features), 4 waves as 2x2, each 2x4 blocks of 32x32;
+// chunk = 64 points; next chunk's global loads are in flight during the MFMAs (register staging).
+// ------------------------------------------------------------------------------------------------
+#define WG2_CP 64                 // points per chunk (2 stash tiles)
+#define WG2_ROWB 288              // LDS row: 32 points x 8 B + 32 B pad
+#define WG2_XB 4                  // X blocks per workgroup
+#define WG2_YB 8                  // Y blocks per workgroup
+#define WG2_ROWS_PER_TILE ((WG2_XB + WG2_YB) * 8)
+#define WG2_BUF_BYTES (2 * WG2_ROWS_PER_TILE * WG2_ROWB)
+
+// transpose read of 4 points x (this lane's feature) through the compiler-tracked builtin (the
+// compiler counts lgkmcnt and schedules the reads against the MFMAs; an inline-asm version raced:
+// hipcc copied the asm's destination registers before the data had landed)
+typedef short ncw_s16x4 __attribute__((ext_vector_type(4)));
+typedef short ncw_s16x8 __attribute__((ext_vector_type(8)));
+NCW_DEV bf16x8 tr_frag(const char* lds_ptr) {
+    typedef __attribute__((address_space(3))) ncw_s16x4* lp;
+    const ncw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds_ptr));        // points +0..3
+    const ncw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds_ptr + 32));   // points +4..7
+    const ncw_s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const NcwWgradDesc* __restrict__ descs,
+                                                         const int32_t* __restrict__ prefix, int n_desc, int ksplit,
+                                                         int64_t ntiles) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * WG2_BUF_BYTES];
+    const int d = wg_find(prefix, n_desc, blockIdx.x);
+    const NcwWgradDesc D = descs[d];
+    const int local = blockIdx.x - prefix[d];
+    const int quad = local / ksplit, ks = local - quad * ksplit;
+    const int nqj = (D.rby + WG2_YB - 1) / WG2_YB;
+    const int qi = quad / nqj, qj = quad - qi * nqj;
+    const int nbi = min(WG2_XB, D.rbx - WG2_XB * qi), nbj = min(WG2_YB, D.rby - WG2_YB * qj);
+    const int64_t tpk = ((ntiles + ksplit - 1) / ksplit + 1) & ~(int64_t)1;  // even number of tiles per slice
+    const int64_t t_begin = (int64_t)ks * tpk, t_end = min(t_begin + tpk, ntiles);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wi = wave >> 1, wj = wave & 1;  // wave tile: i-blocks 2wi..2wi+1, j-blocks 4wj..4wj+3
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    const bool do_bias = (D.dbias != nullptr) && (qj == 0) && (wj == 0);
+    // ---- staging bookkeeping: 12 blocks x 4 g x 2 tiles = 96 wave-loads per chunk, 24 per wave ----------
+    const __bf16* xg = (const __bf16*)D.x;
+    const __bf16* yg = (const __bf16*)D.y;
+    constexpr int NLD = (WG2_XB + WG2_YB) * 4 * 2 / 4;  // wave-loads per wave per chunk
+    uint2 stg[NLD];
+    // Branch-free loads (clamped, always-valid addresses) so that all 24 are in flight together;
+    // out-of-range tiles / blocks are zeroed when they are written to LDS.
+    auto issue_loads = [&](int64_t t0) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int it = wave + 4 * k;          // 0..95
+            const int g = it & 3;
+            const int blk = (it >> 2) % (WG2_XB + WG2_YB);
+            const int tp = (it >> 2) / (WG2_XB + WG2_YB);
+            const int64_t tile = min(t0 + tp, t_end - 1);
+            const bool isx = blk < WG2_XB;
+            const int bsel = isx ? min(blk, nbi - 1) : min(blk - WG2_XB, nbj - 1);
+            const __bf16* base = isx ? xg : yg;
+            const int rb = isx ? D.rbx : D.rby;
+            const int b0 = isx ? WG2_XB * qi : WG2_YB * qj;
+            // explicit GLOBAL address space: a flat load would also count on lgkmcnt and stall the LDS waits
+            typedef const __attribute__((address_space(1))) unsigned long long* gptr_t;
+            const unsigned long long raw = *(gptr_t)(base + ((((size_t)tile * rb + (b0 + bsel)) * 4 + g) * 64 + lane) * 4);
+            stg[k] = make_uint2((unsigned)raw, (unsigned)(raw >> 32));
+        }
+    };
+    auto load_ok = [&](int k, int64_t t0) -> bool {
+        const int it = wave + 4 * k;
+        const int blk = (it >> 2) % (WG2_XB + WG2_YB);
+        const int tp = (it >> 2) / (WG2_XB + WG2_YB);
+        const bool bok = blk < WG2_XB ? blk < nbi : (blk - WG2_XB) < nbj;
+        return bok && (t0 + tp < t_end);
+    };
+    auto write_lds = [&](char* buf, int64_t t0) {
+        const int p = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int it = wave + 4 * k;
+            const int g = it & 3;
+            const int blk = (it >> 2) % (WG2_XB + WG2_YB);
+            const int tp = (it >> 2) / (WG2_XB + WG2_YB);
+            const int row = (tp * (WG2_XB + WG2_YB) + blk) * 8 + 2 * g + h;
+            const bool ok = load_ok(k, t0);
+            uint2 v = stg[k];
+            v.x = ok ? v.x : 0u;
+            v.y = ok ? v.y : 0u;
+            *reinterpret_cast<uint2*>(buf + row * WG2_ROWB + p * 8) = v;
+        }
+    };
+    // per-lane constant part of the transpose-read address
+    const int q = lane >> 4, s = lane & 15;
+    const int kh = q >> 1, fhalf = q & 1;
+    const int fsrc = 16 * fhalf + 4 * (s & 3);
+    const int row_in_blk = 2 * (fsrc >> 3) + ((fsrc >> 2) & 1);
+    const int psrc = 8 * kh + (s >> 2);
+    const unsigned lane_off = row_in_blk * WG2_ROWB + psrc * 8;
+
+    int cur = 0;
+    if (t_begin < t_end) {
+        issue_loads(t_begin);
+        write_lds(lds, t_begin);
+    }
+    __syncthreads();
+    for (int64_t t0 = t_begin; t0 < t_end; t0 += 2) {
+        const bool has_next = t0 + 2 < t_end;
+        if (has_next) issue_loads(t0 + 2);
+        const char* bufp = lds + cur * WG2_BUF_BYTES;
+#pragma unroll
+        for (int kstep = 0; kstep < WG2_CP / 16; ++kstep) {
+            const int tp = kstep >> 1, pb = 16 * (kstep & 1);
+            const char* kbase = bufp + tp * (WG2_ROWS_PER_TILE * WG2_ROWB) + pb * 8 + lane_off;
+            bf16x8 af[2], bfr[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = tr_frag(kbase + (2 * wi + a) * 8 * WG2_ROWB);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bfr[b] = tr_frag(kbase + (WG2_XB + 4 * wj + b) * 8 * WG2_ROWB);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sacc += (float)af[a][e];
+                bsum[a] += sacc;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (has_next) write_lds(lds + (cur ^ 1) * WG2_BUF_BYTES, t0 + 2);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- epilogue -----------------------------------------------------------------------------------
+    if (t_begin >= t_end) return;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int ib = 2 * wi + a;
+        if (ib >= nbi) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int jb = 4 * wj + b;
+            if (jb >= nbj) continue;
+            const int col = (WG2_YB * qj + jb) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (WG2_XB * qi + ib) * 32 + ncw_feat_of(r, lane >> 5);
+                atomicAdd(&D.dense[(size_t)row * D.ld + col], acc[a][b][r]);
+            }
+        }
+        if (do_bias) {
+            const float tot = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+            if (lane < 32) atomicAdd(&D.dbias[(WG2_XB * qi + ib) * 32 + lane], tot);
+        }
+    }
+}
+
 extern "C" int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
                          int prec, int64_t n_points, void* stream) {
     if (n_desc <= 0 || total_wgs <= 0 || n_points <= 0) return 0;
@@ -158,7 +327,7 @@ extern "C" int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, in
     const int64_t ntiles = (n_points + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (prec == NCW_PREC_BF16)
-        hipLaunchKernelGGL(wgrad_kernel<PrecBF16>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+        hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
     else if (prec == NCW_PREC_F32)
         hipLaunchKernelGGL(wgrad_kernel<PrecF32>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
     else return NCW_E_BADARG;

@@ -86,7 +86,9 @@ class WgradBatch:
             d.x, d.y, d.dense, d.dbias = x, y, dense, db
             d.rbx, d.rby, d.ld = rbx, rby, ld
             descs.append(d)
-            prefix.append(prefix[-1] + ((rbx + 3) // 4) * ((rby + 3) // 4) * ksplit)
+            # workgroup tile: 128 x 128 (f32 kernel) or 128 x 256 (bf16 transpose-read kernel)
+            yb = 8 if self.prec == L.PREC_BF16 else 4
+            prefix.append(prefix[-1] + ((rbx + 3) // 4) * ((rby + yb - 1) // yb) * ksplit)
         arr = (L.NcwWgradDesc * len(descs))(*descs)
         tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         pre = torch.tensor(prefix, dtype=torch.int32, device=self.device)
