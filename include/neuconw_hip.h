@@ -279,6 +279,20 @@ int ncw_boundary(const float* near, const float* far, const float* z, int n, int
                  void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Voxel guidance (config 3): native replacement of kaolin's SPC ray tracing used by
+ * tools/prepare_data/generate_voxel.py:311-439 / renderer.py:380-456.  Occupancy = bit-packed dense
+ * grid of side 2^level over [-1,1]^3 (x slowest) + 8^3-brick mask.  3 <= level <= 10.
+ * ---------------------------------------------------------------------------------------- */
+/* set the voxels containing the given normalised points (atomicOr; occ/brick must be zeroed first):
+ * occ  uint32[(2^level)^3 / 32], brick uint32[ceil((2^level / 8)^3 / 32)] */
+int ncw_voxel_build(const float* pts_normalised, int64_t n, int level, uint32_t* occ, uint32_t* brick, void* stream);
+/* per ray: entry depth (SfM units) of the first / last occupied voxel; 0 where the ray misses or
+ * near <= 1e-4 (generate_voxel.py:397).  scene_origin_host: HOST float[3]. */
+int ncw_ray_voxel_near_far(const float* rays_o_sfm, const float* rays_d, int R, const float* scene_origin_host,
+                           float scale, int level, const uint32_t* occ, const uint32_t* brick, float* near_sfm,
+                           float* far_sfm, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Compositor: renderer.py:205-216 (background alpha) + :586-783 (render_core after the networks).
  * HOST structs of device pointers.
  * ---------------------------------------------------------------------------------------- */

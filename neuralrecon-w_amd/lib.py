@@ -118,6 +118,9 @@ NcwCompositeGrad = _ptr_struct(
 
 _VP = C.c_void_p
 _PROTOS = {
+    "ncw_voxel_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ncw_ray_voxel_near_far": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ncw_color_fwd": (C.c_int, [C.POINTER(NcwColorNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NcwColorStash), C.c_void_p]),
     "ncw_color_bwd": (C.c_int, [C.POINTER(NcwColorNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p,

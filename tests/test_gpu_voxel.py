@@ -1,0 +1,78 @@
+"""Config 3 (voxel-guided sampling): native ray / voxel near-far against the brute-force slab oracle,
+and the whole render() with a fine octree window + boundary samples against the oracle."""
+import math
+
+import pytest
+import torch
+
+from tests._build import build_system, state_dict_cpu
+from tests._util import rel_err, synth_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def _shell(level, r0=0.5, thick=0.06):
+    G = 1 << level
+    c = (torch.arange(G).float() + 0.5) * (2.0 / G) - 1.0
+    x, y, z = torch.meshgrid(c, c, c, indexing="ij")
+    rad = (x * x + y * y + z * z).sqrt()
+    return (rad - r0).abs() < thick
+
+
+@pytest.mark.parametrize("level", [4, 6])
+def test_ray_voxel_near_far_vs_bruteforce(level):
+    from neuralrecon_w_amd import voxel
+    from oracle import neuconw_oracle as O
+
+    occ = _shell(level)
+    origin, scale = torch.tensor([0.1, -0.05, 0.2]), 1.7
+    R = 500
+    rays, _, _, _ = synth_rays(R, 5, 10)
+    o = rays[:, 0:3] * scale + origin  # SfM-space origins looking at the shell
+    d = rays[:, 3:6]
+    o[:50] = origin + 0.01 * torch.randn(50, 3)           # rays starting inside the cube, at the shell centre
+    d[50:60] = torch.nn.functional.normalize(torch.randn(10, 3), dim=-1)  # some rays that miss
+    o[50:60] = origin + torch.tensor([5.0, 5.0, 5.0])
+    near_ref, far_ref = O.ray_voxel_near_far(o.double(), d.double(), occ, origin.double(), scale)
+    od = voxel.occupancy_from_dense(occ.cuda(), origin, scale)
+    near, far = voxel.get_near_far(o.cuda(), d.cuda(), od)
+    near, far = near.cpu(), far.cpu()
+    hit_ref = near_ref > 0
+    assert torch.equal(near > 0, hit_ref)
+    assert int(hit_ref.sum()) > 300 and int((~hit_ref).sum()) >= 10
+    assert rel_err(near[hit_ref], near_ref[hit_ref]) < 1e-5
+    assert rel_err(far[hit_ref], far_ref[hit_ref]) < 1e-5
+    assert bool((far >= near).all())
+
+
+def test_render_with_fine_octree_window_and_boundary_samples():
+    """sampler narrowed to surface +- SAMPLE_RANGE voxels, 10 boundary samples (renderer.py:415-456, 549-566)."""
+    import neuralrecon_w_amd as nw
+    from neuralrecon_w_amd import voxel
+    from oracle import neuconw_oracle as O
+
+    level = 6
+    occ = _shell(level, 0.5, 0.05)
+    emb, neuconw, nerf, rdr = build_system(prec=nw.PREC_F32, n_samples=16, n_importance=16, boundary_samples=10,
+                                           sample_range=4, seed=11)
+    with torch.no_grad():
+        for n, p in neuconw.named_parameters():
+            if n.endswith("weight_g"):
+                p.mul_(1.0 + 0.05 * torch.randn_like(p))
+    vs = 2.0 / (1 << level)
+    rdr.fine_octree_data = voxel.occupancy_from_dense(occ.cuda(), torch.zeros(3), 1.0, voxel_size=vs)
+    R = 96
+    rays, ts, label, rgbs = synth_rays(R, 8, 64)
+    out = rdr.render(rays.cuda(), ts.cuda(), label.cuda(), perturb_overwrite=0, background_rgb=torch.zeros(1, 3).cuda(),
+                     cos_anneal_ratio=0.5)
+    sd = state_dict_cpu(emb, neuconw, nerf, torch.float32)
+    cfg = dict(n_samples=16, n_importance=16, n_outside=4, up_sample_steps=2, s_val_base=3, render_bg=True,
+               trim_sphere=True, mesh_mask_list=["sky"], depth_loss=True, skip_in=(4,), multires=6, multires_view=4,
+               boundary_samples=10, sample_range=4, radius=1.0)
+    fine = dict(occ=occ, scene_origin=torch.zeros(3), scale=1.0, voxel_size=vs)
+    ref = O.render(sd, cfg, rays, ts, label, 0.5, torch.zeros(1, 3), fine_octree=fine)
+    assert out["weights"].shape == ref["weights"].shape == (R, 16 + 16 + 10 + 4)
+    for k in ("color", "depth", "weights_sum", "gradient_error", "mask_error", "sfm_depth_loss", "color_bg"):
+        assert rel_err(out[k].detach().cpu(), ref[k]) < 2e-4, (k, rel_err(out[k].detach().cpu(), ref[k]))
+    for k in ("weights", "cdf_fine", "gradients"):
+        assert rel_err(out[k].detach().cpu(), ref[k]) < 2e-3, (k, rel_err(out[k].detach().cpu(), ref[k]))
