@@ -132,8 +132,20 @@ typedef struct NcwPoints {
     const float* z;            /* modes 1,2: [R,per_ray]                                     */
     const float* sample_dist;  /* mode 2: [R]                                                */
     int32_t per_ray;
-    int32_t mode;              /* 0: x;  1: o + d z;  2: section mid-point o + d (z_i + dist_i/2) */
+    int32_t mode;              /* 0: x;  1: o + d z;  2: section mid-point o + d (z_i + dist_i/2);
+                                  3: regular grid generated on chip (utils/visualization.py:46-50)  */
+    /* mode 3: point p (+ grid_start) of linspace(gmin, gmax, gdim)^3, meshgrid 'ij' (x slowest),
+     * mapped to the unit sphere as (x - gorigin) / gradius. */
+    float gmin[3], gmax[3], gorigin[3], gradius;
+    int32_t gdim;
+    int32_t _gpad;
+    int64_t gstart;
 } NcwPoints;
+
+/* config 5 (tools/extract_mesh.py / utils/visualization.py:37-85): sdf of `count` points of the regular grid
+ * described by pts (mode 3) starting at linear index pts->gstart; no coordinate array ever exists. */
+int ncw_sdf_infer_points(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t count, float* sdf, void* stream);
+
 
 /* Activation stash of the SDF net in fragment-native layout [tile32][blocks][4][64 lanes][4]
  * (element = f32 for prec 0, bf16 for prec 1).  HOST struct of device pointers.

@@ -10,7 +10,23 @@ struct Fast { static constexpr bool v = (P::id == NCW_PREC_BF16); };
 // ---- point of lane ---------------------------------------------------------------------------
 // mode 0: x[p];  1: o + d z[p];  2: o + d (z_i + dist_i / 2) with dist_i = z_{i+1} - z_i, last =
 // sample_dist  (renderer.py:586-597 / :172-179)
+NCW_DEV float grid_linspace(float start, float end, int steps, int i) {  // torch.linspace element i
+    if (steps == 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+}
+
 NCW_DEV void load_point(const NcwPoints& s, int64_t p, float (&xs)[3], int64_t& ray) {
+    if (s.mode == 3) {
+        const int64_t q = p + s.gstart;
+        const int64_t d = s.gdim;
+        const int iz = (int)(q % d), iy = (int)((q / d) % d), ix = (int)(q / (d * d));
+        xs[0] = (grid_linspace(s.gmin[0], s.gmax[0], s.gdim, ix) - s.gorigin[0]) / s.gradius;
+        xs[1] = (grid_linspace(s.gmin[1], s.gmax[1], s.gdim, iy) - s.gorigin[1]) / s.gradius;
+        xs[2] = (grid_linspace(s.gmin[2], s.gmax[2], s.gdim, iz) - s.gorigin[2]) / s.gradius;
+        ray = p;
+        return;
+    }
     if (s.mode == 0) {
         xs[0] = s.x[p * 3 + 0]; xs[1] = s.x[p * 3 + 1]; xs[2] = s.x[p * 3 + 2];
         ray = p;

@@ -377,16 +377,22 @@ static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, i
 }
 
 extern "C" int ncw_sdf_infer(const NcwSdfNet* net, int prec, const float* x, int64_t n, float* sdf, void* stream) {
-    NcwPoints src;
+    NcwPoints src = {};
     src.x = x; src.rays_o = nullptr; src.rays_d = nullptr; src.z = nullptr; src.sample_dist = nullptr;
     src.per_ray = 1; src.mode = 0;
     return sdf_infer_any(net, prec, src, n, sdf, stream);
 }
 
+extern "C" int ncw_sdf_infer_points(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t count, float* sdf,
+                                    void* stream) {
+    if (!pts) return NCW_E_BADARG;
+    return sdf_infer_any(net, prec, *pts, count, sdf, stream);
+}
+
 extern "C" int ncw_sdf_infer_rays(const NcwSdfNet* net, int prec, const float* rays_o, const float* rays_d,
                                   const float* z, int R, int n, float* sdf, void* stream) {
     if (R < 0 || n <= 0) return NCW_E_BADARG;
-    NcwPoints src;
+    NcwPoints src = {};
     src.x = nullptr; src.rays_o = rays_o; src.rays_d = rays_d; src.z = z; src.sample_dist = nullptr;
     src.per_ray = n; src.mode = 1;
     return sdf_infer_any(net, prec, src, (int64_t)R * n, sdf, stream);

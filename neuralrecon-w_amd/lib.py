@@ -49,7 +49,9 @@ class NcwSdfNet(C.Structure):
 
 class NcwPoints(C.Structure):
     _fields_ = [("x", C.c_void_p), ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("z", C.c_void_p),
-                ("sample_dist", C.c_void_p), ("per_ray", C.c_int32), ("mode", C.c_int32)]
+                ("sample_dist", C.c_void_p), ("per_ray", C.c_int32), ("mode", C.c_int32),
+                ("gmin", C.c_float * 3), ("gmax", C.c_float * 3), ("gorigin", C.c_float * 3), ("gradius", C.c_float),
+                ("gdim", C.c_int32), ("_gpad", C.c_int32), ("gstart", C.c_int64)]
 
 
 class NcwSdfStash(C.Structure):
@@ -118,6 +120,8 @@ NcwCompositeGrad = _ptr_struct(
 
 _VP = C.c_void_p
 _PROTOS = {
+    "ncw_sdf_infer_points": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p,
+                                       C.c_void_p]),
     "ncw_voxel_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ncw_ray_voxel_near_far": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
