@@ -8,7 +8,7 @@ from torch import nn
 from . import lib as L
 from .neuconw import _PackedNet, _wvb, default_prec, points_struct
 from .packing import PackPlan
-from .stash import StashArena
+from .stash import StashArena, StashCache
 
 
 class NeRF(_PackedNet):
@@ -94,29 +94,36 @@ class NeRF(_PackedNet):
         dev = self._first_param().device
         plan = self.packed(prec)
         RBN, RBH = self.W // 32, self.W // 64
-        ar = StashArena(dev, prec, n)
-        ids = dict(gp=ar.new(3), aux1=ar.new(3), featn=ar.new(RBN), zalpha=ar.new(1), zfeat=ar.new(RBN),
-                   zrgb=ar.new(1))
-        ids["h"] = {i: ar.new(RBN) for i in range(1, self.D + 1)}
-        ids["zp"] = [ar.new(RBN) for _ in range(self.D)]
-        ids["e"] = [ar.new(RBH) for _ in range(self.n_head)]
-        ids["ze"] = [ar.new(RBH) for _ in range(self.n_head)]
-        ar.allocate()
-        st = L.NcwNerfStash()
-        for k in ("gp", "aux1", "featn", "zalpha", "zfeat", "zrgb"):
-            setattr(st, k, ar.ptr(ids[k]))
-        for i, v in ids["h"].items():
-            st.h[i] = ar.ptr(v)
-        for k in ("zp", "e", "ze"):
-            for i, v in enumerate(ids[k]):
-                getattr(st, k)[i] = ar.ptr(v)
+
+        def build():
+            ar = StashArena(dev, prec, n)
+            ids = dict(gp=ar.new(3), aux1=ar.new(3), featn=ar.new(RBN), zalpha=ar.new(1), zfeat=ar.new(RBN),
+                       zrgb=ar.new(1))
+            ids["h"] = {i: ar.new(RBN) for i in range(1, self.D + 1)}
+            ids["zp"] = [ar.new(RBN) for _ in range(self.D)]
+            ids["e"] = [ar.new(RBH) for _ in range(self.n_head)]
+            ids["ze"] = [ar.new(RBH) for _ in range(self.n_head)]
+            ar.allocate()
+            st = L.NcwNerfStash()
+            for k in ("gp", "aux1", "featn", "zalpha", "zfeat", "zrgb"):
+                setattr(st, k, ar.ptr(ids[k]))
+            for i, v in ids["h"].items():
+                st.h[i] = ar.ptr(v)
+            for k in ("zp", "e", "ze"):
+                for i, v in enumerate(ids[k]):
+                    getattr(st, k)[i] = ar.ptr(v)
+            return dict(arena=ar, ids=ids, stash=st)
+
+        ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev)), build)
+        ar, ids, st = ent["arena"], ent["ids"], ent["stash"]
         density = torch.empty(n, device=dev, dtype=torch.float32)
         rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
         a = a.contiguous().float()
         x4c = x4.contiguous().float() if x4 is not None else None
         L.check(L.get_lib().ncw_nerf_fwd(plan.net, prec, pts, L.ptr(x4c), n, L.ptr(a), L.ptr(density), L.ptr(rgb), st,
                                          L.stream_ptr(dev)), "ncw_nerf_fwd")
-        return density, rgb, dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, keep=(a, x4c))
+        return density, rgb, dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, keep=(a, x4c),
+                                  lease=ent)
 
     def bwd_stash(self, ctx, d_density, d_rgb, d_a):
         dev = self._first_param().device
@@ -163,5 +170,6 @@ class NeRF(_PackedNet):
         prec = default_prec() if prec is None else prec
         n = input_pts.shape[0]
         pts = points_struct(x=input_pts[:, :3].contiguous(), rays_d=input_views.contiguous().float())
-        density, rgb, _ = self.fwd_stash(pts, n, prec, embedding_a, x4=input_pts)
+        density, rgb, c = self.fwd_stash(pts, n, prec, embedding_a, x4=input_pts)
+        StashCache.release(c["lease"])
         return density.reshape(n, 1), rgb

@@ -12,7 +12,7 @@ from torch import nn
 
 from . import lib as L
 from .packing import PackPlan
-from .stash import StashArena, WgradBatch
+from .stash import StashArena, StashCache, WgradBatch
 
 
 def points_struct(x=None, rays_o=None, rays_d=None, z=None, sample_dist=None, mode=0):
@@ -209,25 +209,31 @@ class SDFNetwork(nn.Module):
         dev = self.lin0.bias.device
         plan = self.packed(prec)
         RB, Lm = self.d_hidden // 32, self.n_lin
-        ar = StashArena(dev, prec, n)
-        ids = dict(gamma=ar.new(2), feat=ar.new(RB), dfeat=ar.new(RB), zsdf=ar.new(1), one=ar.new(1))
-        ids["h"] = {l: ar.new(RB) for l in range(1, Lm)}
-        ids["s"] = {l: ar.new(RB) for l in range(Lm - 1)}
-        ids["t"] = {l: ar.new(RB) for l in range(Lm - 1)}
-        ids["qbar"] = {l: ar.new(2 if l == 0 else RB) for l in range(Lm)}
-        ids["zbar"] = {l: ar.new(RB) for l in range(Lm - 1)}
-        ar.allocate()
-        st = L.NcwSdfStash()
-        st.gamma, st.feat, st.dfeat = ar.ptr(ids["gamma"]), ar.ptr(ids["feat"]), ar.ptr(ids["dfeat"])
-        st.zsdf, st.one = ar.ptr(ids["zsdf"]), ar.ptr(ids["one"])
-        for k in ("h", "s", "t", "qbar", "zbar"):
-            for l, i in ids[k].items():
-                getattr(st, k)[l] = ar.ptr(i)
+
+        def build():
+            ar = StashArena(dev, prec, n)
+            ids = dict(gamma=ar.new(2), feat=ar.new(RB), dfeat=ar.new(RB), zsdf=ar.new(1), one=ar.new(1))
+            ids["h"] = {l: ar.new(RB) for l in range(1, Lm)}
+            ids["s"] = {l: ar.new(RB) for l in range(Lm - 1)}
+            ids["t"] = {l: ar.new(RB) for l in range(Lm - 1)}
+            ids["qbar"] = {l: ar.new(2 if l == 0 else RB) for l in range(Lm)}
+            ids["zbar"] = {l: ar.new(RB) for l in range(Lm - 1)}
+            ar.allocate()
+            st = L.NcwSdfStash()
+            st.gamma, st.feat, st.dfeat = ar.ptr(ids["gamma"]), ar.ptr(ids["feat"]), ar.ptr(ids["dfeat"])
+            st.zsdf, st.one = ar.ptr(ids["zsdf"]), ar.ptr(ids["one"])
+            for k in ("h", "s", "t", "qbar", "zbar"):
+                for l, i in ids[k].items():
+                    getattr(st, k)[l] = ar.ptr(i)
+            return dict(arena=ar, ids=ids, stash=st)
+
+        ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev)), build)
+        ar, ids, st = ent["arena"], ent["ids"], ent["stash"]
         sdf = torch.empty(n, device=dev, dtype=torch.float32)
         grad = torch.empty(n, 3, device=dev, dtype=torch.float32)
         L.check(L.get_lib().ncw_sdf_fwd(plan.net, prec, pts, n, L.ptr(sdf), L.ptr(grad), st, L.stream_ptr(dev)),
                 "ncw_sdf_fwd")
-        ctx = dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan)
+        ctx = dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, lease=ent)
         return sdf, grad, ctx
 
     def bwd_stash(self, ctx, d_sdf, d_grad):
@@ -368,26 +374,32 @@ class RenderingNetwork(_PackedNet):
         dev = self._first_param().device
         plan = self.packed(prec)
         RBF, RBH, RBC = self.d_feature // 32, self.head_channels // 32, self.d_hidden // 32
-        ar = StashArena(dev, prec, n)
-        ids = dict(aux1=ar.new(3), aux2=ar.new(1), f=ar.new(RBF), zf=ar.new(RBF), zo=ar.new(1))
-        ids["e"] = [ar.new(RBH) for _ in range(self.n_head)]
-        ids["ze"] = [ar.new(RBH) for _ in range(self.n_head)]
-        ids["x"] = [ar.new(RBC) for _ in range(self.n_lin - 1)]
-        ids["zx"] = [ar.new(RBC) for _ in range(self.n_lin - 1)]
-        ar.allocate()
-        st = L.NcwColorStash()
-        for k in ("aux1", "aux2", "f", "zf", "zo"):
-            setattr(st, k, ar.ptr(ids[k]))
-        for k in ("e", "ze", "x", "zx"):
-            for i, v in enumerate(ids[k]):
-                getattr(st, k)[i] = ar.ptr(v)
+
+        def build():
+            ar = StashArena(dev, prec, n)
+            ids = dict(aux1=ar.new(3), aux2=ar.new(1), f=ar.new(RBF), zf=ar.new(RBF), zo=ar.new(1))
+            ids["e"] = [ar.new(RBH) for _ in range(self.n_head)]
+            ids["ze"] = [ar.new(RBH) for _ in range(self.n_head)]
+            ids["x"] = [ar.new(RBC) for _ in range(self.n_lin - 1)]
+            ids["zx"] = [ar.new(RBC) for _ in range(self.n_lin - 1)]
+            ar.allocate()
+            st = L.NcwColorStash()
+            for k in ("aux1", "aux2", "f", "zf", "zo"):
+                setattr(st, k, ar.ptr(ids[k]))
+            for k in ("e", "ze", "x", "zx"):
+                for i, v in enumerate(ids[k]):
+                    getattr(st, k)[i] = ar.ptr(v)
+            return dict(arena=ar, ids=ids, stash=st)
+
+        ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev)), build)
+        ar, ids, st = ent["arena"], ent["ids"], ent["stash"]
         rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
         normals = normals.contiguous().float()
         a = a.contiguous().float()
         L.check(L.get_lib().ncw_color_fwd(plan.net, prec, pts, n, L.ptr(normals), L.ptr(a), feat_ptr, L.ptr(rgb), st,
                                           L.stream_ptr(dev)), "ncw_color_fwd")
         return rgb, dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, rgb=rgb, feat_ptr=feat_ptr,
-                         keep=(normals, a))
+                         keep=(normals, a), lease=ent)
 
     def bwd_stash(self, ctx, d_rgb, d_grad, d_a, dfeat_ptr):
         """d_grad [n,3] is updated in place (+= d normals); d_a [R,n_a] accumulates (atomics)."""
@@ -461,7 +473,8 @@ class NeuconW(nn.Module):
     def gradient(self, x, prec=None):
         prec = default_prec() if prec is None else prec
         xf = x.reshape(-1, 3).float().contiguous()
-        _, grad, _ = self.sdf_net.fwd_stash(points_struct(x=xf), xf.shape[0], prec)
+        _, grad, c = self.sdf_net.fwd_stash(points_struct(x=xf), xf.shape[0], prec)
+        StashCache.release(c["lease"])
         return grad
 
     @torch.no_grad()
@@ -476,6 +489,8 @@ class NeuconW(nn.Module):
         a = x[..., 6:].reshape(n, -1).float().contiguous()
         pts = points_struct(x=xyz, rays_d=dirs)
         sdf, grad, sctx = self.sdf_net.fwd_stash(pts, n, prec)
-        rgb, _ = self.color_net.fwd_stash(pts, n, prec, grad, a, sctx["arena"].ptr(sctx["ids"]["feat"]))
+        rgb, cctx = self.color_net.fwd_stash(pts, n, prec, grad, a, sctx["arena"].ptr(sctx["ids"]["feat"]))
+        StashCache.release(sctx["lease"])
+        StashCache.release(cctx["lease"])
         inv_s = self.deviation_network.inv_s().reshape(1, 1)
         return rgb.reshape(R, S, 3), inv_s, sdf.reshape(R, S), grad.reshape(R, S, 3)

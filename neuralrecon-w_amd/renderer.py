@@ -17,7 +17,7 @@ import yaml
 from . import lib as L
 from . import rayops
 from .neuconw import default_prec, points_struct
-from .stash import WgradBatch
+from .stash import StashCache, WgradBatch
 
 SKY_LABEL_ID = 2  # datasets/mask_utils.py: get_label_id_mapping()["sky"]
 LABEL_IDS = {"sky": 2}
@@ -66,6 +66,10 @@ class _RenderFn(torch.autograd.Function):
         extras = (o["color_sphere"], o["color_bg"], o["weights"], o["cdf"], o["inside"], o["normals"],
                   sdf.view(R, S), grad.view(R, S, 3), o["mid_z"], o["dists"], o["eik"][:, 1].contiguous(), inv_s)
         ctx.mark_non_differentiable(*extras)
+        if not any(ctx.needs_input_grad):  # inference: nobody will come back for the stashes
+            for c in (sctx, cctx, nctx):
+                if c is not None:
+                    StashCache.release(c["lease"])
         return (o["color"], o["weights_sum"], o["depth"], o["eik"][:, 0].contiguous()) + extras
 
     @staticmethod
@@ -82,16 +86,24 @@ class _RenderFn(torch.autograd.Function):
         neuconw.color_net.bwd_stash(cctx, g["d_rgb"].view(R * S, 3), d_grad, d_a, dfeat_ptr)
         neuconw.sdf_net.bwd_stash(sctx, g["d_sdf"].view(R * S), d_grad)
         plans = [sctx["plan"], cctx["plan"]]
-        b_in = WgradBatch(dev, prec, R * S)
-        neuconw.sdf_net.add_wgrads(sctx, b_in)
-        neuconw.color_net.add_wgrads(cctx, b_in)
+        # the product list only depends on the (cached) stash arenas: build it once per lease
+        b_in = sctx["lease"].get("wgrad_batch")
+        if b_in is None or b_in.tag != (id(cctx["lease"]), prec):
+            b_in = WgradBatch(dev, prec, R * S)
+            b_in.tag = (id(cctx["lease"]), prec)
+            neuconw.sdf_net.add_wgrads(sctx, b_in)
+            neuconw.color_net.add_wgrads(cctx, b_in)
+            sctx["lease"]["wgrad_batch"] = b_in
         b_bg = None
         if ctx.use_bg:
             M = comp.S + comp.O
             nerf.bwd_stash(nctx, g["d_density"].view(R * M), g["d_bg_rgb"].view(R * M, 3), d_a)
             plans.append(nctx["plan"])
-            b_bg = WgradBatch(dev, prec, R * M)
-            nerf.add_wgrads(nctx, b_bg)
+            b_bg = nctx["lease"].get("wgrad_batch")
+            if b_bg is None:
+                b_bg = WgradBatch(dev, prec, R * M)
+                nerf.add_wgrads(nctx, b_bg)
+                nctx["lease"]["wgrad_batch"] = b_bg
         for p in plans:
             p.g_arena.zero_()
         b_in.run()
@@ -125,6 +137,9 @@ class _RenderFn(torch.autograd.Function):
         d_var = (g["d_inv_s"] * 10.0 * inv_s * live).reshape(ctx.variance.shape)
         if not ctx.use_bg:  # background parameters were passed but unused
             pass
+        for c in (sctx, cctx, nctx):
+            if c is not None:
+                StashCache.release(c["lease"])
         return (None, None, None, None, None, None, None, None, d_a, d_var) + tuple(out)
 
 

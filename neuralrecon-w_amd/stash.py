@@ -70,6 +70,12 @@ class WgradBatch:
     def run(self):
         if not self.items or self.n == 0:
             return
+        hit = self.__dict__.get("_launch")
+        if hit is not None:
+            tab, pre, nd, wgs, ks = hit
+            L.check(L.get_lib().ncw_wgrad(L.ptr(tab), L.ptr(pre), nd, wgs, ks, self.prec, self.n,
+                                          L.stream_ptr(self.device)), "ncw_wgrad")
+            return
         tiles = (self.n + 31) // 32
         chunk_tiles = 2 if self.prec == L.PREC_BF16 else 1
         ksplit = max(1, min(16, tiles // (8 * chunk_tiles)))
@@ -77,6 +83,7 @@ class WgradBatch:
         hit = WgradBatch._cache.get(key)
         if hit is not None:
             tab, pre, nd, wgs, ks = hit
+            self._launch = hit
             L.check(L.get_lib().ncw_wgrad(L.ptr(tab), L.ptr(pre), nd, wgs, ks, self.prec, self.n,
                                           L.stream_ptr(self.device)), "ncw_wgrad")
             return
@@ -97,3 +104,28 @@ class WgradBatch:
         if len(WgradBatch._cache) > 16:
             WgradBatch._cache.clear()
         WgradBatch._cache[key] = (tab, pre, len(descs), prefix[-1], ksplit)
+        self._launch = WgradBatch._cache[key]
+
+
+class StashCache:
+    """Per-module cache of activation-stash arenas keyed by (prec, n, device).  An entry is LEASED:
+    while a forward's stash is waiting for its backward it is `busy` and a concurrent forward
+    (validation render, inference) gets a fresh arena instead of clobbering it."""
+
+    def __init__(self):
+        self._e = {}
+
+    def acquire(self, key, builder):
+        e = self._e.get(key)
+        if e is not None and not e["busy"]:
+            e["busy"] = True
+            return e
+        new = builder()
+        new["busy"] = True
+        self._e[key] = new  # keep the most recent one (a lease that is never returned just gets dropped)
+        return new
+
+    @staticmethod
+    def release(e):
+        if e is not None:
+            e["busy"] = False
