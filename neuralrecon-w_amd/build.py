@@ -13,6 +13,7 @@ OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libneuconw_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
+FLAGS += os.environ.get("NCW_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _sources():

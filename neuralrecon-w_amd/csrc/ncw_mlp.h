@@ -152,9 +152,12 @@ NCW_DEV void cvec_copy(CVec<RB>& d, const CVec<RB>& s) {
         NCW_CHECK_LAUNCH();                                                                         \
     } while (0)
 
-// LDS slot size of the weight ring by network width (two slots per workgroup)
-template <int RB>
-struct RingSlot { static constexpr int bytes = RB >= 8 ? 65536 : 16384; };
+// LDS slot size of the weight ring by network width and target occupancy (two slots per workgroup):
+// OCC = 1: one 4-wave workgroup per CU (kernels that need > 256 registers per lane), 2 x 64 KiB;
+// OCC = 2: two workgroups per CU (<= 256 registers: the backward chains), 2 x 32 KiB each, so one
+//          workgroup's VALU epilogue / stash traffic overlaps the other's MFMAs.
+template <int RB, int OCC = 1>
+struct RingSlot { static constexpr int bytes = RB >= 8 ? (OCC >= 2 ? 32768 : 65536) : 16384; };
 
 #define NCW_RING_DECL(SLOTB)                                              \
     __shared__ __attribute__((aligned(16))) char ring_mem__[2 * (SLOTB)]; \

@@ -9,9 +9,9 @@ NCW_DEV void inverted_sphere(const float (&x)[3], float (&p4)[4]) {
     p4[0] = x[0] / r; p4[1] = x[1] / r; p4[2] = x[2] / r; p4[3] = 1.0f / r;
 }
 
-template <class P, int RBN, int RBH>
+template <class P, int RBN, int RBH, int OCC = 1>
 struct NerfShapes {
-    static constexpr int SLOT = RingSlot<RBN>::bytes;
+    static constexpr int SLOT = RingSlot<RBN, OCC>::bytes;
     static constexpr int FCB_P0 = ncw_first_chunk_bytes<P, 3, 84, RBN, SLOT>();
     static constexpr int FCB_P = ncw_first_chunk_bytes<P, RBN, 32 * RBN, RBN, SLOT>();
     static constexpr int FCB_PS = ncw_first_chunk_bytes<P, RBN + 3, 32 * RBN + 84, RBN, SLOT>();
@@ -140,13 +140,13 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
 }
 
 template <class P, int RBN, int RBH>
-__global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_bwd_kernel(NcwNerfNet net, NcwPoints src, int64_t n,
+__global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void nerf_bwd_kernel(NcwNerfNet net, NcwPoints src, int64_t n,
                                                                      const float* __restrict__ d_density,
                                                                      const float* __restrict__ d_rgb,
                                                                      float* __restrict__ d_a, NcwNerfStash st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
-    typedef NerfShapes<P, RBN, RBH> SH;
+    typedef NerfShapes<P, RBN, RBH, 2> SH;
     NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
     ring_prologue(ring, net.wt_rgb, SH::FCB_TRGB);

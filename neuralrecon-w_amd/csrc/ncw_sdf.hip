@@ -17,9 +17,9 @@ NCW_DEV NcwPoints points_from_x(const float* x) {
 }
 
 // Shapes of the packed SDF matrices as seen by the weight ring (first-chunk sizes for prefetch).
-template <class P, int RB>
+template <class P, int RB, int OCC = 1>
 struct SdfShapes {
-    static constexpr int SLOT = RingSlot<RB>::bytes;
+    static constexpr int SLOT = RingSlot<RB, OCC>::bytes;
     static constexpr int FCB_W0 = ncw_first_chunk_bytes<P, 2, 39, RB, SLOT>();              // lin0: K = gamma
     static constexpr int FCB_WH = ncw_first_chunk_bytes<P, RB, 32 * RB, RB, SLOT>();        // hidden
     static constexpr int FCB_WS = ncw_first_chunk_bytes<P, RB + 2, 32 * RB + 39, RB, SLOT>();  // skip layer
@@ -30,11 +30,10 @@ struct SdfShapes {
 };
 
 // z_l = b_l + W_l u_l for a hidden layer l (1 <= l <= L-2), honouring the skip concatenation
-template <class P, int RB>
+template <class P, int RB, int SLOT>
 NCW_DEV void sdf_hidden_layer(CVec<RB>& acc, const Act<P, RB>& act, const Act<P, 2>& gact, const NcwSdfNet& net, int l,
                               WRing& ring, const void* w_next, int next_bytes, int lane) {
     typedef typename P::welem WE;
-    constexpr int SLOT = RingSlot<RB>::bytes;
     load_bias(acc, net.b[l], lane);
     if (l == net.skip_layer) {
         Act<P, RB + 2> cat;
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_infer_kernel(NcwSdfNet 
     softplus_epilogue<P, RB>(act, acc, nullptr, nullptr, 0, lane);
     for (int l = 1; l < L - 1; ++l) {
         next_of(l, wn, nbts);
-        sdf_hidden_layer<P, RB>(acc, act, gact, net, l, ring, wn, nbts, lane);
+        sdf_hidden_layer<P, RB, SH::SLOT>(acc, act, gact, net, l, ring, wn, nbts, lane);
         softplus_epilogue<P, RB>(act, acc, nullptr, nullptr, 0, lane);
     }
     CVec<1> o;
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet ne
     softplus_epilogue<P, RB>(act, acc, (SE*)st.h[1], (SE*)st.s[0], tile, lane);
     for (int l = 1; l < L - 1; ++l) {
         next_of(l, wn, nbts);
-        sdf_hidden_layer<P, RB>(acc, act, gact, net, l, ring, wn, nbts, lane);
+        sdf_hidden_layer<P, RB, SH::SLOT>(acc, act, gact, net, l, ring, wn, nbts, lane);
         softplus_epilogue<P, RB>(act, acc, (SE*)st.h[l + 1], (SE*)st.s[l], tile, lane);
     }
     {
@@ -220,12 +219,12 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet ne
 // backward (second order)
 // ---------------------------------------------------------------------------------------------
 template <class P, int RB>
-__global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_bwd_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+__global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void sdf_bwd_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
                                                                     const float* __restrict__ d_sdf,
                                                                     const float* __restrict__ d_grad, NcwSdfStash st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
-    typedef SdfShapes<P, RB> SH;
+    typedef SdfShapes<P, RB, 2> SH;
     NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
     const int h = lane >> 5;
