@@ -218,12 +218,27 @@ NCW_HD constexpr int ncw_unit_first_feature(int rb, int sub) {
     return (P::id == NCW_PREC_F32) ? 32 * rb + ncw_feat_of(sub, 0) : 16 * (2 * rb + sub);
 }
 
-// acc[RB_OUT] += W . in, W streamed through the LDS ring.  ALL threads of the workgroup must call
+// B-operand providers.  mma_stream pulls the B operand of unit (rb, sub) from a provider; prepare(rb)
+// is called once, immediately before the first unit of in-block rb.  An eager provider wraps a ready
+// Act; a LAZY provider evaluates the previous layer's epilogue (activation, stash stores, bf16
+// packing) for just that block, so the VALU work of block rb+1 overlaps the MFMAs of block rb inside
+// one wave (MFMA and VALU are separate pipes) instead of idling the matrix pipe for a whole epilogue.
+template <class P, int RB_IN_>
+struct ActB {
+    static constexpr int RB_IN = RB_IN_;
+    const Act<P, RB_IN_>& a;
+    NCW_DEV explicit ActB(const Act<P, RB_IN_>& a_) : a(a_) {}
+    NCW_DEV void prepare(int) {}
+    NCW_DEV auto b(int rb, int sub) const { return unit_b<RB_IN_>(a, rb, sub); }
+};
+
+// acc[RB_OUT] += W . B, W streamed through the LDS ring.  ALL threads of the workgroup must call
 // this with identical (uniform) arguments.  w_next/next_bytes: first chunk of the matrix the NEXT
 // mma_stream call will consume (nullptr at the end of the kernel).
-template <int RB_IN, int RB_OUT, int K_REAL, int SLOT, int RB_STRIDE = RB_OUT, class P>
-NCW_DEV void mma_stream(CVec<RB_OUT>& acc, const Act<P, RB_IN>& in, WRing& ring, const typename P::welem* __restrict__ wp,
-                        const void* w_next, int next_bytes, int lane) {
+template <int RB_OUT, int K_REAL, int SLOT, int RB_STRIDE, class P, class BP>
+NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename P::welem* __restrict__ wp,
+                          const void* w_next, int next_bytes, int lane) {
+    constexpr int RB_IN = BP::RB_IN;
     constexpr int UPB = UnitsPerBlock<P>::v;
     constexpr int NU = ncw_nb_used(RB_IN, K_REAL) * UPB;
     constexpr int UB = ncw_unit_bytes<P>(RB_STRIDE);
@@ -245,14 +260,22 @@ NCW_DEV void mma_stream(CVec<RB_OUT>& acc, const Act<P, RB_IN>& in, WRing& ring,
             const int q = c * CU + u;
             if (q >= NU) continue;
             const int rb = q / UPB, sub = q % UPB;
+            if (sub == 0) bp.prepare(rb);
             if (ncw_unit_first_feature<P>(rb, sub) >= K_REAL) continue;
-            const auto b = unit_b<RB_IN>(in, rb, sub);
+            const auto b = bp.b(rb, sub);
             const Frag* w = lw + (size_t)u * RB_STRIDE * 64;
 #pragma unroll
             for (int ro = 0; ro < RB_OUT; ++ro) acc.v[ro] = unit_mfma(w[ro * 64], b, acc.v[ro]);
         }
         ring.cur ^= 1;
     }
+}
+
+template <int RB_IN, int RB_OUT, int K_REAL, int SLOT, int RB_STRIDE = RB_OUT, class P>
+NCW_DEV void mma_stream(CVec<RB_OUT>& acc, const Act<P, RB_IN>& in, WRing& ring, const typename P::welem* __restrict__ wp,
+                        const void* w_next, int next_bytes, int lane) {
+    ActB<P, RB_IN> bp(in);
+    mma_stream_b<RB_OUT, K_REAL, SLOT, RB_STRIDE, P>(acc, bp, ring, wp, w_next, next_bytes, lane);
 }
 
 // concatenation of two activation vectors along the feature axis (skip connections: zero cost)
@@ -299,14 +322,18 @@ NCW_DEV void load_bias(CVec<RB>& acc, const float* __restrict__ bp, int lane) {
 // sigma(100 z) (exactly 1 above the threshold).  FAST selects hardware exp2/log2.
 template <bool FAST>
 NCW_DEV void softplus100(float z, float& y, float& s) {
-    const float bz = 100.f * z;
     if (FAST) {
-        float e = __builtin_amdgcn_exp2f(bz * 1.4426950408889634f);  // exp(bz)
-        float l = __builtin_amdgcn_logf(1.f + e) * (0.6931471805599453f * 0.01f);
-        float sg = e * __builtin_amdgcn_rcpf(1.f + e);
-        y = bz > 20.f ? z : l;
-        s = bz > 20.f ? 1.f : sg;
+        // overflow-free form, 6 VALU ops (2 transcendental) for y and 3 more (1 transcendental) for s:
+        //   w = exp(-|100 z|) in (0,1];  y = max(z,0) + log(1+w)/100;  s = 1 - exp(-100 y)  (== sigmoid(100 z)).
+        // Above torch's threshold (100 z > 20) w < 2.1e-9, so y = z and s = 1 to f32 rounding -- the same
+        // values the thresholded reference form returns.
+        const float t = z * 144.26950408889634f;  // 100 z log2(e)
+        const float w = __builtin_amdgcn_exp2f(-__builtin_fabsf(t));
+        const float l = __builtin_amdgcn_logf(1.f + w);  // log2(1 + w)
+        y = __builtin_fmaf(l, 0.6931471805599453f * 0.01f, __builtin_fmaxf(z, 0.f));
+        s = 1.f - __builtin_amdgcn_exp2f(y * -144.26950408889634f);
     } else {
+        const float bz = 100.f * z;
         float e = expf(bz);
         float l = log1pf(e) * 0.01f;
         float sg = 1.f / (1.f + expf(-bz));

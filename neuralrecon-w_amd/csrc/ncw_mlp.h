@@ -137,6 +137,99 @@ NCW_DEV void relu_backward(Act<P, RB>& za, const CVec<RB>& u, const typename P::
     }
 }
 
+// ---- lazy B providers: the previous layer's epilogue evaluated block by block inside the MFMA stream ----
+// u = Softplus100(z) (+ stash of u and of Softplus'), optionally followed by NX extra ready blocks
+// (the gamma blocks of the SDF skip connection).
+template <class P, int RB, int NX = 0>
+struct SoftplusB {
+    static constexpr int RB_IN = RB + NX;
+    typedef typename P::selem SE;
+    const CVec<RB>& z;
+    SE* st_h;
+    SE* st_s;
+    size_t tile;
+    int lane;
+    const Act<P, (NX > 0 ? NX : 1)>* extra;
+    Act<P, RB> act;
+    NCW_DEV SoftplusB(const CVec<RB>& z_, SE* h, SE* s, size_t t, int l, const Act<P, (NX > 0 ? NX : 1)>* x = nullptr)
+        : z(z_), st_h(h), st_s(s), tile(t), lane(l), extra(x) {}
+    NCW_DEV void prepare(int rb) {
+        if (rb >= RB) return;
+        f32x16 yv, sv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float y, sg;
+            softplus100<Fast<P>::v>(z.v[rb][r], y, sg);
+            yv[r] = y;
+            sv[r] = sg;
+        }
+        if (st_s) stash_store_block(st_s, tile, RB, rb, sv, lane);
+        if (st_h) stash_store_block(st_h, tile, RB, rb, yv, lane);
+        to_act_block<RB>(act, rb, yv);
+    }
+    NCW_DEV auto b(int rb, int sub) const {
+        if constexpr (NX > 0) {
+            if (rb >= RB) return unit_b<NX>(*extra, rb - RB, sub);
+        }
+        return unit_b<RB>(act, rb < RB ? rb : 0, sub);
+    }
+};
+
+// u = relu(z) (+ stash), optionally followed by NX ready blocks (aux inputs / NeRF skip)
+template <class P, int RB, int NX = 0>
+struct ReluB {
+    static constexpr int RB_IN = RB + NX;
+    typedef typename P::selem SE;
+    const CVec<RB>& z;
+    SE* st;
+    size_t tile;
+    int lane;
+    const Act<P, (NX > 0 ? NX : 1)>* extra;
+    Act<P, RB> act;
+    NCW_DEV ReluB(const CVec<RB>& z_, SE* s, size_t t, int l, const Act<P, (NX > 0 ? NX : 1)>* x = nullptr)
+        : z(z_), st(s), tile(t), lane(l), extra(x) {}
+    NCW_DEV void prepare(int rb) {
+        if (rb >= RB) return;
+        f32x16 yv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[r] = fmaxf(z.v[rb][r], 0.f);
+        if (st) stash_store_block(st, tile, RB, rb, yv, lane);
+        to_act_block<RB>(act, rb, yv);
+    }
+    NCW_DEV auto b(int rb, int sub) const {
+        if constexpr (NX > 0) {
+            if (rb >= RB) return unit_b<NX>(*extra, rb - RB, sub);
+        }
+        return unit_b<RB>(act, rb < RB ? rb : 0, sub);
+    }
+};
+
+// u = z (identity; + stash), optionally followed by NX ready blocks
+template <class P, int RB, int NX = 0>
+struct LinearB {
+    static constexpr int RB_IN = RB + NX;
+    typedef typename P::selem SE;
+    const CVec<RB>& z;
+    SE* st;
+    size_t tile;
+    int lane;
+    const Act<P, (NX > 0 ? NX : 1)>* extra;
+    Act<P, RB> act;
+    NCW_DEV LinearB(const CVec<RB>& z_, SE* s, size_t t, int l, const Act<P, (NX > 0 ? NX : 1)>* x = nullptr)
+        : z(z_), st(s), tile(t), lane(l), extra(x) {}
+    NCW_DEV void prepare(int rb) {
+        if (rb >= RB) return;
+        if (st) stash_store_block(st, tile, RB, rb, z.v[rb], lane);
+        to_act_block<RB>(act, rb, z.v[rb]);
+    }
+    NCW_DEV auto b(int rb, int sub) const {
+        if constexpr (NX > 0) {
+            if (rb >= RB) return unit_b<NX>(*extra, rb - RB, sub);
+        }
+        return unit_b<RB>(act, rb < RB ? rb : 0, sub);
+    }
+};
+
 template <int RB>
 NCW_DEV void cvec_copy(CVec<RB>& d, const CVec<RB>& s) {
 #pragma unroll

@@ -30,12 +30,16 @@ struct SdfShapes {
 };
 
 // z_l = b_l + W_l u_l for a hidden layer l (1 <= l <= L-2), honouring the skip concatenation
-template <class P, int RB, int SLOT>
-NCW_DEV void sdf_hidden_layer(CVec<RB>& acc, const Act<P, RB>& act, const Act<P, 2>& gact, const NcwSdfNet& net, int l,
+template <class P, int RB, int SLOT, class GammaFn>
+NCW_DEV void sdf_hidden_layer(CVec<RB>& acc, const Act<P, RB>& act, GammaFn&& gamma_fn, const NcwSdfNet& net, int l,
                               WRing& ring, const void* w_next, int next_bytes, int lane) {
     typedef typename P::welem WE;
     load_bias(acc, net.b[l], lane);
     if (l == net.skip_layer) {
+        // gamma is re-materialised here (recomputed / reloaded from the stash) instead of being kept
+        // live across all layers: 16-32 registers less on the critical allocation
+        Act<P, 2> gact;
+        gamma_fn(gact);
         Act<P, RB + 2> cat;
         act_concat<RB, 2>(cat, act, gact);
         mma_stream<RB + 2, RB, 32 * RB + 39, SLOT>(acc, cat, ring, (const WE*)net.w[l], w_next, next_bytes, lane);
@@ -63,11 +67,11 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_infer_kernel(NcwSdfNet 
     load_point(src, p, xs, ray);
     xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
 
-    CVec<2> gam;
-    freq_encode<2, 3, 6, Fast<P>::v>(gam, xs, lane);
-    Act<P, 2> gact;
-    to_act(gact, gam);
-
+    auto make_gamma = [&](Act<P, 2>& g) {
+        CVec<2> gam;
+        freq_encode<2, 3, 6, Fast<P>::v>(gam, xs, lane);
+        to_act(g, gam);
+    };
     CVec<RB> acc;
     Act<P, RB> act;
     auto next_of = [&](int l, const void*& w, int& bytes) {  // matrix consumed after forward layer l
@@ -79,11 +83,15 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_infer_kernel(NcwSdfNet 
     int nbts;
     load_bias(acc, net.b[0], lane);
     next_of(0, wn, nbts);
-    mma_stream<2, RB, 39, SH::SLOT>(acc, gact, ring, (const WE*)net.w[0], wn, nbts, lane);
+    {
+        Act<P, 2> gact;
+        make_gamma(gact);
+        mma_stream<2, RB, 39, SH::SLOT>(acc, gact, ring, (const WE*)net.w[0], wn, nbts, lane);
+    }
     softplus_epilogue<P, RB>(act, acc, nullptr, nullptr, 0, lane);
     for (int l = 1; l < L - 1; ++l) {
         next_of(l, wn, nbts);
-        sdf_hidden_layer<P, RB, SH::SLOT>(acc, act, gact, net, l, ring, wn, nbts, lane);
+        sdf_hidden_layer<P, RB, SH::SLOT>(acc, act, make_gamma, net, l, ring, wn, nbts, lane);
         softplus_epilogue<P, RB>(act, acc, nullptr, nullptr, 0, lane);
     }
     CVec<1> o;
@@ -113,12 +121,11 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet ne
     load_point(src, p, xs, ray);
     xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
 
-    CVec<2> gam;
-    freq_encode<2, 3, 6, Fast<P>::v>(gam, xs, lane);
-    stash_store<2>((SE*)st.gamma, tile, gam, lane);
-    Act<P, 2> gact;
-    to_act(gact, gam);
-
+    auto reload_gamma = [&](Act<P, 2>& g) {  // gamma lives in the stash between layer 0 and the skip layer
+        CVec<2> gm;
+        stash_load<2>(gm, (const SE*)st.gamma, tile, lane);
+        to_act(g, gm);
+    };
     CVec<RB> acc;
     Act<P, RB> act;
     auto next_of = [&](int l, const void*& w, int& bytes) {
@@ -130,11 +137,18 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet ne
     int nbts;
     load_bias(acc, net.b[0], lane);
     next_of(0, wn, nbts);
-    mma_stream<2, RB, 39, SH::SLOT>(acc, gact, ring, (const WE*)net.w[0], wn, nbts, lane);
+    {
+        CVec<2> gam;
+        freq_encode<2, 3, 6, Fast<P>::v>(gam, xs, lane);
+        stash_store<2>((SE*)st.gamma, tile, gam, lane);
+        Act<P, 2> gact;
+        to_act(gact, gam);
+        mma_stream<2, RB, 39, SH::SLOT>(acc, gact, ring, (const WE*)net.w[0], wn, nbts, lane);
+    }
     softplus_epilogue<P, RB>(act, acc, (SE*)st.h[1], (SE*)st.s[0], tile, lane);
     for (int l = 1; l < L - 1; ++l) {
         next_of(l, wn, nbts);
-        sdf_hidden_layer<P, RB, SH::SLOT>(acc, act, gact, net, l, ring, wn, nbts, lane);
+        sdf_hidden_layer<P, RB, SH::SLOT>(acc, act, reload_gamma, net, l, ring, wn, nbts, lane);
         softplus_epilogue<P, RB>(act, acc, (SE*)st.h[l + 1], (SE*)st.s[l], tile, lane);
     }
     {
