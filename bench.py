@@ -73,6 +73,7 @@ def build_models(device, prec, seed=0):
         s_val_base=S_VAL_BASE, spc_options={"recontruct_path": "/nonexistent", "voxel_size": 0.1, "min_track_length": 1},
         sample_range=16, boundary_samples=0, nerf_far_override=False, render_bg=True, trim_sphere=True,
         mesh_mask_list=["sky"], depth_loss=True, prec=prec)
+    rdr.sync_free = True  # identical loss value/gradients, no mid-step device->host sync (see renderer.py)
     return emb, neuconw, nerf, rdr
 
 
@@ -156,8 +157,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("NCW_BENCH_ONE_GPU_TEST"):  # plumbing test: N ranks share GPU 0 over gloo
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("NCW_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch N>1 through torch.distributed.run"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -205,12 +212,16 @@ def main():
 
     # ---- per-kernel HIP-event timing over a few more live steps (same stream) -> roofline ---------------
     roofline = None
+    # every rank runs the same extra steps (the step contains the gradient all-reduce); only rank 0 records
+    prof_steps = max(2, min(5, args.steps))
     if rank == 0:
         L.PROFILE = {}
-        prof_steps = max(2, min(5, args.steps))
-        for i in range(prof_steps):
-            step(args.warmup + args.steps + i)
-        torch.cuda.synchronize()
+    for i in range(prof_steps):
+        step(args.warmup + args.steps + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
         prof, L.PROFILE = L.PROFILE, None
         fl = kernel_flops(R)
         rows = {}

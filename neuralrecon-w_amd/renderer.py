@@ -177,6 +177,9 @@ class NeuconWRenderer:
         if save_sample or save_step_sample:
             raise NotImplementedError("debug PLY dumps (open3d) are out of scope")
         self.prec = default_prec() if prec is None else prec
+        # sync_free=True keeps render() free of device->host synchronisations (see sfm_depth_loss below);
+        # the default reproduces the reference's output shapes exactly.
+        self.sync_free = False
 
     # ---- sampler (renderer.py:458-568, under no_grad) -------------------------------------------
     def _sdf_rays(self, rays_o, rays_d, z):
@@ -316,7 +319,15 @@ class NeuconWRenderer:
             mask_error = F.binary_cross_entropy(weights_sum.clip(1e-3, 1.0 - 1e-3), mask, reduction="none")
         else:
             mask_error = torch.zeros_like(weights_sum)
-        if self.depth_loss and torch.sum(depth_weight > 0) > 0:  # renderer.py:892-897
+        if self.depth_loss and self.sync_free:
+            # Same loss, no device->host sync: the reference returns the SELECTED entries (a data-dependent
+            # shape, renderer.py:892-897) and the loss takes their mean; here every ray keeps an entry,
+            # scaled so that `.mean()` over all R entries equals the reference's mean over the selected ones
+            # (and 0 when none is selected, like the reference's zeros_like branch).
+            sel = (depth_weight > 0).to(depth.dtype)
+            cnt = sel.sum().clamp_min(1.0)
+            sfm_depth_loss = ((depth - depth_gt) ** 2) * depth_weight * sel * (float(depth.shape[0]) / cnt)
+        elif self.depth_loss and torch.sum(depth_weight > 0) > 0:  # renderer.py:892-897
             sfm_depth_loss = (((depth - depth_gt) ** 2) * depth_weight)[depth_weight > 0]
         else:
             sfm_depth_loss = torch.zeros_like(depth)

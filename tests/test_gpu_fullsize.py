@@ -107,3 +107,18 @@ def test_properties_at_full_baseline_shape():
     perm = torch.randperm(R, device=rays.device)
     outp = rdr.render(rays[perm], ts[perm], label[perm], perturb_overwrite=0, background_rgb=bg, cos_anneal_ratio=0.5)
     assert torch.allclose(outp["color"], out["color"][perm], atol=1e-6)
+
+
+def test_sync_free_depth_loss_is_the_same_loss():
+    import neuralrecon_w_amd as nw
+
+    emb, neuconw, nerf, rdr = build_system(prec=nw.PREC_F32, seed=4)
+    rays, ts, label, rgbs = synth_rays(64, 5, 64)
+    args = (rays.cuda(), ts.cuda(), label.cuda())
+    a = rdr.render(*args, perturb_overwrite=0, background_rgb=torch.zeros(1, 3).cuda())
+    rdr.sync_free = True
+    b = rdr.render(*args, perturb_overwrite=0, background_rgb=torch.zeros(1, 3).cuda())
+    assert b["sfm_depth_loss"].shape == (64,) and a["sfm_depth_loss"].shape[0] < 64
+    assert abs(float(a["sfm_depth_loss"].mean()) - float(b["sfm_depth_loss"].mean())) < 1e-7
+    la, lb = loss_from_outputs(a, rgbs.cuda()), loss_from_outputs(b, rgbs.cuda())
+    assert abs(float(la) - float(lb)) < 1e-6
