@@ -185,7 +185,7 @@ def main():
         loss = loss_fn(out, rgbs)
         loss.backward()
         if world > 1:
-            ddp.allreduce_grads(params, world)
+            ddp.allreduce_grads(params, world, flat_buffers=[rdr.flat_grad_buffer()])
         torch.nn.utils.clip_grad_norm_(params, 0.99)  # train.py:61
         opt.step()
         return loss

@@ -33,7 +33,18 @@ def _worker(rank, world, port, q):
     lin(x).sum().backward()
     local = [p.grad.clone() for p in lin.parameters()]
     params = list(lin.parameters()) + list(dead.parameters())
-    ddp.allreduce_grads(params, world)
+    # second module whose .grad tensors are views of ONE persistent flat buffer (the renderer's layout)
+    lin2 = torch.nn.Linear(3, 2)
+    ddp.broadcast_params([lin2])
+    flat = torch.zeros(sum(p.numel() for p in lin2.parameters()))
+    off = 0
+    for p in lin2.parameters():
+        p.grad = flat[off:off + p.numel()].view(p.shape)
+        p.grad.fill_(float(rank + 1))
+        off += p.numel()
+    ddp.allreduce_grads(params + list(lin2.parameters()), world, flat_buffers=[flat])
+    assert torch.allclose(flat, torch.full_like(flat, 1.5)), flat  # mean of 1 and 2, reduced in place
+    assert all(p.grad.data_ptr() >= flat.data_ptr() for p in lin2.parameters())
     tl = lambda ts: [t.detach().reshape(-1).tolist() for t in ts]  # noqa: E731  (plain lists cross the queue)
     q.put((rank, tl(lin.parameters()), tl(local), tl([p.grad for p in lin.parameters()]),
            [p.grad is None for p in dead.parameters()]))
