@@ -153,14 +153,18 @@ NCW_DEV void mma(CVec<RB_OUT>& acc, const Act<PrecBF16, RB_IN>& in, const __bf16
 typedef __attribute__((address_space(1))) void ncw_gvoid;
 typedef __attribute__((address_space(3))) void ncw_lvoid;
 
+// LDS pointers are kept in address space 3 explicitly: through a generic pointer hipcc emits
+// flat_load (slow LDS aperture path, counted on vmcnt AND lgkmcnt) instead of ds_read_b128.
+typedef __attribute__((address_space(3))) char ncw_lchar;
 struct WRing {
-    char* slot[2];
+    ncw_lchar* base;   // two slots: base, base + slot_bytes
     int cur;
     int slot_bytes;
+    NCW_DEV ncw_lchar* slot(int i) const { return base + i * slot_bytes; }
 };
 
 // cooperative DMA of `bytes` (multiple of 16) from gsrc into an LDS slot by all waves of the WG
-NCW_DEV void ring_issue(char* lds_slot, const void* gsrc, int bytes) {
+NCW_DEV void ring_issue(ncw_lchar* lds_slot, const void* gsrc, int bytes) {
     const int nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -198,7 +202,7 @@ NCW_HD constexpr int ncw_first_chunk_bytes() {
 
 NCW_DEV void ring_prologue(WRing& ring, const void* w_first, int first_bytes) {
     ring.cur = 0;
-    ring_issue(ring.slot[0], w_first, first_bytes);
+    ring_issue(ring.slot(0), w_first, first_bytes);
 }
 
 // B operand of unit (rb, sub)
@@ -250,11 +254,12 @@ NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename
         __syncthreads();
         if (c + 1 < NCH) {
             const int nu = (c + 2) * CU <= NU ? CU : NU - (c + 1) * CU;
-            ring_issue(ring.slot[ring.cur ^ 1], reinterpret_cast<const char*>(wp) + (size_t)(c + 1) * CU * UB, nu * UB);
+            ring_issue(ring.slot(ring.cur ^ 1), reinterpret_cast<const char*>(wp) + (size_t)(c + 1) * CU * UB, nu * UB);
         } else if (w_next != nullptr) {
-            ring_issue(ring.slot[ring.cur ^ 1], w_next, next_bytes);
+            ring_issue(ring.slot(ring.cur ^ 1), w_next, next_bytes);
         }
-        const Frag* lw = reinterpret_cast<const Frag*>(ring.slot[ring.cur]) + lane;
+        typedef const __attribute__((address_space(3))) Frag* lfrag_t;
+        lfrag_t lw = (lfrag_t)(ring.slot(ring.cur)) + lane;
 #pragma unroll
         for (int u = 0; u < CU; ++u) {
             const int q = c * CU + u;
@@ -263,9 +268,12 @@ NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename
             if (sub == 0) bp.prepare(rb);
             if (ncw_unit_first_feature<P>(rb, sub) >= K_REAL) continue;
             const auto b = bp.b(rb, sub);
-            const Frag* w = lw + (size_t)u * RB_STRIDE * 64;
+            lfrag_t w = lw + u * RB_STRIDE * 64;
 #pragma unroll
-            for (int ro = 0; ro < RB_OUT; ++ro) acc.v[ro] = unit_mfma(w[ro * 64], b, acc.v[ro]);
+            for (int ro = 0; ro < RB_OUT; ++ro) {
+                const Frag a = w[ro * 64];
+                acc.v[ro] = unit_mfma(a, b, acc.v[ro]);
+            }
         }
         ring.cur ^= 1;
     }

@@ -255,8 +255,7 @@ struct RingSlot { static constexpr int bytes = RB >= 8 ? (OCC >= 2 ? 32768 : 655
 #define NCW_RING_DECL(SLOTB)                                              \
     __shared__ __attribute__((aligned(16))) char ring_mem__[2 * (SLOTB)]; \
     WRing ring;                                                           \
-    ring.slot[0] = ring_mem__;                                            \
-    ring.slot[1] = ring_mem__ + (SLOTB);                                  \
+    ring.base = (ncw_lchar*)ring_mem__;                                   \
     ring.cur = 0;                                                         \
     ring.slot_bytes = (SLOTB)
 
