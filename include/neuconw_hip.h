@@ -264,6 +264,10 @@ typedef struct NcwWgradDesc {
  * ceil(rbx/4)*ceil(rby/4)*ksplit workgroups per product; total_wgs = wg_prefix[n_desc]. */
 int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
               int prec, int64_t n_points, void* stream);
+/* bf16 only, explicit workgroup tile: tile 0 = 128 x 256 features (wg_prefix counts ceil(rbx/4)*ceil(rby/8)*ksplit),
+ * tile 1 = 256 x 256 (ceil(rbx/8)*ceil(rby/8)*ksplit): every stash element is read once per product. */
+int ncw_wgrad_tiled(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
+                    int tile, int64_t n_points, void* stream);
 
 /* Layout converters between row-major f32 [n, F] and the stash layout (rb = ceil(F/32) blocks,
  * element type by prec).  Used at the module boundary (NeuconW.forward returning feature vectors,

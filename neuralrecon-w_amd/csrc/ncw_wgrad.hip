@@ -181,77 +181,82 @@ NCW_DEV bf16x8 tr_frag(const char* lds_ptr) {
     return __builtin_bit_cast(bf16x8, w);
 }
 
+template <int XB, int YB>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const NcwWgradDesc* __restrict__ descs,
                                                          const int32_t* __restrict__ prefix, int n_desc, int ksplit,
                                                          int64_t ntiles) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * WG2_BUF_BYTES];
+    constexpr int WI = XB / 2, WJ = YB / 2;  // blocks per wave (waves tile the output 2 x 2)
+    constexpr int ROWS_PER_TILE = (XB + YB) * 8;
+    constexpr int BUF_BYTES = 2 * ROWS_PER_TILE * WG2_ROWB;
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF_BYTES];
     const int d = wg_find(prefix, n_desc, blockIdx.x);
     const NcwWgradDesc D = descs[d];
     const int local = blockIdx.x - prefix[d];
     const int quad = local / ksplit, ks = local - quad * ksplit;
-    const int nqj = (D.rby + WG2_YB - 1) / WG2_YB;
+    const int nqj = (D.rby + YB - 1) / YB;
     const int qi = quad / nqj, qj = quad - qi * nqj;
-    const int nbi = min(WG2_XB, D.rbx - WG2_XB * qi), nbj = min(WG2_YB, D.rby - WG2_YB * qj);
+    const int nbi = min(XB, D.rbx - XB * qi), nbj = min(YB, D.rby - YB * qj);
     const int64_t tpk = ((ntiles + ksplit - 1) / ksplit + 1) & ~(int64_t)1;  // even number of tiles per slice
     const int64_t t_begin = (int64_t)ks * tpk, t_end = min(t_begin + tpk, ntiles);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wi = wave >> 1, wj = wave & 1;  // wave tile: i-blocks 2wi..2wi+1, j-blocks 4wj..4wj+3
-    f32x16 acc[2][4];
+    const int wi = wave >> 1, wj = wave & 1;  // wave tile: i-blocks WI*wi.., j-blocks WJ*wj..
+    f32x16 acc[WI][WJ];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WI; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < WJ; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bsum[2] = {0.f, 0.f};
-    const bool do_bias = (D.dbias != nullptr) && (qj == 0) && (wj == 0);
-    // ---- staging bookkeeping: 12 blocks x 4 g x 2 tiles = 96 wave-loads per chunk, 24 per wave ----------
-    const __bf16* xg = (const __bf16*)D.x;
-    const __bf16* yg = (const __bf16*)D.y;
-    constexpr int NLD = (WG2_XB + WG2_YB) * 4 * 2 / 4;  // wave-loads per wave per chunk
+    float bsum[WI];
+#pragma unroll
+    for (int a = 0; a < WI; ++a) bsum[a] = 0.f;
+    const bool do_bias = __builtin_amdgcn_readfirstlane((int)((D.dbias != nullptr) && (qj == 0) && (wj == 0))) != 0;
+    // ---- staging bookkeeping: 12 blocks x 4 g x 2 tiles = 96 wave-loads per chunk, 24 per wave.  Wave w
+    // owns g == w of every (tile, block): the address is  [uniform base of (tile, block)] + [w*512 + lane*8],
+    // i.e. one per-lane 32-bit offset for the whole kernel and scalar (SALU) base arithmetic per load. -----
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    const char* xg = (const char*)D.x;
+    const char* yg = (const char*)D.y;
+    constexpr int NBLK = XB + YB;
+    constexpr int NLD = NBLK * 2;  // (block, tile-in-chunk) pairs: one 8-byte load each per wave
+    const unsigned lane_goff = (unsigned)(uw * 512 + lane * 8);
     uint2 stg[NLD];
-    // Branch-free loads (clamped, always-valid addresses) so that all 24 are in flight together;
-    // out-of-range tiles / blocks are zeroed when they are written to LDS.
     auto issue_loads = [&](int64_t t0) {
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
-            const int it = wave + 4 * k;          // 0..95
-            const int g = it & 3;
-            const int blk = (it >> 2) % (WG2_XB + WG2_YB);
-            const int tp = (it >> 2) / (WG2_XB + WG2_YB);
-            const int64_t tile = min(t0 + tp, t_end - 1);
-            const bool isx = blk < WG2_XB;
-            const int bsel = isx ? min(blk, nbi - 1) : min(blk - WG2_XB, nbj - 1);
-            const __bf16* base = isx ? xg : yg;
-            const int rb = isx ? D.rbx : D.rby;
-            const int b0 = isx ? WG2_XB * qi : WG2_YB * qj;
-            // explicit GLOBAL address space: a flat load would also count on lgkmcnt and stall the LDS waits
+            const int blk = k % NBLK, tp = k / NBLK;
+            const int64_t tile = min(t0 + tp, t_end - 1);   // clamped: always a valid address
+            const bool isx = blk < XB;
+            const int bsel = isx ? min(blk, nbi - 1) : min(blk - XB, nbj - 1);
+            const char* base = isx ? xg : yg;
+            const int64_t rb = isx ? D.rbx : D.rby;
+            const int64_t b0 = isx ? XB * qi : YB * qj;
+            const char* ub = base + (tile * rb + b0 + bsel) * 2048;   // scalar arithmetic
             typedef const __attribute__((address_space(1))) unsigned long long* gptr_t;
-            const unsigned long long raw = *(gptr_t)(base + ((((size_t)tile * rb + (b0 + bsel)) * 4 + g) * 64 + lane) * 4);
+            const unsigned long long raw = *(gptr_t)(ub + lane_goff);
             stg[k] = make_uint2((unsigned)raw, (unsigned)(raw >> 32));
         }
     };
-    auto load_ok = [&](int k, int64_t t0) -> bool {
-        const int it = wave + 4 * k;
-        const int blk = (it >> 2) % (WG2_XB + WG2_YB);
-        const int tp = (it >> 2) / (WG2_XB + WG2_YB);
-        const bool bok = blk < WG2_XB ? blk < nbi : (blk - WG2_XB) < nbj;
-        return bok && (t0 + tp < t_end);
-    };
+    // LDS row of (tile tp, block blk, g = wave, half h) = (tp*NBLK + blk)*8 + 2*wave + h
+    const unsigned lane_woff = (unsigned)((2 * uw + (lane >> 5)) * WG2_ROWB + (lane & 31) * 8);
     auto write_lds = [&](char* buf, int64_t t0) {
-        const int p = lane & 31, h = lane >> 5;
+        typedef __attribute__((address_space(3))) unsigned long long* lptr_t;
+        const bool full = (t0 + 1 < t_end) && (nbi == XB) && (nbj == YB);   // uniform
+        if (full) {
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int it = wave + 4 * k;
-            const int g = it & 3;
-            const int blk = (it >> 2) % (WG2_XB + WG2_YB);
-            const int tp = (it >> 2) / (WG2_XB + WG2_YB);
-            const int row = (tp * (WG2_XB + WG2_YB) + blk) * 8 + 2 * g + h;
-            const bool ok = load_ok(k, t0);
-            uint2 v = stg[k];
-            v.x = ok ? v.x : 0u;
-            v.y = ok ? v.y : 0u;
-            *reinterpret_cast<uint2*>(buf + row * WG2_ROWB + p * 8) = v;
+            for (int k = 0; k < NLD; ++k)
+                *(lptr_t)(buf + lane_woff + k * 8 * WG2_ROWB) = ((unsigned long long)stg[k].y << 32) | stg[k].x;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int blk = k % NBLK, tp = k / NBLK;
+                const bool bok = blk < XB ? blk < nbi : (blk - XB) < nbj;
+                const bool ok = bok && (t0 + tp < t_end);
+                uint2 v = stg[k];
+                v.x = ok ? v.x : 0u;
+                v.y = ok ? v.y : 0u;
+                *(lptr_t)(buf + lane_woff + k * 8 * WG2_ROWB) = ((unsigned long long)v.y << 32) | v.x;
+            }
         }
     };
     // per-lane constant part of the transpose-read address
@@ -271,53 +276,75 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const NcwWgradDesc* __r
     for (int64_t t0 = t_begin; t0 < t_end; t0 += 2) {
         const bool has_next = t0 + 2 < t_end;
         if (has_next) issue_loads(t0 + 2);
-        const char* bufp = lds + cur * WG2_BUF_BYTES;
+        const char* bufp = lds + cur * BUF_BYTES;
 #pragma unroll
         for (int kstep = 0; kstep < WG2_CP / 16; ++kstep) {
             const int tp = kstep >> 1, pb = 16 * (kstep & 1);
-            const char* kbase = bufp + tp * (WG2_ROWS_PER_TILE * WG2_ROWB) + pb * 8 + lane_off;
-            bf16x8 af[2], bfr[4];
+            const char* kbase = bufp + tp * (ROWS_PER_TILE * WG2_ROWB) + pb * 8 + lane_off;
+            bf16x8 af[WI], bfr[WJ];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = tr_frag(kbase + (2 * wi + a) * 8 * WG2_ROWB);
+            for (int a = 0; a < WI; ++a) af[a] = tr_frag(kbase + (WI * wi + a) * 8 * WG2_ROWB);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bfr[b] = tr_frag(kbase + (WG2_XB + 4 * wj + b) * 8 * WG2_ROWB);
+            for (int b = 0; b < WJ; ++b) bfr[b] = tr_frag(kbase + (XB + WJ * wj + b) * 8 * WG2_ROWB);
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                float sacc = 0.f;
+            for (int a = 0; a < WI; ++a) {
+                {   // branch-free (keeps the 4 k-steps one basic block so LDS reads pipeline under the MFMAs):
+                    // bf16 -> f32 is a 16-bit shift; 4 words of 2 bf16 each
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 wv = __builtin_bit_cast(u32x4, af[a]);
+                    float sacc = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sacc += (float)af[a][e];
-                bsum[a] += sacc;
+                    for (int e = 0; e < 4; ++e)
+                        sacc += __builtin_bit_cast(float, wv[e] << 16) + __builtin_bit_cast(float, wv[e] & 0xffff0000u);
+                    bsum[a] += sacc;
+                }
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < WJ; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
             }
         }
-        if (has_next) write_lds(lds + (cur ^ 1) * WG2_BUF_BYTES, t0 + 2);
+        if (has_next) write_lds(lds + (cur ^ 1) * BUF_BYTES, t0 + 2);
         __syncthreads();
         cur ^= 1;
     }
     // ---- epilogue -----------------------------------------------------------------------------------
     if (t_begin >= t_end) return;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int ib = 2 * wi + a;
+    for (int a = 0; a < WI; ++a) {
+        const int ib = WI * wi + a;
         if (ib >= nbi) continue;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int jb = 4 * wj + b;
+        for (int b = 0; b < WJ; ++b) {
+            const int jb = WJ * wj + b;
             if (jb >= nbj) continue;
-            const int col = (WG2_YB * qj + jb) * 32 + (lane & 31);
+            const int col = (YB * qj + jb) * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (WG2_XB * qi + ib) * 32 + ncw_feat_of(r, lane >> 5);
+                const int row = (XB * qi + ib) * 32 + ncw_feat_of(r, lane >> 5);
                 atomicAdd(&D.dense[(size_t)row * D.ld + col], acc[a][b][r]);
             }
         }
         if (do_bias) {
             const float tot = bsum[a] + __shfl_xor(bsum[a], 32, 64);
-            if (lane < 32) atomicAdd(&D.dbias[(WG2_XB * qi + ib) * 32 + lane], tot);
+            if (lane < 32) atomicAdd(&D.dbias[(XB * qi + ib) * 32 + lane], tot);
         }
     }
+}
+
+// tile: 0 = 128 x 256 (X x Y features per workgroup), 1 = 256 x 256 (each stash element is read once per
+// product; for products with more than 4 X blocks).  bf16 only; the f32 kernel ignores it.
+extern "C" int ncw_wgrad_tiled(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
+                               int tile, int64_t n_points, void* stream) {
+    if (n_desc <= 0 || total_wgs <= 0 || n_points <= 0) return 0;
+    if (ksplit < 1 || (tile != 0 && tile != 1)) return NCW_E_BADARG;
+    const int64_t ntiles = (n_points + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (tile == 0)
+        hipLaunchKernelGGL((wgrad_bf16_kernel<4, 8>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+    else
+        hipLaunchKernelGGL((wgrad_bf16_kernel<8, 8>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+    NCW_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
@@ -327,7 +354,7 @@ extern "C" int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, in
     const int64_t ntiles = (n_points + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (prec == NCW_PREC_BF16)
-        hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+        hipLaunchKernelGGL((wgrad_bf16_kernel<4, 8>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
     else if (prec == NCW_PREC_F32)
         hipLaunchKernelGGL(wgrad_kernel<PrecF32>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
     else return NCW_E_BADARG;

@@ -65,46 +65,54 @@ class WgradBatch:
     def add(self, x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr=0):
         self.items.append((x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr))
 
-    _cache = {}  # content-addressed device tables: (items, prec, n) -> (table, prefix, n_desc, wgs, ksplit)
+    _cache = {}  # content-addressed device tables: (items, prec, n, tile) -> (table, prefix, n_desc, wgs, ksplit)
+
+    def _launch_group(self, items, tile, ksplit):
+        """tile: None = f32 kernel (128x128), 0 = bf16 128x256, 1 = bf16 256x256."""
+        if not items:
+            return None
+        key = (tuple(items), self.prec, self.n, tile, str(self.device))
+        hit = WgradBatch._cache.get(key)
+        if hit is None:
+            xb, yb = (4, 4) if tile is None else ((4, 8) if tile == 0 else (8, 8))
+            descs, prefix = [], [0]
+            for (x, rbx, y, rby, dense, ld, db) in items:
+                d = L.NcwWgradDesc()
+                d.x, d.y, d.dense, d.dbias = x, y, dense, db
+                d.rbx, d.rby, d.ld = rbx, rby, ld
+                descs.append(d)
+                prefix.append(prefix[-1] + ((rbx + xb - 1) // xb) * ((rby + yb - 1) // yb) * ksplit)
+            arr = (L.NcwWgradDesc * len(descs))(*descs)
+            tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            pre = torch.tensor(prefix, dtype=torch.int32, device=self.device)
+            if len(WgradBatch._cache) > 32:
+                WgradBatch._cache.clear()
+            hit = WgradBatch._cache[key] = (tab, pre, len(descs), prefix[-1], ksplit)
+        return (tile,) + hit
 
     def run(self):
         if not self.items or self.n == 0:
             return
-        hit = self.__dict__.get("_launch")
-        if hit is not None:
-            tab, pre, nd, wgs, ks = hit
-            L.check(L.get_lib().ncw_wgrad(L.ptr(tab), L.ptr(pre), nd, wgs, ks, self.prec, self.n,
-                                          L.stream_ptr(self.device)), "ncw_wgrad")
-            return
-        tiles = (self.n + 31) // 32
-        chunk_tiles = 2 if self.prec == L.PREC_BF16 else 1
-        ksplit = max(1, min(16, tiles // (8 * chunk_tiles)))
-        key = (tuple(self.items), self.prec, self.n, str(self.device))
-        hit = WgradBatch._cache.get(key)
-        if hit is not None:
-            tab, pre, nd, wgs, ks = hit
-            self._launch = hit
-            L.check(L.get_lib().ncw_wgrad(L.ptr(tab), L.ptr(pre), nd, wgs, ks, self.prec, self.n,
-                                          L.stream_ptr(self.device)), "ncw_wgrad")
-            return
-        descs, prefix = [], [0]
-        for (x, rbx, y, rby, dense, ld, db) in self.items:
-            d = L.NcwWgradDesc()
-            d.x, d.y, d.dense, d.dbias = x, y, dense, db
-            d.rbx, d.rby, d.ld = rbx, rby, ld
-            descs.append(d)
-            # workgroup tile: 128 x 128 (f32 kernel) or 128 x 256 (bf16 transpose-read kernel)
-            yb = 8 if self.prec == L.PREC_BF16 else 4
-            prefix.append(prefix[-1] + ((rbx + 3) // 4) * ((rby + yb - 1) // yb) * ksplit)
-        arr = (L.NcwWgradDesc * len(descs))(*descs)
-        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-        pre = torch.tensor(prefix, dtype=torch.int32, device=self.device)
-        L.check(L.get_lib().ncw_wgrad(L.ptr(tab), L.ptr(pre), len(descs), prefix[-1], ksplit, self.prec, self.n,
-                                      L.stream_ptr(self.device)), "ncw_wgrad")
-        if len(WgradBatch._cache) > 16:
-            WgradBatch._cache.clear()
-        WgradBatch._cache[key] = (tab, pre, len(descs), prefix[-1], ksplit)
-        self._launch = WgradBatch._cache[key]
+        groups = self.__dict__.get("_groups")
+        if groups is None:
+            tiles = (self.n + 31) // 32
+            chunk_tiles = 2 if self.prec == L.PREC_BF16 else 1
+            ksplit = max(1, min(16, tiles // (8 * chunk_tiles)))
+            if self.prec == L.PREC_BF16:
+                big = [it for it in self.items if it[1] > 4]      # more than 4 X blocks: 256 x 256 tiles
+                small = [it for it in self.items if it[1] <= 4]
+                groups = [g for g in (self._launch_group(big, 1, ksplit), self._launch_group(small, 0, ksplit)) if g]
+            else:
+                groups = [self._launch_group(self.items, None, ksplit)]
+            self._groups = groups
+        lib = L.get_lib()
+        for tile, tab, pre, nd, wgs, ks in groups:
+            if tile is None:
+                L.check(lib.ncw_wgrad(L.ptr(tab), L.ptr(pre), nd, wgs, ks, self.prec, self.n, L.stream_ptr(self.device)),
+                        "ncw_wgrad")
+            else:
+                L.check(lib.ncw_wgrad_tiled(L.ptr(tab), L.ptr(pre), nd, wgs, ks, tile, self.n,
+                                            L.stream_ptr(self.device)), "ncw_wgrad_tiled")
 
 
 class StashCache:
