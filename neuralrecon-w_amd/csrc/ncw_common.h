@@ -239,7 +239,10 @@ struct ActB {
 // acc[RB_OUT] += W . B, W streamed through the LDS ring.  ALL threads of the workgroup must call
 // this with identical (uniform) arguments.  w_next/next_bytes: first chunk of the matrix the NEXT
 // mma_stream call will consume (nullptr at the end of the kernel).
-template <int RB_OUT, int K_REAL, int SLOT, int RB_STRIDE, class P, class BP>
+// PIPE (explicit double-buffering of the weight fragments, +8 fragment registers) pays in the kernels that
+// own a whole SIMD (one workgroup per CU, 64 KiB slots); the two-workgroups-per-CU kernels (32 KiB slots) are
+// capped at 256 registers -- there the other workgroup's waves hide the LDS latency and PIPE only spills.
+template <int RB_OUT, int K_REAL, int SLOT, int RB_STRIDE, class P, class BP, bool PIPE = (SLOT != 32768)>
 NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename P::welem* __restrict__ wp,
                           const void* w_next, int next_bytes, int lane) {
     constexpr int RB_IN = BP::RB_IN;
@@ -260,6 +263,11 @@ NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename
         }
         typedef const __attribute__((address_space(3))) Frag* lfrag_t;
         lfrag_t lw = (lfrag_t)(ring.slot(ring.cur)) + lane;
+        // Software pipeline: the RB_OUT weight fragments of the NEXT active unit are read from LDS while the
+        // MFMAs of the current unit issue (hipcc otherwise emits ds_read -> s_waitcnt lgkmcnt(0) -> mfma
+        // one by one and the matrix pipe idles on LDS latency).  Unit validity is compile-time.
+        Frag cur[RB_OUT], nxt[RB_OUT];
+        bool loaded = false;
 #pragma unroll
         for (int u = 0; u < CU; ++u) {
             const int q = c * CU + u;
@@ -267,12 +275,31 @@ NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename
             const int rb = q / UPB, sub = q % UPB;
             if (sub == 0) bp.prepare(rb);
             if (ncw_unit_first_feature<P>(rb, sub) >= K_REAL) continue;
-            const auto b = bp.b(rb, sub);
-            lfrag_t w = lw + u * RB_STRIDE * 64;
+            if (!loaded) {
 #pragma unroll
-            for (int ro = 0; ro < RB_OUT; ++ro) {
-                const Frag a = w[ro * 64];
-                acc.v[ro] = unit_mfma(a, b, acc.v[ro]);
+                for (int ro = 0; ro < RB_OUT; ++ro) cur[ro] = (lw + u * RB_STRIDE * 64)[ro * 64];
+                loaded = true;
+            }
+            int un = -1;  // next active unit of this chunk
+#pragma unroll
+            for (int v = CU - 1; v > u; --v) {
+                const int qv = c * CU + v;
+                if (qv < NU && ncw_unit_first_feature<P>(qv / UPB, qv % UPB) < K_REAL) un = v;
+            }
+            if (PIPE && un >= 0) {
+#pragma unroll
+                for (int ro = 0; ro < RB_OUT; ++ro) nxt[ro] = (lw + un * RB_STRIDE * 64)[ro * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const auto b = bp.b(rb, sub);
+#pragma unroll
+            for (int ro = 0; ro < RB_OUT; ++ro) acc.v[ro] = unit_mfma(cur[ro], b, acc.v[ro]);
+            if (PIPE && un >= 0) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ro = 0; ro < RB_OUT; ++ro) cur[ro] = nxt[ro];
+            } else {
+                loaded = false;
             }
         }
         ring.cur ^= 1;
