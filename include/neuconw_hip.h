@@ -154,7 +154,7 @@ int ncw_sdf_infer_points(const NcwSdfNet* net, int prec, const NcwPoints* pts, i
 typedef struct NcwSdfStash {
     void* gamma;                 /* encoding, 2 blocks                                        */
     void* h[NCW_MAX_LAYERS];     /* h[l], l>=1: input of layer l = Softplus(z_{l-1}), rb blocks */
-    void* s[NCW_MAX_LAYERS];     /* s[l] = Softplus'(z_l), l <= L-2                            */
+    void* s[NCW_MAX_LAYERS];     /* unused (Softplus'(z_l) is recomputed as 1 - exp(-100 h[l+1])); kept for ABI */
     void* t[NCW_MAX_LAYERS];     /* t[l] = a_l * s[l] (adjoint pass), l <= L-2                 */
     void* feat;                  /* feature vector z_{L-1}[1:], rb blocks                      */
     void* dfeat;                 /* upstream d(feat), rb blocks                                */

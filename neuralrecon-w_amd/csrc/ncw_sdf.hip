@@ -29,6 +29,19 @@ struct SdfShapes {
     static constexpr int FCB_T0 = ncw_first_chunk_bytes<P, RB, 32 * RB, 2, SLOT>();         // wt[0]
 };
 
+// Softplus'(z_l) recovered from the stashed activation h_{l+1} = Softplus(z_l):  s = 1 - exp(-100 h)
+// (exactly sigmoid(100 z); 1 above torch's threshold to f32 rounding).  Saves a whole stash vector per
+// layer (write in the forward, reads in the adjoint pass and in the backward).
+template <class P, class SE>
+NCW_DEV void load_sprime_block(f32x16& sv, const SE* __restrict__ st_h, size_t tile, int RB, int rb, int lane) {
+    stash_load_block(sv, st_h, tile, RB, rb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (Fast<P>::v) sv[r] = 1.f - __builtin_amdgcn_exp2f(sv[r] * -144.26950408889634f);
+        else sv[r] = -expm1f(-100.f * sv[r]);
+    }
+}
+
 // z_l = b_l + W_l u_l for a hidden layer l (1 <= l <= L-2), honouring the skip concatenation
 template <class P, int RB, int SLOT, class GammaFn>
 NCW_DEV void sdf_hidden_layer(CVec<RB>& acc, const Act<P, RB>& act, GammaFn&& gamma_fn, const NcwSdfNet& net, int l,
@@ -145,11 +158,11 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet ne
         to_act(gact, gam);
         mma_stream<2, RB, 39, SH::SLOT>(acc, gact, ring, (const WE*)net.w[0], wn, nbts, lane);
     }
-    softplus_epilogue<P, RB>(act, acc, (SE*)st.h[1], (SE*)st.s[0], tile, lane);
+    softplus_epilogue<P, RB>(act, acc, (SE*)st.h[1], nullptr, tile, lane);
     for (int l = 1; l < L - 1; ++l) {
         next_of(l, wn, nbts);
         sdf_hidden_layer<P, RB, SH::SLOT>(acc, act, reload_gamma, net, l, ring, wn, nbts, lane);
-        softplus_epilogue<P, RB>(act, acc, (SE*)st.h[l + 1], (SE*)st.s[l], tile, lane);
+        softplus_epilogue<P, RB>(act, acc, (SE*)st.h[l + 1], nullptr, tile, lane);
     }
     {
         CVec<1> o;
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet ne
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             f32x16 sv;
-            stash_load_block(sv, (const SE*)st.s[l], tile, RB, rb, lane);
+            load_sprime_block<P>(sv, (const SE*)st.h[l + 1], tile, RB, rb, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) sv[r] *= a.v[rb][r];
             stash_store_block((SE*)st.t[l], tile, RB, rb, sv, lane);
@@ -297,7 +310,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void sdf_bwd_kernel(NcwSdfNet
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             f32x16 sv, tv, z2, ab;
-            stash_load_block(sv, (const SE*)st.s[l], tile, RB, rb, lane);
+            load_sprime_block<P>(sv, (const SE*)st.h[l + 1], tile, RB, rb, lane);
             stash_load_block(tv, (const SE*)st.t[l], tile, RB, rb, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void sdf_bwd_kernel(NcwSdfNet
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             f32x16 sv, z2;
-            stash_load_block(sv, (const SE*)st.s[l], tile, RB, rb, lane);
+            load_sprime_block<P>(sv, (const SE*)st.h[l + 1], tile, RB, rb, lane);
             stash_load_block(z2, (const SE*)st.zbar[l], tile, RB, rb, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) z2[r] = u.v[rb][r] * sv[r] + z2[r];

@@ -214,7 +214,7 @@ class SDFNetwork(nn.Module):
             ar = StashArena(dev, prec, n)
             ids = dict(gamma=ar.new(2), feat=ar.new(RB), dfeat=ar.new(RB), zsdf=ar.new(1), one=ar.new(1))
             ids["h"] = {l: ar.new(RB) for l in range(1, Lm)}
-            ids["s"] = {l: ar.new(RB) for l in range(Lm - 1)}
+            ids["s"] = {}  # Softplus' is recomputed from h (s = 1 - exp(-100 h)): no stash vector
             ids["t"] = {l: ar.new(RB) for l in range(Lm - 1)}
             ids["qbar"] = {l: ar.new(2 if l == 0 else RB) for l in range(Lm)}
             ids["zbar"] = {l: ar.new(RB) for l in range(Lm - 1)}
