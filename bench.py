@@ -100,7 +100,9 @@ def kernel_flops(R):
         "ncw_color_bwd": 2.0 * n_in * M_COL,
         "ncw_nerf_fwd": 2.0 * n_bg * M_BG,
         "ncw_nerf_bwd": 2.0 * n_bg * M_BG,
-        "ncw_wgrad": 2.0 * n_in * (2 * M_SDF + M_COL) + 2.0 * n_bg * M_BG,   # 2 launches (inside + background)
+        # weight-gradient GEMMs of all three networks: 2 batches (inside + background) x 2 tile variants
+        "ncw_wgrad_tiled": 2.0 * n_in * (2 * M_SDF + M_COL) + 2.0 * n_bg * M_BG,
+        "ncw_wgrad": 2.0 * n_in * (2 * M_SDF + M_COL) + 2.0 * n_bg * M_BG,   # f32 mode uses this entry point
         "ncw_sdf_infer_rays": 2.0 * R * (N_SAMPLES + per_step_imp * (UP_STEPS - 1)) * M_SDF1,
     }
 
@@ -233,13 +235,41 @@ def main():
         avg_ms = rows[dom][0] / rows[dom][1]
         ach = fl[dom] / (rows[dom][0] * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if prec == nw.PREC_BF16 else 157.3
+        # HBM traffic of the dominant entry point per launch: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, KB)
+        # of this same command, committed under profiles/ (bench.py cannot run rocprof on itself).
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_v2.json")))
+            keys = {"ncw_wgrad_tiled": "wgrad_bf16_kernel", "ncw_sdf_bwd": "sdf_bwd_kernel", "ncw_sdf_fwd": "sdf_fwd_kernel"}
+            sel = [v for k, v in tj.items() if keys.get(dom, "\0") in k]
+            if sel and prec == nw.PREC_BF16 and R == R_PER_GPU:
+                kb = sum((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * v["launches"] for v in sel)
+                traffic = round(kb * 1024.0 / sum(v["launches"] for v in sel), 0)  # bytes per launch (uncorrected)
+        except Exception:
+            traffic = None
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                    "frac": round(ach / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                     "launches_per_step": rows[dom][1],
                     "algorithmic_gflop_per_launch": round(fl[dom] / rows[dom][1] / 1e9, 2),
                     "kernel_tflops": {k: round(fl[k] / (rows[k][0] * 1e-3) / 1e12, 1) for k in rows if fl.get(k)},
                     "per_step_kernel_ms": {k: round(v[0], 4) for k, v in sorted(rows.items(), key=lambda kv: -kv[1][0])},
                     "sum_kernel_ms_per_step": round(total_ms, 4)}
+        if dom.startswith("ncw_wgrad"):
+            # The weight-gradient GEMMs reduce over the POINTS: every product streams its two stash operands
+            # once (algorithmic bytes = sum over products of (rbx + rby) x 32 features x elem x points); at
+            # ~180 FLOP/B they sit left of the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B): HBM-bound.
+            esz = 2 if prec == nw.PREC_BF16 else 4
+            alg_bytes = 0.0
+            for mod in (neuconw.sdf_net, nerf):
+                for ent in mod.__dict__.get("_stash_cache")._e.values():
+                    wb = ent.get("wgrad_batch")
+                    if wb is not None:
+                        tiles = (wb.n + 31) // 32
+                        alg_bytes += sum((it[1] + it[3]) * 1024 * esz * tiles for it in wb.items)
+            gbs = alg_bytes / (rows[dom][0] * 1e-3) / 1e9
+            roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                             "frac": round(gbs / 8000.0, 4), "algorithmic_gbytes_per_step": round(alg_bytes / 1e9, 3),
+                             "mfma_tflops": round(ach, 1)})
         # step-level MFMA fraction: all algorithmic FLOPs of the step / wall time
         step_flops = 2.0 * R * ((N_SAMPLES + (UP_STEPS - 1) * N_IMPORTANCE // UP_STEPS) * M_SDF1
                                 + S * (6 * M_SDF + 3 * M_COL) + (S + N_OUTSIDE) * 3 * M_BG)
