@@ -331,6 +331,158 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const NcwWgradDesc* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the bf16 kernel: the stash bytes go global -> LDS with global_load_lds_dwordx4 (no
+// staging registers, no ds_write pass), FOUR one-tile buffers rotate so that three tiles (96 KiB per CU)
+// are always in flight -- HBM latency is hidden by depth, not by occupancy.  The DMA writes lane-linear
+// 1 KiB pieces, so the bank-conflict fix is a SOURCE-side swizzle: inside each 256-byte row r (32 points
+// x 8 B) the 16-byte slots are rotated by (r & 3) * 64 bytes, which puts the four rows a transpose-read
+// group touches on disjoint banks.  Only DMA ops use vmcnt inside the loop, so the waits are counted
+// (s_waitcnt vmcnt(16): two younger tiles stay in flight) around a raw s_barrier.
+// ------------------------------------------------------------------------------------------------
+template <int XB, int YB>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const NcwWgradDesc* __restrict__ descs,
+                                                        const int32_t* __restrict__ prefix, int n_desc, int ksplit,
+                                                        int64_t ntiles) {
+    constexpr int WI = XB / 2, WJ = YB / 2;
+    constexpr int NBLK = XB + YB;
+    constexpr int BUF = NBLK * 2048;          // one tile of all blocks
+    constexpr int NBUF = 4;
+    constexpr int PPW = NBLK * 2 / 4;         // 1 KiB pieces per wave per tile
+    __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF];
+    const int d = wg_find(prefix, n_desc, blockIdx.x);
+    const NcwWgradDesc D = descs[d];
+    const int local = blockIdx.x - prefix[d];
+    const int quad = local / ksplit, ks = local - quad * ksplit;
+    const int nqj = (D.rby + YB - 1) / YB;
+    const int qi = quad / nqj, qj = quad - qi * nqj;
+    const int nbi = min(XB, D.rbx - XB * qi), nbj = min(YB, D.rby - YB * qj);
+    const int64_t tpk = (ntiles + ksplit - 1) / ksplit;
+    const int64_t t_begin = (int64_t)ks * tpk, t_end = min(t_begin + tpk, ntiles);
+    if (t_begin >= t_end) return;  // uniform: whole workgroup
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    const int wi = uw >> 1, wj = uw & 1;
+    f32x16 acc[WI][WJ];
+#pragma unroll
+    for (int a = 0; a < WI; ++a)
+#pragma unroll
+        for (int b = 0; b < WJ; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[WI];
+#pragma unroll
+    for (int a = 0; a < WI; ++a) bsum[a] = 0.f;
+    const bool do_bias = (D.dbias != nullptr) && (qj == 0) && (wj == 0);
+    const char* xg = (const char*)D.x;
+    const char* yg = (const char*)D.y;
+    // ---- DMA issue: piece pc (0 .. 2*NBLK) = block pc/2, rows 4*(pc&1) .. +3; lane L fills slot L ------------
+    const int prow = lane >> 4, pslot = lane & 15;  // row within the piece, 16-byte slot within the row
+    auto issue_tile = [&](int64_t tile_raw, int bufi) {
+        const int64_t tile = min(tile_raw, t_end - 1);  // past the end: harmless re-load (keeps vmcnt counts uniform)
+        ncw_lchar* lbuf = (ncw_lchar*)lds + bufi * BUF;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int pc = uw + 4 * k;
+            const int blk = pc >> 1, r0 = 4 * (pc & 1);
+            const bool isx = blk < XB;
+            const int bsel = isx ? min(blk, nbi - 1) : min(blk - XB, nbj - 1);
+            const char* base = isx ? xg : yg;
+            const int64_t rb = isx ? D.rbx : D.rby;
+            const int64_t b0 = isx ? XB * qi : YB * qj;
+            const char* ub = base + (tile * rb + b0 + bsel) * 2048 + r0 * 256;   // scalar
+            const int r = r0 + prow;                                                // row inside the block
+            const unsigned src = (unsigned)(prow * 256 + ((pslot * 16 - (r & 3) * 64) & 255));
+            // issued as asm so the compiler does not see an LDS write it would fence with vmcnt(0) before every
+            // LDS read; the counted waits below are the synchronisation
+            const unsigned long long ubi = (unsigned long long)ub;
+            const unsigned ulo = __builtin_amdgcn_readfirstlane((unsigned)ubi);
+            const unsigned uhi = __builtin_amdgcn_readfirstlane((unsigned)(ubi >> 32));
+            const unsigned long long ubu = ((unsigned long long)uhi << 32) | ulo;
+            const unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lbuf + blk * 2048 + r0 * 256));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(src), "s"(ubu), "s"(loff) : "memory");
+        }
+    };
+    // ---- transpose-read addressing (see wgrad_bf16_kernel): source lane s of 16-lane group q ---------------
+    const int q = lane >> 4, s = lane & 15;
+    const int kh = q >> 1, fhalf = q & 1;
+    const int fsrc = 16 * fhalf + 4 * (s & 3);
+    const int rr = 2 * (fsrc >> 3) + ((fsrc >> 2) & 1);  // row inside the block
+    const int psrc = 8 * kh + (s >> 2);
+    unsigned toff[2][2];  // [k-step within the tile][4-point half]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            toff[kk][hf] = (unsigned)(rr * 256 + (((psrc + 16 * kk + 4 * hf) * 8 + (rr & 3) * 64) & 255));
+    auto frag = [&](const ncw_lchar* blockp, int kk) -> bf16x8 {
+        typedef __attribute__((address_space(3))) ncw_s16x4* lp;
+        const ncw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(blockp + toff[kk][0]));
+        const ncw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(blockp + toff[kk][1]));
+        const ncw_s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, w);
+    };
+    // ---- pipeline -------------------------------------------------------------------------------------
+    issue_tile(t_begin + 0, 0);
+    issue_tile(t_begin + 1, 1);
+    issue_tile(t_begin + 2, 2);
+    int bufi = 0;
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        // tiles t, t+1, t+2 are in flight (PPW DMA ops each, issued in that order): retire tile t only
+        if (PPW == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_tile(t + 3, (bufi + 3) & 3);  // the buffer read in the previous iteration (everyone passed the barrier)
+        const ncw_lchar* bufp = (const ncw_lchar*)lds + bufi * BUF;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[WI], bfr[WJ];
+#pragma unroll
+            for (int a = 0; a < WI; ++a) af[a] = frag(bufp + (WI * wi + a) * 2048, kk);
+#pragma unroll
+            for (int b = 0; b < WJ; ++b) bfr[b] = frag(bufp + (XB + WJ * wj + b) * 2048, kk);
+#pragma unroll
+            for (int a = 0; a < WI; ++a) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 wv = __builtin_bit_cast(u32x4, af[a]);
+                float sacc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    sacc += __builtin_bit_cast(float, wv[e] << 16) + __builtin_bit_cast(float, wv[e] & 0xffff0000u);
+                bsum[a] += sacc;
+#pragma unroll
+                for (int b = 0; b < WJ; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        bufi = (bufi + 1) & 3;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy tail loads before LDS goes away
+    // ---- epilogue ---------------------------------------------------------------------------------------
+    typedef __attribute__((address_space(1))) float* gfp;
+#pragma unroll
+    for (int a = 0; a < WI; ++a) {
+        const int ib = WI * wi + a;
+        if (ib >= nbi) continue;
+#pragma unroll
+        for (int b = 0; b < WJ; ++b) {
+            const int jb = WJ * wj + b;
+            if (jb >= nbj) continue;
+            const int col = (YB * qj + jb) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (XB * qi + ib) * 32 + ncw_feat_of(r, lane >> 5);
+                atomicAdd((float*)&D.dense[(size_t)row * D.ld + col], acc[a][b][r]);
+            }
+        }
+        if (do_bias) {
+            const float tot = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+            if (lane < 32) atomicAdd(&D.dbias[(XB * qi + ib) * 32 + lane], tot);
+        }
+    }
+}
+
 // tile: 0 = 128 x 256 (X x Y features per workgroup), 1 = 256 x 256 (each stash element is read once per
 // product; for products with more than 4 X blocks).  bf16 only; the f32 kernel ignores it.
 extern "C" int ncw_wgrad_tiled(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
@@ -340,9 +492,9 @@ extern "C" int ncw_wgrad_tiled(const NcwWgradDesc* descs, const int32_t* wg_pref
     const int64_t ntiles = (n_points + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (tile == 0)
-        hipLaunchKernelGGL((wgrad_bf16_kernel<4, 8>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+        hipLaunchKernelGGL((wgrad_dma_kernel<4, 8>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
     else
-        hipLaunchKernelGGL((wgrad_bf16_kernel<8, 8>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+        hipLaunchKernelGGL((wgrad_dma_kernel<8, 8>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
     NCW_CHECK_LAUNCH();
     return 0;
 }
