@@ -260,12 +260,10 @@ def main():
             # ~180 FLOP/B they sit left of the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B): HBM-bound.
             esz = 2 if prec == nw.PREC_BF16 else 4
             alg_bytes = 0.0
-            for mod in (neuconw.sdf_net, nerf):
-                for ent in mod.__dict__.get("_stash_cache")._e.values():
-                    wb = ent.get("wgrad_batch")
-                    if wb is not None:
-                        tiles = (wb.n + 31) // 32
-                        alg_bytes += sum((it[1] + it[3]) * 1024 * esz * tiles for it in wb.items)
+            for ent in neuconw.sdf_net.__dict__.get("_stash_cache")._e.values():
+                wb = ent.get("wgrad_batch")
+                if wb is not None:
+                    alg_bytes += type(wb).algorithmic_bytes(wb.items, esz)
             gbs = alg_bytes / (rows[dom][0] * 1e-3) / 1e9
             roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                              "frac": round(gbs / 8000.0, 4), "algorithmic_gbytes_per_step": round(alg_bytes / 1e9, 3),

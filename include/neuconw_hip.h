@@ -258,14 +258,18 @@ typedef struct NcwWgradDesc {
     const void* y;     /* stash, rby blocks  (input-feature side)   */
     float* dense;      /* [32*rbx, ld] (+ column offset already applied) */
     float* dbias;      /* [32*rbx] or NULL                           */
-    int32_t rbx, rby, ld, _pad;
+    int32_t rbx, rby, ld;
+    int32_t ksplit;    /* ncw_wgrad_tiled only: > 0 overrides the launch-wide split-K for this product */
+    int64_t n_points;  /* ncw_wgrad_tiled only: > 0 overrides the launch-wide point count            */
 } NcwWgradDesc;
 /* descs: DEVICE array; wg_prefix: device int32[n_desc+1] exclusive prefix of
  * ceil(rbx/4)*ceil(rby/4)*ksplit workgroups per product; total_wgs = wg_prefix[n_desc]. */
 int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
               int prec, int64_t n_points, void* stream);
 /* bf16 only, explicit workgroup tile: tile 0 = 128 x 256 features (wg_prefix counts ceil(rbx/4)*ceil(rby/8)*ksplit),
- * tile 1 = 256 x 256 (ceil(rbx/8)*ceil(rby/8)*ksplit): every stash element is read once per product. */
+ * tile 1 = 256 x 256 (ceil(rbx/8)*ceil(rby/8)*ksplit): every stash element is read once per product.
+ * A product's own ksplit / n_points (when > 0) replace the launch-wide values, so products of different
+ * networks and sizes share ONE launch with a work-proportional split. */
 int ncw_wgrad_tiled(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
                     int tile, int64_t n_points, void* stream);
 

@@ -152,187 +152,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const NcwWgradDesc* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16 fast path: no scatter-transpose.  The stash bytes of a chunk are copied VERBATIM into LDS (8-byte
-// rows of "4 features of one point", padded 288-byte rows -> conflict-free) and the MFMA operands
-// "8 points of one feature" are produced by the hardware transpose read ds_read_b64_tr_b16:
+// bf16 fast path: no scatter-transpose.  The stash bytes of a tile are copied VERBATIM into LDS and the MFMA
+// operands "8 points of one feature" are produced by the hardware transpose read ds_read_b64_tr_b16:
 //   within a 16-lane group, out[lane i][j] = src[lane 4j + i/4][i % 4]      (probed on gfx950,
 //   scripts/probes/tr16_probe.hip), so with source lane s pointing at (point p0 + s/4, features
 //   f0 + 4 (s%4) ..+3) lane i receives feature f0 + i of points p0..p0+3.
-// Workgroup tile = 128 (X features) x 256 (Y features), 4 waves as 2x2, each 2x4 blocks of 32x32;
-// chunk = 64 points; next chunk's global loads are in flight during the MFMAs (register staging).
+// The transpose read goes through the compiler-tracked builtin (the compiler counts lgkmcnt and schedules
+// the reads against the MFMAs; an inline-asm version raced: hipcc copied the asm's destination registers
+// before the data had landed).
 // ------------------------------------------------------------------------------------------------
-#define WG2_CP 64                 // points per chunk (2 stash tiles)
-#define WG2_ROWB 288              // LDS row: 32 points x 8 B + 32 B pad
-#define WG2_XB 4                  // X blocks per workgroup
-#define WG2_YB 8                  // Y blocks per workgroup
-#define WG2_ROWS_PER_TILE ((WG2_XB + WG2_YB) * 8)
-#define WG2_BUF_BYTES (2 * WG2_ROWS_PER_TILE * WG2_ROWB)
-
-// transpose read of 4 points x (this lane's feature) through the compiler-tracked builtin (the
-// compiler counts lgkmcnt and schedules the reads against the MFMAs; an inline-asm version raced:
-// hipcc copied the asm's destination registers before the data had landed)
 typedef short ncw_s16x4 __attribute__((ext_vector_type(4)));
 typedef short ncw_s16x8 __attribute__((ext_vector_type(8)));
-NCW_DEV bf16x8 tr_frag(const char* lds_ptr) {
-    typedef __attribute__((address_space(3))) ncw_s16x4* lp;
-    const ncw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds_ptr));        // points +0..3
-    const ncw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds_ptr + 32));   // points +4..7
-    const ncw_s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, w);
-}
-
-template <int XB, int YB>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const NcwWgradDesc* __restrict__ descs,
-                                                         const int32_t* __restrict__ prefix, int n_desc, int ksplit,
-                                                         int64_t ntiles) {
-    constexpr int WI = XB / 2, WJ = YB / 2;  // blocks per wave (waves tile the output 2 x 2)
-    constexpr int ROWS_PER_TILE = (XB + YB) * 8;
-    constexpr int BUF_BYTES = 2 * ROWS_PER_TILE * WG2_ROWB;
-    __shared__ __attribute__((aligned(16))) char lds[2 * BUF_BYTES];
-    const int d = wg_find(prefix, n_desc, blockIdx.x);
-    const NcwWgradDesc D = descs[d];
-    const int local = blockIdx.x - prefix[d];
-    const int quad = local / ksplit, ks = local - quad * ksplit;
-    const int nqj = (D.rby + YB - 1) / YB;
-    const int qi = quad / nqj, qj = quad - qi * nqj;
-    const int nbi = min(XB, D.rbx - XB * qi), nbj = min(YB, D.rby - YB * qj);
-    const int64_t tpk = ((ntiles + ksplit - 1) / ksplit + 1) & ~(int64_t)1;  // even number of tiles per slice
-    const int64_t t_begin = (int64_t)ks * tpk, t_end = min(t_begin + tpk, ntiles);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wi = wave >> 1, wj = wave & 1;  // wave tile: i-blocks WI*wi.., j-blocks WJ*wj..
-    f32x16 acc[WI][WJ];
-#pragma unroll
-    for (int a = 0; a < WI; ++a)
-#pragma unroll
-        for (int b = 0; b < WJ; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bsum[WI];
-#pragma unroll
-    for (int a = 0; a < WI; ++a) bsum[a] = 0.f;
-    const bool do_bias = __builtin_amdgcn_readfirstlane((int)((D.dbias != nullptr) && (qj == 0) && (wj == 0))) != 0;
-    // ---- staging bookkeeping: 12 blocks x 4 g x 2 tiles = 96 wave-loads per chunk, 24 per wave.  Wave w
-    // owns g == w of every (tile, block): the address is  [uniform base of (tile, block)] + [w*512 + lane*8],
-    // i.e. one per-lane 32-bit offset for the whole kernel and scalar (SALU) base arithmetic per load. -----
-    const int uw = __builtin_amdgcn_readfirstlane(wave);
-    const char* xg = (const char*)D.x;
-    const char* yg = (const char*)D.y;
-    constexpr int NBLK = XB + YB;
-    constexpr int NLD = NBLK * 2;  // (block, tile-in-chunk) pairs: one 8-byte load each per wave
-    const unsigned lane_goff = (unsigned)(uw * 512 + lane * 8);
-    uint2 stg[NLD];
-    auto issue_loads = [&](int64_t t0) {
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int blk = k % NBLK, tp = k / NBLK;
-            const int64_t tile = min(t0 + tp, t_end - 1);   // clamped: always a valid address
-            const bool isx = blk < XB;
-            const int bsel = isx ? min(blk, nbi - 1) : min(blk - XB, nbj - 1);
-            const char* base = isx ? xg : yg;
-            const int64_t rb = isx ? D.rbx : D.rby;
-            const int64_t b0 = isx ? XB * qi : YB * qj;
-            const char* ub = base + (tile * rb + b0 + bsel) * 2048;   // scalar arithmetic
-            typedef const __attribute__((address_space(1))) unsigned long long* gptr_t;
-            const unsigned long long raw = *(gptr_t)(ub + lane_goff);
-            stg[k] = make_uint2((unsigned)raw, (unsigned)(raw >> 32));
-        }
-    };
-    // LDS row of (tile tp, block blk, g = wave, half h) = (tp*NBLK + blk)*8 + 2*wave + h
-    const unsigned lane_woff = (unsigned)((2 * uw + (lane >> 5)) * WG2_ROWB + (lane & 31) * 8);
-    auto write_lds = [&](char* buf, int64_t t0) {
-        typedef __attribute__((address_space(3))) unsigned long long* lptr_t;
-        const bool full = (t0 + 1 < t_end) && (nbi == XB) && (nbj == YB);   // uniform
-        if (full) {
-#pragma unroll
-            for (int k = 0; k < NLD; ++k)
-                *(lptr_t)(buf + lane_woff + k * 8 * WG2_ROWB) = ((unsigned long long)stg[k].y << 32) | stg[k].x;
-        } else {
-#pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int blk = k % NBLK, tp = k / NBLK;
-                const bool bok = blk < XB ? blk < nbi : (blk - XB) < nbj;
-                const bool ok = bok && (t0 + tp < t_end);
-                uint2 v = stg[k];
-                v.x = ok ? v.x : 0u;
-                v.y = ok ? v.y : 0u;
-                *(lptr_t)(buf + lane_woff + k * 8 * WG2_ROWB) = ((unsigned long long)v.y << 32) | v.x;
-            }
-        }
-    };
-    // per-lane constant part of the transpose-read address
-    const int q = lane >> 4, s = lane & 15;
-    const int kh = q >> 1, fhalf = q & 1;
-    const int fsrc = 16 * fhalf + 4 * (s & 3);
-    const int row_in_blk = 2 * (fsrc >> 3) + ((fsrc >> 2) & 1);
-    const int psrc = 8 * kh + (s >> 2);
-    const unsigned lane_off = row_in_blk * WG2_ROWB + psrc * 8;
-
-    int cur = 0;
-    if (t_begin < t_end) {
-        issue_loads(t_begin);
-        write_lds(lds, t_begin);
-    }
-    __syncthreads();
-    for (int64_t t0 = t_begin; t0 < t_end; t0 += 2) {
-        const bool has_next = t0 + 2 < t_end;
-        if (has_next) issue_loads(t0 + 2);
-        const char* bufp = lds + cur * BUF_BYTES;
-#pragma unroll
-        for (int kstep = 0; kstep < WG2_CP / 16; ++kstep) {
-            const int tp = kstep >> 1, pb = 16 * (kstep & 1);
-            const char* kbase = bufp + tp * (ROWS_PER_TILE * WG2_ROWB) + pb * 8 + lane_off;
-            bf16x8 af[WI], bfr[WJ];
-#pragma unroll
-            for (int a = 0; a < WI; ++a) af[a] = tr_frag(kbase + (WI * wi + a) * 8 * WG2_ROWB);
-#pragma unroll
-            for (int b = 0; b < WJ; ++b) bfr[b] = tr_frag(kbase + (XB + WJ * wj + b) * 8 * WG2_ROWB);
-#pragma unroll
-            for (int a = 0; a < WI; ++a) {
-                {   // branch-free (keeps the 4 k-steps one basic block so LDS reads pipeline under the MFMAs):
-                    // bf16 -> f32 is a 16-bit shift; 4 words of 2 bf16 each
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 wv = __builtin_bit_cast(u32x4, af[a]);
-                    float sacc = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        sacc += __builtin_bit_cast(float, wv[e] << 16) + __builtin_bit_cast(float, wv[e] & 0xffff0000u);
-                    bsum[a] += sacc;
-                }
-#pragma unroll
-                for (int b = 0; b < WJ; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-            }
-        }
-        if (has_next) write_lds(lds + (cur ^ 1) * BUF_BYTES, t0 + 2);
-        __syncthreads();
-        cur ^= 1;
-    }
-    // ---- epilogue -----------------------------------------------------------------------------------
-    if (t_begin >= t_end) return;
-#pragma unroll
-    for (int a = 0; a < WI; ++a) {
-        const int ib = WI * wi + a;
-        if (ib >= nbi) continue;
-#pragma unroll
-        for (int b = 0; b < WJ; ++b) {
-            const int jb = WJ * wj + b;
-            if (jb >= nbj) continue;
-            const int col = (YB * qj + jb) * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (XB * qi + ib) * 32 + ncw_feat_of(r, lane >> 5);
-                atomicAdd(&D.dense[(size_t)row * D.ld + col], acc[a][b][r]);
-            }
-        }
-        if (do_bias) {
-            const float tot = bsum[a] + __shfl_xor(bsum[a], 32, 64);
-            if (lane < 32) atomicAdd(&D.dbias[(XB * qi + ib) * 32 + lane], tot);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
-// LDS-DMA variant of the bf16 kernel: the stash bytes go global -> LDS with global_load_lds_dwordx4 (no
+// Staging: the stash bytes go global -> LDS with global_load_lds_dwordx4 (no
 // staging registers, no ds_write pass), FOUR one-tile buffers rotate so that three tiles (96 KiB per CU)
 // are always in flight -- HBM latency is hidden by depth, not by occupancy.  The DMA writes lane-linear
 // 1 KiB pieces, so the bank-conflict fix is a SOURCE-side swizzle: inside each 256-byte row r (32 points
@@ -353,6 +186,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const NcwWgradDesc* __re
     const int d = wg_find(prefix, n_desc, blockIdx.x);
     const NcwWgradDesc D = descs[d];
     const int local = blockIdx.x - prefix[d];
+    if (D.ksplit > 0) ksplit = D.ksplit;                    // per-product split (load balancing)
+    if (D.n_points > 0) ntiles = (D.n_points + 31) / 32;    // per-product point count (merged launches)
     const int quad = local / ksplit, ks = local - quad * ksplit;
     const int nqj = (D.rby + YB - 1) / YB;
     const int qi = quad / nqj, qj = quad - qi * nqj;
@@ -506,7 +341,7 @@ extern "C" int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, in
     const int64_t ntiles = (n_points + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (prec == NCW_PREC_BF16)
-        hipLaunchKernelGGL((wgrad_bf16_kernel<4, 8>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+        hipLaunchKernelGGL(wgrad_kernel<PrecBF16>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
     else if (prec == NCW_PREC_F32)
         hipLaunchKernelGGL(wgrad_kernel<PrecF32>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
     else return NCW_E_BADARG;

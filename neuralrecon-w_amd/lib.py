@@ -63,7 +63,8 @@ class NcwSdfStash(C.Structure):
 
 class NcwWgradDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dense", C.c_void_p), ("dbias", C.c_void_p),
-                ("rbx", C.c_int32), ("rby", C.c_int32), ("ld", C.c_int32), ("_pad", C.c_int32)]
+                ("rbx", C.c_int32), ("rby", C.c_int32), ("ld", C.c_int32), ("ksplit", C.c_int32),
+                ("n_points", C.c_int64)]
 
 
 class NcwColorNet(C.Structure):

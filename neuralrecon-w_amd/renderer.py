@@ -86,29 +86,27 @@ class _RenderFn(torch.autograd.Function):
         neuconw.color_net.bwd_stash(cctx, g["d_rgb"].view(R * S, 3), d_grad, d_a, dfeat_ptr)
         neuconw.sdf_net.bwd_stash(sctx, g["d_sdf"].view(R * S), d_grad)
         plans = [sctx["plan"], cctx["plan"]]
-        # the product list only depends on the (cached) stash arenas: build it once per lease
-        b_in = sctx["lease"].get("wgrad_batch")
-        if b_in is None or b_in.tag != (id(cctx["lease"]), prec):
-            b_in = WgradBatch(dev, prec, R * S)
-            b_in.tag = (id(cctx["lease"]), prec)
-            neuconw.sdf_net.add_wgrads(sctx, b_in)
-            neuconw.color_net.add_wgrads(cctx, b_in)
-            sctx["lease"]["wgrad_batch"] = b_in
-        b_bg = None
         if ctx.use_bg:
             M = comp.S + comp.O
             nerf.bwd_stash(nctx, g["d_density"].view(R * M), g["d_bg_rgb"].view(R * M, 3), d_a)
             plans.append(nctx["plan"])
-            b_bg = nctx["lease"].get("wgrad_batch")
-            if b_bg is None:
-                b_bg = WgradBatch(dev, prec, R * M)
+        # every weight-gradient product of the step (SDF, colour, background NeRF) in ONE launch; the product
+        # list only depends on the (cached) stash arenas: build it once per lease combination
+        tag = (id(cctx["lease"]), id(nctx["lease"]) if ctx.use_bg else None, prec)
+        batch = sctx["lease"].get("wgrad_batch")
+        if batch is None or batch.tag != tag:
+            batch = WgradBatch(dev, prec, R * S)
+            batch.tag = tag
+            neuconw.sdf_net.add_wgrads(sctx, batch)
+            neuconw.color_net.add_wgrads(cctx, batch)
+            if ctx.use_bg:
+                b_bg = WgradBatch(dev, prec, R * (comp.S + comp.O))
                 nerf.add_wgrads(nctx, b_bg)
-                nctx["lease"]["wgrad_batch"] = b_bg
+                batch.extend(b_bg)
+            sctx["lease"]["wgrad_batch"] = batch
         for p in plans:
             p.g_arena.zero_()
-        b_in.run()
-        if b_bg is not None:
-            b_bg.run()
+        batch.run()
         # parameter gradients land in ONE persistent flat fp32 buffer whose views ARE the parameters'
         # .grad (the DDP all-reduce operand, ddp.py): no per-parameter copies, no per-step allocation.
         flat, views = rdr._grad_views(ctx.params)
@@ -131,7 +129,7 @@ class _RenderFn(torch.autograd.Function):
                 out.append(v)
                 off += p.numel()
             keep = [pl.unpack_grads(tviews) for pl in plans]
-        ctx._keep = (keep, b_in, b_bg)
+        ctx._keep = (keep, batch)
         inv_s = ctx.inv_s
         live = ((inv_s > 1e-6) & (inv_s < 1e6)).float()
         d_var = (g["d_inv_s"] * 10.0 * inv_s * live).reshape(ctx.variance.shape)

@@ -54,7 +54,14 @@ class StashArena:
 
 
 class WgradBatch:
-    """Collects (X, Y, dense) weight-gradient products and runs them in one ncw_wgrad launch."""
+    """Collects (X, Y, dense) weight-gradient products and runs them in one launch.
+
+    bf16: every product of every network of the step goes through ONE ncw_wgrad_tiled launch (256 x 256
+    workgroup tiles).  The kernel is HBM-bound with one workgroup per CU, so the split-K factor is chosen
+    PER PRODUCT such that the launch is ~3 rounds of equal-length workgroups over the 256 CUs
+    (scripts/bench_wgrad.py: 5.2 TB/s of stash bytes, against 4.3 TB/s for one launch per network/shape).  f32: the exact kernel, one launch per point count."""
+
+    TARGET_WGS = 768
 
     def __init__(self, device, prec, n_points):
         self.device = torch.device(device)
@@ -62,56 +69,78 @@ class WgradBatch:
         self.n = int(n_points)
         self.items = []
 
-    def add(self, x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr=0):
-        self.items.append((x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr))
+    def add(self, x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr=0, n=None):
+        self.items.append((x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr, self.n if n is None else int(n)))
 
-    _cache = {}  # content-addressed device tables: (items, prec, n, tile) -> (table, prefix, n_desc, wgs, ksplit)
+    def extend(self, other):
+        """Take over another batch's products (they keep their own point count)."""
+        self.items.extend(other.items)
 
-    def _launch_group(self, items, tile, ksplit):
-        """tile: None = f32 kernel (128x128), 0 = bf16 128x256, 1 = bf16 256x256."""
-        if not items:
-            return None
-        key = (tuple(items), self.prec, self.n, tile, str(self.device))
+    _cache = {}  # content-addressed device tables: (items, prec, tile) -> (table, prefix, n_desc, wgs, ksplit, n)
+
+    @staticmethod
+    def algorithmic_bytes(items, elem=2):
+        """Stash bytes the products stream from HBM: every X and Y block once per product."""
+        return sum((it[1] + it[3]) * 1024 * elem * ((it[7] + 31) // 32) for it in items)
+
+    def _table(self, items, tile, ksplits, ksplit, n):
+        key = (tuple(items), tuple(ksplits), self.prec, tile, ksplit, n, str(self.device))
         hit = WgradBatch._cache.get(key)
         if hit is None:
             xb, yb = (4, 4) if tile is None else ((4, 8) if tile == 0 else (8, 8))
             descs, prefix = [], [0]
-            for (x, rbx, y, rby, dense, ld, db) in items:
+            for (x, rbx, y, rby, dense, ld, db, ni), ksp in zip(items, ksplits):
                 d = L.NcwWgradDesc()
                 d.x, d.y, d.dense, d.dbias = x, y, dense, db
                 d.rbx, d.rby, d.ld = rbx, rby, ld
+                d.ksplit, d.n_points = (ksp, ni) if tile is not None else (0, 0)
                 descs.append(d)
-                prefix.append(prefix[-1] + ((rbx + xb - 1) // xb) * ((rby + yb - 1) // yb) * ksplit)
+                prefix.append(prefix[-1] + ((rbx + xb - 1) // xb) * ((rby + yb - 1) // yb) * ksp)
             arr = (L.NcwWgradDesc * len(descs))(*descs)
             tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             pre = torch.tensor(prefix, dtype=torch.int32, device=self.device)
             if len(WgradBatch._cache) > 32:
                 WgradBatch._cache.clear()
-            hit = WgradBatch._cache[key] = (tab, pre, len(descs), prefix[-1], ksplit)
+            hit = WgradBatch._cache[key] = (tab, pre, len(descs), prefix[-1], ksplit, n)
         return (tile,) + hit
 
+    def _plan(self):
+        items = [it for it in self.items if it[7] > 0]
+        if not items:
+            return []
+        if self.prec == L.PREC_BF16:
+            # cost of one (product, 256x256 quad): stash blocks streamed x tiles
+            def quads(it):
+                return ((it[1] + 7) // 8) * ((it[3] + 7) // 8)
+            def cost(it):
+                # a quad costs the same whatever its real block count (missing blocks are re-reads of a
+                # valid one, L2 hits): weighting by HBM bytes instead measured 1.55 ms vs 1.02 ms per step
+                return (it[7] + 31) // 32
+            total = sum(cost(it) * quads(it) for it in items)
+            per_wg = max(1.0, total / self.TARGET_WGS)
+            ksplits = []
+            for it in items:
+                tiles = (it[7] + 31) // 32
+                ksplits.append(int(max(1, min(tiles // 8 if tiles >= 8 else 1, round(cost(it) / per_wg)))))
+            return [self._table(items, 1, ksplits, 1, max(it[7] for it in items))]
+        groups = []
+        for n in sorted({it[7] for it in items}):
+            sub = [it for it in items if it[7] == n]
+            ksplit = max(1, min(16, ((n + 31) // 32) // 8))
+            groups.append(self._table(sub, None, [ksplit] * len(sub), ksplit, n))
+        return groups
+
     def run(self):
-        if not self.items or self.n == 0:
-            return
         groups = self.__dict__.get("_groups")
         if groups is None:
-            tiles = (self.n + 31) // 32
-            chunk_tiles = 2 if self.prec == L.PREC_BF16 else 1
-            ksplit = max(1, min(16, tiles // (8 * chunk_tiles)))
-            if self.prec == L.PREC_BF16:
-                big = [it for it in self.items if it[1] > 4]      # more than 4 X blocks: 256 x 256 tiles
-                small = [it for it in self.items if it[1] <= 4]
-                groups = [g for g in (self._launch_group(big, 1, ksplit), self._launch_group(small, 0, ksplit)) if g]
-            else:
-                groups = [self._launch_group(self.items, None, ksplit)]
-            self._groups = groups
+            groups = self._groups = self._plan()
         lib = L.get_lib()
-        for tile, tab, pre, nd, wgs, ks in groups:
+        for tile, tab, pre, nd, wgs, ks, n in groups:
             if tile is None:
-                L.check(lib.ncw_wgrad(L.ptr(tab), L.ptr(pre), nd, wgs, ks, self.prec, self.n, L.stream_ptr(self.device)),
+                L.check(lib.ncw_wgrad(L.ptr(tab), L.ptr(pre), nd, wgs, ks, self.prec, n, L.stream_ptr(self.device)),
                         "ncw_wgrad")
             else:
-                L.check(lib.ncw_wgrad_tiled(L.ptr(tab), L.ptr(pre), nd, wgs, ks, tile, self.n,
+                L.check(lib.ncw_wgrad_tiled(L.ptr(tab), L.ptr(pre), nd, wgs, ks, tile, n,
                                             L.stream_ptr(self.device)), "ncw_wgrad_tiled")
 
 
