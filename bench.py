@@ -172,24 +172,16 @@ def main():
     torch.cuda.set_device(dev)
     prec = nw.PREC_BF16 if args.prec == "bf16" else nw.PREC_F32
     emb, neuconw, nerf, rdr = build_models(dev, prec)
-    if world > 1:
-        ddp.broadcast_params([emb, neuconw, nerf])
-    params = [p for m in (emb, neuconw, nerf) for p in m.parameters()]
-    # LR rule of train.py:21-25: 1e-4 * world*batch / 4096; Adam eps 1e-7 (utils/__init__.py:24-31)
-    opt = torch.optim.Adam(params, lr=1e-4 * world * args.rays / 4096.0, eps=1e-7)
+    # LR rule of train.py:21-25: 1e-4 * world*batch / 4096; Adam eps 1e-7 (utils/__init__.py:24-31); clip 0.99
+    # (train.py:61).  TrainStep = render + loss + backward + one flat all-reduce + clip + Adam (trainer.py).
     R = args.rays
+    train = nw.TrainStep(rdr, [emb, neuconw, nerf], loss_fn, lr=1e-4 * world * R / 4096.0, eps=1e-7, clip=0.99,
+                         world_size=world)
     rays, ts, label, rgbs = synth_batch(R, 1000 + rank, dev)
     bg = torch.zeros(1, 3, device=dev)
 
     def step(i):
-        opt.zero_grad(set_to_none=True)
-        out = rdr.render(rays, ts, label, background_rgb=bg, cos_anneal_ratio=min(1.0, i / 50000.0))
-        loss = loss_fn(out, rgbs)
-        loss.backward()
-        if world > 1:
-            ddp.allreduce_grads(params, world, flat_buffers=[rdr.flat_grad_buffer()])
-        torch.nn.utils.clip_grad_norm_(params, 0.99)  # train.py:61
-        opt.step()
+        loss, _ = train(rays, ts, label, rgbs, background_rgb=bg, cos_anneal_ratio=min(1.0, i / 50000.0))
         return loss
 
     for i in range(args.warmup):

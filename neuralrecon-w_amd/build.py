@@ -9,8 +9,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "csrc", "build")
-LIB = os.path.join(HERE, "libneuconw_hip.so")
+# NCW_BUILD_TAG builds an experiment variant beside the product library (scripts/ only; lib.py loads it
+# when NEUCONW_HIP_LIB points at it)
+TAG = os.environ.get("NCW_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "csrc", "build" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(HERE, "libneuconw_hip%s.so" % ("_" + TAG if TAG else ""))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
 FLAGS += os.environ.get("NCW_EXTRA_HIPCC_FLAGS", "").split()

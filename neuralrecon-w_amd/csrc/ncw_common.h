@@ -170,6 +170,9 @@ NCW_DEV void ring_issue(ncw_lchar* lds_slot, const void* gsrc, int bytes) {
     const int lane = threadIdx.x & 63;
     const int pieces = (bytes + 1023) >> 10;
     const char* g0 = reinterpret_cast<const char*>(gsrc) + lane * 16;
+#ifdef NCW_EXP_NODMA  // timing experiment only: results are garbage
+    return;
+#endif
     for (int pc = wave; pc < pieces; pc += nw) {
         if (pc * 1024 + lane * 16 < bytes)
             __builtin_amdgcn_global_load_lds((ncw_gvoid*)(g0 + (size_t)pc * 1024), (ncw_lvoid*)(lds_slot + pc * 1024), 16,
@@ -254,7 +257,9 @@ NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename
     typedef typename std::conditional<P::id == NCW_PREC_F32, float, bf16x8>::type Frag;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
+#ifndef NCW_EXP_NOBAR  // timing experiment only
         __syncthreads();
+#endif
         if (c + 1 < NCH) {
             const int nu = (c + 2) * CU <= NU ? CU : NU - (c + 1) * CU;
             ring_issue(ring.slot(ring.cur ^ 1), reinterpret_cast<const char*>(wp) + (size_t)(c + 1) * CU * UB, nu * UB);

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libneuconw_hip.so")
+# NEUCONW_HIP_LIB: another build of the SAME library (experiment variants from build.py NCW_BUILD_TAG)
+LIB_PATH = os.environ.get("NEUCONW_HIP_LIB") or os.path.join(HERE, "libneuconw_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1

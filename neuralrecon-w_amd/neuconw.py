@@ -176,7 +176,10 @@ class SDFNetwork(nn.Module):
         return plan
 
     def _param_version(self):
-        return tuple(p._version for p in self.parameters())
+        # _ncw_version_srcs: base tensors whose in-place updates change these parameters without touching their
+        # own version counters (trainer.FlatParams re-seats p.data into one flat buffer)
+        return tuple(p._version for p in self.parameters()) + \
+            tuple(t._version for t in self.__dict__.get("_ncw_version_srcs", ()))
 
     def packed(self, prec):
         """Pack plan with weights up to date on the current stream."""
@@ -276,7 +279,10 @@ class _PackedNet(nn.Module):
         self._plans = {}
 
     def _param_version(self):
-        return tuple(p._version for p in self.parameters())
+        # _ncw_version_srcs: base tensors whose in-place updates change these parameters without touching their
+        # own version counters (trainer.FlatParams re-seats p.data into one flat buffer)
+        return tuple(p._version for p in self.parameters()) + \
+            tuple(t._version for t in self.__dict__.get("_ncw_version_srcs", ()))
 
     def _first_param(self):
         return next(self.parameters())

@@ -270,6 +270,18 @@ class NeuconWRenderer:
             self._gv = c = (key, flat, views)
         return c[1], c[2]
 
+    def adopt_grad_buffer(self, params, flat):
+        """Use `flat` (fp32, numel = sum of `params`) as the persistent flat gradient buffer: the trainer's
+        flat gradient storage (trainer.FlatParams) -- the weight-norm backward then writes straight into it."""
+        params = list(params)
+        assert [id(p) for p in params] == [id(p) for p in self._params()], "adopt_grad_buffer: parameter order"
+        assert flat.numel() == sum(p.numel() for p in params) and flat.dtype == torch.float32
+        views, off = {}, 0
+        for p in params:
+            views[id(p)] = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        self._gv = (tuple(id(p) for p in params), flat, views)
+
     def flat_grad_buffer(self):
         """The persistent flat gradient buffer of (sdf, colour, background) parameters, or None."""
         c = self.__dict__.get("_gv")

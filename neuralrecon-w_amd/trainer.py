@@ -1,0 +1,126 @@
+"""The optimiser side of the train step, laid out for one GPU per process.
+
+The reference's recipe (train.py:21-25,61; utils/__init__.py:23-31; neuconw_system.py:178-184) is
+`Adam(lr, eps=1e-7)` over embedding + NeuconW + NeRF, a global grad-norm clip of 0.99 and, under DDP, a
+gradient all-reduce.  With ~90 parameter tensors that is three passes of many small launches per step.
+Here every trainable parameter is RE-SEATED into one flat fp32 buffer and every `.grad` into one flat
+gradient buffer (the renderer writes its weight-norm backward straight into it, renderer.py `_grad_views`),
+so that per step there is ONE zero-fill, ONE all-reduce, ONE norm and ONE Adam update, with the same
+arithmetic per element as the stock optimiser.  `state_dict()` keys and shapes of the modules are unchanged
+(checkpoint format of utils/__init__.py:64-98); parameters stay ordinary `nn.Parameter`s.
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatParams:
+    """Flat parameter / gradient storage for `modules` (an iterable of nn.Module).
+
+    Order: the renderer's packed-network parameters first (their gradient slice is adopted by the renderer
+    as its persistent flat gradient buffer), then every remaining parameter in module order.  Parameters
+    that never receive a gradient (the reference's dead layers: NeuconW.xyz_encoding_final,
+    NeRF.views_linears) keep a zero gradient, for which Adam's update is exactly zero -- the same end state
+    as the stock optimiser skipping them."""
+
+    def __init__(self, modules, renderer=None):
+        modules = list(modules)
+        seen, params = set(), []
+        first = list(renderer._params()) if renderer is not None else []
+        for p in first + [p for m in modules for p in m.parameters()]:
+            if id(p) not in seen and p.requires_grad:
+                seen.add(id(p))
+                params.append(p)
+        if not params:
+            raise ValueError("no trainable parameters")
+        dev = params[0].device
+        for p in params:
+            if p.device != dev or p.dtype != torch.float32:
+                raise ValueError("FlatParams needs fp32 parameters on one device")
+        n = sum(p.numel() for p in params)
+        self.params = params
+        self.flat = torch.nn.Parameter(torch.empty(n, device=dev, dtype=torch.float32))
+        self.flat_grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat.grad = self.flat_grad
+        self.slices = {}
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                view = self.flat.data[off:off + k].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_grad[off:off + k].view(p.shape)
+                self.slices[id(p)] = (off, k)
+                off += k
+        # the packed-weight caches key on parameter version counters; updates now arrive through `flat`
+        for m in modules:
+            for sub in m.modules():
+                sub.__dict__["_ncw_version_srcs"] = sub.__dict__.get("_ncw_version_srcs", ()) + (self,)
+        self._epoch = 0
+        if renderer is not None and first:
+            nr = sum(p.numel() for p in first)
+            renderer.adopt_grad_buffer(first, self.flat_grad[:nr])
+        self.renderer = renderer
+
+    @property
+    def _version(self):
+        return (self.flat._version, self._epoch)
+
+    def mark_updated(self):
+        """Call after an optimiser step on `flat`: fused optimiser kernels do not bump tensor version
+        counters, and the packed-weight caches must see that the parameters changed."""
+        self._epoch += 1
+
+    def zero_grad(self):
+        """One fill; `.grad` tensors stay the same views (autograd and the renderer accumulate in place)."""
+        self.flat_grad.zero_()
+        for p in self.params:  # a foreign optimizer.zero_grad(set_to_none=True) would have dropped the views
+            if p.grad is None:
+                off, k = self.slices[id(p)]
+                p.grad = self.flat_grad[off:off + k].view(p.shape)
+
+    def allreduce(self, world_size=None, group=None):
+        """Mean of the flat gradient over ranks: one RCCL all-reduce over xGMI, in place."""
+        if not dist.is_available() or not dist.is_initialized():
+            return
+        world_size = dist.get_world_size(group) if world_size is None else world_size
+        if world_size == 1:
+            return
+        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
+        self.flat_grad.div_(world_size)
+
+    def broadcast(self, src=0, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast(self.flat.data, src=src, group=group)
+
+
+class TrainStep:
+    """render -> loss -> backward -> all-reduce -> clip -> Adam, the timed region of SURVEY 8(d).
+
+    loss_fn(outputs, targets) -> scalar is the user's (NeuconWLoss, losses.py:21-43)."""
+
+    def __init__(self, renderer, modules, loss_fn, lr, eps=1e-7, betas=(0.9, 0.999), clip=0.99, world_size=1,
+                 group=None):
+        self.renderer, self.loss_fn, self.clip = renderer, loss_fn, clip
+        self.world_size, self.group = world_size, group
+        self.fp = FlatParams(modules, renderer)
+        self.fp.broadcast(group=group)
+        kw = dict(lr=lr, eps=eps, betas=betas)
+        try:
+            self.opt = torch.optim.Adam([self.fp.flat], fused=True, **kw)
+        except (RuntimeError, TypeError, ValueError):
+            self.opt = torch.optim.Adam([self.fp.flat], **kw)
+
+    def __call__(self, rays, ts, label, targets, background_rgb=None, cos_anneal_ratio=0.0, **render_kw):
+        fp = self.fp
+        fp.zero_grad()
+        out = self.renderer.render(rays, ts, label, background_rgb=background_rgb,
+                                   cos_anneal_ratio=cos_anneal_ratio, **render_kw)
+        loss = self.loss_fn(out, targets)
+        loss.backward()
+        fp.allreduce(self.world_size, self.group)
+        if self.clip is not None:
+            torch.nn.utils.clip_grad_norm_([fp.flat], self.clip)  # train.py:61
+        self.opt.step()
+        fp.mark_updated()
+        return loss, out

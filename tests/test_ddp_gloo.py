@@ -70,3 +70,49 @@ def test_allreduce_grads_world2():
     for a, b, m0, m1 in zip(l0, l1, g0, g1):
         assert torch.allclose(T(m0), (T(a) + T(b)) / 2) and torch.equal(T(m0), T(m1))
     assert all(d0) and all(d1)
+
+
+def _worker_flat(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from neuralrecon_w_amd.trainer import FlatParams
+
+    torch.manual_seed(rank)  # replicas start different: FlatParams.broadcast makes them rank 0's
+    lin, emb = torch.nn.Linear(5, 3), torch.nn.Embedding(6, 2)
+    fp = FlatParams([emb, lin])
+    fp.broadcast()
+    opt = torch.optim.Adam([fp.flat], lr=1e-2, eps=1e-7)
+    g = torch.Generator().manual_seed(100 + rank)  # each rank owns its shard of the batch
+    for _ in range(2):
+        x, idx = torch.randn(4, 5, generator=g), torch.randint(0, 6, (3,), generator=g)
+        fp.zero_grad()
+        (lin(x).sum() + emb(idx).pow(2).sum()).backward()
+        local = fp.flat_grad.clone()
+        fp.allreduce()
+        torch.nn.utils.clip_grad_norm_([fp.flat], 0.99)
+        opt.step()
+    q.put((rank, fp.flat.detach().tolist(), local.tolist(), fp.flat_grad.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_train_step_world2():
+    """The trainer's exchange: ONE all-reduce of the flat gradient, replicas stay bit-identical."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_flat, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, l0, g0), (_, w1, l1, g1) = res
+    T = torch.tensor
+    assert torch.equal(T(w0), T(w1))
+    assert torch.equal(T(g0), T(g1))
+    assert not torch.equal(T(l0), T(l1))  # the shards really differed
