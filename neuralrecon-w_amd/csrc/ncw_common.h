@@ -362,6 +362,11 @@ NCW_DEV void load_bias(CVec<RB>& acc, const float* __restrict__ bp, int lane) {
 // sigma(100 z) (exactly 1 above the threshold).  FAST selects hardware exp2/log2.
 template <bool FAST>
 NCW_DEV void softplus100(float z, float& y, float& s) {
+#ifdef NCW_EXP_NOSP  // timing experiment only: no transcendental epilogue
+    y = __builtin_fmaxf(z, 0.f);
+    s = 0.5f;
+    return;
+#endif
     if (FAST) {
         // overflow-free form, 6 VALU ops (2 transcendental) for y and 3 more (1 transcendental) for s:
         //   w = exp(-|100 z|) in (0,1];  y = max(z,0) + log(1+w)/100;  s = 1 - exp(-100 y)  (== sigmoid(100 z)).
@@ -468,6 +473,9 @@ NCW_DEV void freq_encode(CVec<RB>& out, const float (&x)[D], int lane) {
 // ---------------------------------------------------------------------------------------------
 template <int RB>
 NCW_DEV void stash_store(float* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
+#ifdef NCW_EXP_NOSTASH  // timing experiment only
+    return;
+#endif
     f32x4* p = reinterpret_cast<f32x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -481,6 +489,9 @@ NCW_DEV void stash_store(float* __restrict__ base, size_t tile, const CVec<RB>& 
 }
 template <int RB>
 NCW_DEV void stash_store(__bf16* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
+#ifdef NCW_EXP_NOSTASH  // timing experiment only
+    return;
+#endif
     bf16x4* p = reinterpret_cast<bf16x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
