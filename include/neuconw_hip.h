@@ -329,6 +329,8 @@ typedef struct NcwCompositeIn {
     const float* bg_rgb;       /* [R,S+O,3] or NULL                               */
     const float* inv_s;        /* [1] device scalar exp(10 variance)              */
     const float* background_rgb; /* [3] or NULL                                   */
+    const float* cos_anneal_dev; /* [1] device scalar or NULL: when set it replaces cos_anneal (so that a
+                                    captured HIP graph of the step can be replayed with a new ratio)  */
     float cos_anneal;
     int32_t R, S, O, has_bg, trim_sphere;
 } NcwCompositeIn;

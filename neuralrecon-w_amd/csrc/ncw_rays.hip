@@ -239,6 +239,7 @@ __global__ void boundary_kernel(const float* __restrict__ near, const float* __r
 struct CompArgs {
     const float *rays_o, *rays_d, *z, *z_feed, *sample_dist, *sdf, *grad, *rgb, *density, *bg_rgb, *inv_s;
     const float* background_rgb;  // [3] or null
+    const float* cos_anneal_dev;  // [1] or null
     float cos_anneal;
     int R, S, O, has_bg, trim_sphere;
 };
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs A, CompOut 
         const size_t q = (size_t)r * S + i;
         const float gx = A.grad[q * 3], gy = A.grad[q * 3 + 1], gz = A.grad[q * 3 + 2];
         const float tc = dx * gx + dy * gy + dz * gz;
-        const float ic = iter_cos_of(tc, A.cos_anneal);
+        const float ic = iter_cos_of(tc, A.cos_anneal_dev ? A.cos_anneal_dev[0] : A.cos_anneal);
         const float sd = A.sdf[q];
         const float en = sd + ic * dist * 0.5f, ep = sd - ic * dist * 0.5f;
         const float pc = sigmoid_acc(ep * inv_s), nc = sigmoid_acc(en * inv_s);
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs A, CompBwd 
     float* dal0 = sm[wv][4];  // accumulates dL/d alpha0
     const float ox = A.rays_o[r * 3], oy = A.rays_o[r * 3 + 1], oz = A.rays_o[r * 3 + 2];
     const float dx = A.rays_d[r * 3], dy = A.rays_d[r * 3 + 1], dz = A.rays_d[r * 3 + 2];
-    const float inv_s = A.inv_s[0], sdist = A.sample_dist[r], c = A.cos_anneal;
+    const float inv_s = A.inv_s[0], sdist = A.sample_dist[r], c = A.cos_anneal_dev ? A.cos_anneal_dev[0] : A.cos_anneal;
     const float* zr = A.z + (size_t)r * S;
     const float dcr = G.d_color[r * 3], dcg = G.d_color[r * 3 + 1], dcb = G.d_color[r * 3 + 2];
     float dws = G.d_wsum[r];
@@ -659,7 +660,7 @@ extern "C" int ncw_composite_fwd(const NcwCompositeIn* in, const NcwCompositeOut
     CompArgs A;
     A.rays_o = in->rays_o; A.rays_d = in->rays_d; A.z = in->z; A.z_feed = in->z_feed; A.sample_dist = in->sample_dist;
     A.sdf = in->sdf; A.grad = in->grad; A.rgb = in->rgb; A.density = in->density; A.bg_rgb = in->bg_rgb;
-    A.inv_s = in->inv_s; A.background_rgb = in->background_rgb; A.cos_anneal = in->cos_anneal;
+    A.inv_s = in->inv_s; A.background_rgb = in->background_rgb; A.cos_anneal = in->cos_anneal; A.cos_anneal_dev = in->cos_anneal_dev;
     A.R = in->R; A.S = in->S; A.O = in->O; A.has_bg = in->has_bg; A.trim_sphere = in->trim_sphere;
     CompOut Q;
     Q.color = out->color; Q.color_sphere = out->color_sphere; Q.color_bg = out->color_bg; Q.weights = out->weights;
@@ -678,7 +679,7 @@ extern "C" int ncw_composite_bwd(const NcwCompositeIn* in, const NcwCompositeGra
     CompArgs A;
     A.rays_o = in->rays_o; A.rays_d = in->rays_d; A.z = in->z; A.z_feed = in->z_feed; A.sample_dist = in->sample_dist;
     A.sdf = in->sdf; A.grad = in->grad; A.rgb = in->rgb; A.density = in->density; A.bg_rgb = in->bg_rgb;
-    A.inv_s = in->inv_s; A.background_rgb = in->background_rgb; A.cos_anneal = in->cos_anneal;
+    A.inv_s = in->inv_s; A.background_rgb = in->background_rgb; A.cos_anneal = in->cos_anneal; A.cos_anneal_dev = in->cos_anneal_dev;
     A.R = in->R; A.S = in->S; A.O = in->O; A.has_bg = in->has_bg; A.trim_sphere = in->trim_sphere;
     CompBwd G;
     G.d_color = g->d_color; G.d_wsum = g->d_weights_sum; G.d_depth = g->d_depth; G.d_eik = g->d_eik_num;

@@ -105,7 +105,7 @@ def _ptr_struct(name, fields_ptr, fields_other=()):
 NcwCompositeIn = _ptr_struct(
     "NcwCompositeIn",
     ["rays_o", "rays_d", "z", "z_feed", "sample_dist", "sdf", "grad", "rgb", "density", "bg_rgb", "inv_s",
-     "background_rgb"],
+     "background_rgb", "cos_anneal_dev"],
     [("cos_anneal", C.c_float), ("R", C.c_int32), ("S", C.c_int32), ("O", C.c_int32), ("has_bg", C.c_int32),
      ("trim_sphere", C.c_int32)],
 )

@@ -85,10 +85,12 @@ class CompositeCtx:
                       density=_f(density) if self.has_bg else None, bg_rgb=_f(bg_rgb) if self.has_bg else None,
                       inv_s=_f(inv_s).reshape(1),
                       background_rgb=_f(background_rgb).reshape(3) if background_rgb is not None else None)
+        # cos_anneal: python float, or a 1-element device tensor (read by the kernels at run time: graph replay)
+        self.t["cos_anneal_dev"] = _f(cos_anneal).reshape(1) if torch.is_tensor(cos_anneal) else None
         s = L.NcwCompositeIn()
         for k, v in self.t.items():
             setattr(s, k, v.data_ptr() if v is not None else 0)
-        s.cos_anneal = float(cos_anneal)
+        s.cos_anneal = 0.0 if torch.is_tensor(cos_anneal) else float(cos_anneal)
         s.R, s.S, s.O, s.has_bg, s.trim_sphere = self.R, self.S, self.O, int(self.has_bg), int(bool(trim_sphere))
         self.cin = s
 

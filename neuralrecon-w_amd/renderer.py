@@ -316,7 +316,8 @@ class NeuconWRenderer:
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
         n_samples, z_vals, z_vals_outside, sample_dist = self.sparse_sampler(rays_o, rays_d, near, far, perturb, _rand)
         bgc = background_rgb.reshape(-1)[:3] if background_rgb is not None else None
-        outs = _RenderFn.apply(self, rays_o, rays_d, z_vals, z_vals_outside, sample_dist, float(cos_anneal_ratio), bgc,
+        outs = _RenderFn.apply(self, rays_o, rays_d, z_vals, z_vals_outside, sample_dist,
+                               cos_anneal_ratio if torch.is_tensor(cos_anneal_ratio) else float(cos_anneal_ratio), bgc,
                                a_embedded, self.neuconw.deviation_network.variance, *self._params())
         (color, wsum, depth, eik_num, color_sphere, color_bg, weights, cdf, inside, normals, sdf, gradients, mid_z,
          dists, eik_den, inv_s) = outs

@@ -97,30 +97,106 @@ class FlatParams:
 class TrainStep:
     """render -> loss -> backward -> all-reduce -> clip -> Adam, the timed region of SURVEY 8(d).
 
-    loss_fn(outputs, targets) -> scalar is the user's (NeuconWLoss, losses.py:21-43)."""
+    loss_fn(outputs, targets) -> scalar is the user's (NeuconWLoss, losses.py:21-43).
+
+    capture=True records the step ONCE into HIP graphs (torch.cuda.CUDAGraph) after `capture_warmup` eager
+    steps and replays it afterwards: the ~130 launches of a step (C-ABI kernels, the loss' elementwise ops,
+    autograd, clip, fused Adam) are submitted as one graph launch, which removes the host-side launch gaps
+    of this launch-bound tail.  Everything that varies between steps is device data: the batch is copied
+    into static buffers, `cos_anneal_ratio` is a device scalar read by the compositor kernels, Adam's step
+    counter is a device tensor (capturable=True), the sampler's jitter comes from torch's graph-safe Philox
+    state.  Requirements: fixed batch shape, a loss_fn without host syncs, renderer.sync_free (set here).
+    With world_size > 1 the gradient all-reduce stays an eager RCCL call between two graphs."""
 
     def __init__(self, renderer, modules, loss_fn, lr, eps=1e-7, betas=(0.9, 0.999), clip=0.99, world_size=1,
-                 group=None):
+                 group=None, capture=False, capture_warmup=3):
         self.renderer, self.loss_fn, self.clip = renderer, loss_fn, clip
         self.world_size, self.group = world_size, group
+        self.capture, self.capture_warmup = bool(capture), int(capture_warmup)
+        self._n_eager, self._graphs, self._static = 0, None, None
         self.fp = FlatParams(modules, renderer)
         self.fp.broadcast(group=group)
         kw = dict(lr=lr, eps=eps, betas=betas)
+        if self.capture:
+            renderer.sync_free = True
+            kw["capturable"] = True
         try:
             self.opt = torch.optim.Adam([self.fp.flat], fused=True, **kw)
         except (RuntimeError, TypeError, ValueError):
             self.opt = torch.optim.Adam([self.fp.flat], **kw)
 
-    def __call__(self, rays, ts, label, targets, background_rgb=None, cos_anneal_ratio=0.0, **render_kw):
-        fp = self.fp
-        fp.zero_grad()
+    # ---- the two halves of a step (the all-reduce sits between them) ---------------------------------
+    def _fwd_bwd(self, rays, ts, label, targets, background_rgb, cos_anneal_ratio, render_kw):
+        self.fp.zero_grad()
         out = self.renderer.render(rays, ts, label, background_rgb=background_rgb,
                                    cos_anneal_ratio=cos_anneal_ratio, **render_kw)
         loss = self.loss_fn(out, targets)
         loss.backward()
-        fp.allreduce(self.world_size, self.group)
-        if self.clip is not None:
-            torch.nn.utils.clip_grad_norm_([fp.flat], self.clip)  # train.py:61
-        self.opt.step()
-        fp.mark_updated()
         return loss, out
+
+    def _update(self):
+        if self.clip is not None:
+            torch.nn.utils.clip_grad_norm_([self.fp.flat], self.clip)  # train.py:61
+        self.opt.step()
+        self.fp.mark_updated()
+
+    def eager_step(self, rays, ts, label, targets, background_rgb=None, cos_anneal_ratio=0.0, **render_kw):
+        loss, out = self._fwd_bwd(rays, ts, label, targets, background_rgb, cos_anneal_ratio, render_kw)
+        self.fp.allreduce(self.world_size, self.group)
+        self._update()
+        return loss, out
+
+    # ---- graph capture ---------------------------------------------------------------------------
+    def _capture(self, rays, ts, label, targets, background_rgb, render_kw):
+        dev = rays.device
+        st = dict(rays=rays.clone(), ts=ts.clone(), label=label.clone(), targets=targets.clone(),
+                  bg=None if background_rgb is None else background_rgb.clone(),
+                  cos=torch.zeros(1, device=dev, dtype=torch.float32))
+        self._render_kw = dict(render_kw)
+        torch.cuda.synchronize(dev)
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            loss, out = self._fwd_bwd(st["rays"], st["ts"], st["label"], st["targets"], st["bg"], st["cos"],
+                                      self._render_kw)
+            if self.world_size == 1:
+                self._update()
+        g2 = None
+        if self.world_size > 1:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._update()
+        st["loss"], st["out"] = loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+        self._graphs, self._static = (g1, g2), st
+
+    def __call__(self, rays, ts, label, targets, background_rgb=None, cos_anneal_ratio=0.0, **render_kw):
+        if not self.capture:
+            return self.eager_step(rays, ts, label, targets, background_rgb, cos_anneal_ratio, **render_kw)
+        if self._graphs is None:
+            if self._n_eager < self.capture_warmup:  # arenas, descriptor tables and Adam state must exist first
+                self._n_eager += 1
+                loss, out = self.eager_step(rays, ts, label, targets, background_rgb, cos_anneal_ratio, **render_kw)
+                # detached, like the replays: an autograd graph of an eager step that is still alive at capture
+                # time keeps its AccumulateGrad nodes (bound to the eager stream) in use, and the engine then
+                # synchronises the capturing stream with that stream -- hipStreamEndCapture crashes on it
+                return loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+            import gc
+            gc.collect()
+            self._capture(rays, ts, label, targets, background_rgb, render_kw)
+            # the capture pass itself does not execute anything: fall through and replay this step
+        st = self._static
+        if dict(render_kw) != self._render_kw or rays.shape != st["rays"].shape:
+            raise ValueError("captured TrainStep: batch shape and render keywords are fixed at capture time")
+        st["rays"].copy_(rays, non_blocking=True)
+        st["ts"].copy_(ts, non_blocking=True)
+        st["label"].copy_(label, non_blocking=True)
+        st["targets"].copy_(targets, non_blocking=True)
+        if st["bg"] is not None:
+            st["bg"].copy_(background_rgb, non_blocking=True)
+        st["cos"].fill_(float(cos_anneal_ratio))
+        g1, g2 = self._graphs
+        g1.replay()
+        if g2 is not None:
+            self.fp.allreduce(self.world_size, self.group)
+            g2.replay()
+        self.fp._epoch += 1
+        return st["loss"], st["out"]

@@ -46,3 +46,40 @@ def test_train_step_matches_per_tensor_recipe():
     pa, pb = named_params(emb, neuconw, nerf), named_params(emb2, neuconw2, nerf2)
     worst = max(float((pa[k] - pb[k]).abs().max()) for k in pa)
     assert worst < 2e-5, worst  # 4 Adam steps of lr 1e-3: any bookkeeping error would show at 1e-3
+
+
+def test_captured_step_replays_like_eager():
+    """TrainStep(capture=True): HIP-graph replay of the whole step follows the eager step, including the
+    per-step cos_anneal_ratio (a device scalar inside the graph) and Adam's bias correction."""
+    import neuralrecon_w_amd as nw
+
+    R, steps = 64, 7
+    rays, ts, label, rgbs = [t.cuda() for t in synth_rays(R, seed=12, n_vocab=64)]
+    bg = torch.zeros(1, 3, device="cuda")
+    runs = []
+    for capture in (False, True):
+        emb, neuconw, nerf, rdr = build_system(seed=6, prec=nw.PREC_F32)
+        rdr.sync_free = True
+        train = nw.TrainStep(rdr, [emb, neuconw, nerf], loss_from_outputs, lr=1e-3, eps=1e-7, clip=0.99,
+                             capture=capture, capture_warmup=3)
+        losses = []
+        for i in range(steps):
+            loss, out = train(rays, ts, label, rgbs, background_rgb=bg, cos_anneal_ratio=0.15 * i,
+                              perturb_overwrite=0)
+            losses.append(float(loss))
+        if capture:
+            assert train._graphs is not None  # steps 3.. were graph replays
+        nstep = float(train.opt.state[train.fp.flat]["step"])
+        runs.append((losses, named_params(emb, neuconw, nerf), float(out["color"].abs().sum()), nstep))
+    (la, pa, ca, na), (lb, pb, cb, nb) = runs
+    assert na == nb == steps  # Adam's bias correction advanced once per replay
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (la, lb)
+    assert la[0] != la[-1]
+    # the weight-gradient atomics are order-dependent in the last bit and Adam turns a sign flip of a ~0 gradient
+    # into a +-lr step, so single elements may differ by a fraction of lr; a bookkeeping error (stale weights,
+    # wrong step count: >= 16 % of every update) would move ALL elements
+    diffs = torch.cat([(pa[k] - pb[k]).abs().reshape(-1) for k in pa])
+    assert float(diffs.max()) < 1e-3, float(diffs.max())
+    assert float((diffs > 2e-5).float().mean()) < 2e-3, float((diffs > 2e-5).float().mean())
+    assert abs(ca - cb) <= 1e-4 * max(1.0, abs(ca))
