@@ -66,3 +66,110 @@ def get_near_far(rays_o_sfm, rays_d, octree_data):
                                                L.ptr(octree_data["brick"]), L.ptr(near), L.ptr(far),
                                                L.stream_ptr(dev)), "ncw_ray_voxel_near_far")
     return near.reshape(R, 1), far.reshape(R, 1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Octree refresh on the device (SURVEY 8f N1): lightning_modules/neuconw_system.py:186-312
+# (`surface_selection`, `octree_update`).  The reference bounces through the CPU (dense grid, nonzero,
+# repeat_interleave, chunked sdf calls with .cpu() per chunk, numpy, kaolin); here the occupied coarse voxels
+# are expanded, swept with the fused SDF kernel and re-voxelised without leaving the GPU.
+# ---------------------------------------------------------------------------------------------------
+def dense_from_occupancy(octree_data):
+    """[G,G,G] bool (x slowest) from the bit mask: generate_voxel.py:181-186 `convert_to_dense`."""
+    G = 1 << int(octree_data["level"])
+    occ = octree_data["occ"]
+    bits = (occ.view(-1, 1) >> torch.arange(32, device=occ.device, dtype=torch.int32).view(1, 32)) & 1
+    return bits.reshape(-1)[: G * G * G].bool().view(G, G, G)
+
+
+def shard_range(total, rank, world):
+    """utils/visualization.py:27-35 `get_local_split`: pad to a multiple of world (a whole extra row per rank
+    when not divisible), contiguous equal slices.  Returns (start, valid_count, padded_slice_length)."""
+    padded = total if total % world == 0 else (total // world + 1) * world
+    per = padded // world
+    start = rank * per
+    return start, max(0, min(per, total - start)), per
+
+
+def _sdf_sharded(renderer, xyz_training, chunk, group=None):
+    """renderer.sdf over all points; with torch.distributed initialised each rank sweeps its slice and ONE
+    all_gather assembles the result (neuconw_system.py:236-256)."""
+    import torch.distributed as dist
+
+    n = xyz_training.shape[0]
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    start, count, per = shard_range(n, rank, world)
+    local = torch.zeros(per, device=xyz_training.device, dtype=torch.float32)
+    for i in range(0, count, chunk):
+        j = min(count, i + chunk)
+        local[i:j] = renderer.sdf(xyz_training[start + i:start + j].reshape(-1, 1, 3)).reshape(-1)
+    if world == 1:
+        return local[:n]
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local, group=group)
+    return torch.cat(parts)[:n]
+
+
+@torch.no_grad()
+def surface_selection(renderer, train_level, threshold, chunk=1 << 22, group=None):
+    """neuconw_system.py:186-264.  Returns (points_sfm [K,3] float32 on the GPU: the lower corners of the
+    level-`train_level` sub-voxels of the occupied coarse voxels whose sdf <= threshold; train_voxel_size).
+    Same arithmetic and operation order as the reference (float32 `ind * voxel + origin`), so the selected
+    set is the reference's up to sdf rounding at the threshold."""
+    od = renderer.octree_data
+    if od is None:
+        od = renderer.octree_data = renderer.get_octree(renderer.origin.device)
+    dev = od["occ"].device
+    level = int(od["level"])
+    octree_origin = od["scene_origin"].float().to(dev).reshape(3)
+    octree_scale = float(od["scale"])
+    dense = dense_from_occupancy(od)
+    sparse_ind = torch.nonzero(dense)  # [n,3], lexicographic in (x,y,z) like the reference
+    up_times = 2 ** (int(train_level) - level)
+    if up_times < 1:
+        raise ValueError("train_level below the octree level")
+    k = torch.arange(0, up_times, device=dev)
+    up_kernel = torch.stack(torch.meshgrid(k, k, k, indexing="ij"), dim=-1).reshape(-1, 3)
+    ind_up = (sparse_ind.repeat_interleave(up_times ** 3, dim=0) * up_times
+              + up_kernel.repeat([sparse_ind.shape[0], 1]))
+    train_voxel_size = 2 / (2 ** int(train_level)) * octree_scale
+    vol_origin = octree_origin - octree_scale
+    xyz_sfm = ind_up * train_voxel_size + vol_origin          # int64 * python float -> float32, then + float32
+    scene_origin = renderer.origin.float().to(dev).reshape(3)
+    xyz_training = (xyz_sfm - scene_origin) / renderer.radius
+    sdf = _sdf_sharded(renderer, xyz_training.contiguous(), int(chunk), group)
+    return xyz_sfm[sdf <= threshold], train_voxel_size
+
+
+@torch.no_grad()
+def octree_from_points(points_sfm, voxel_size, scene_origin, scale):
+    """generate_voxel.py:75-171 `gen_octree(expand=False)` for points already in SfM space: normalise into the
+    cube, keep the points STRICTLY inside (-1,1)^3, level = floor(log2(2 scale / voxel_size)), quantise with
+    kaolin's documented rule floor(clamp(2^level (x+1)/2, 0, 2^level - 1)) -- all in float64 as numpy does.
+    The kaolin octree/SPC tensors are replaced by the dense bit mask the ray kernel reads."""
+    dev = points_sfm.device
+    origin64 = torch.as_tensor(scene_origin, dtype=torch.float64, device=dev).reshape(3)
+    level = int(math.floor(math.log2(2 * float(scale) / float(voxel_size))))
+    if not 3 <= level <= 10:
+        raise ValueError("octree level %d outside the supported 3..10" % level)
+    pn = (points_sfm.double() - origin64) / float(scale)
+    inside = (pn > -1).all(-1) & (pn < 1).all(-1)
+    res = 2 ** level
+    q = torch.floor(torch.clamp(res * (pn[inside] + 1.0) / 2.0, 0, res - 1.0)).long()
+    centres = ((q.float() + 0.5) * (2.0 / res) - 1.0)          # voxel centres quantise back to q exactly
+    data = occupancy_from_points(centres * float(scale) + origin64.float(), origin64.float(), float(scale), level,
+                                 voxel_size)
+    return data
+
+
+@torch.no_grad()
+def octree_update(renderer, train_level, threshold, chunk=1 << 22, group=None):
+    """neuconw_system.py:266-312: rebuild renderer.fine_octree_data from the current SDF."""
+    renderer.fine_octree_data = None
+    pts, train_voxel_size = surface_selection(renderer, train_level, threshold, chunk, group)
+    od = renderer.octree_data
+    data = octree_from_points(pts, train_voxel_size, od["scene_origin"], od["scale"])
+    data["voxel_size"] = train_voxel_size
+    renderer.fine_octree_data = data
+    return data
