@@ -173,14 +173,16 @@ typedef short ncw_s16x8 __attribute__((ext_vector_type(8)));
 // group touches on disjoint banks.  Only DMA ops use vmcnt inside the loop, so the waits are counted
 // (s_waitcnt vmcnt(16): two younger tiles stay in flight) around a raw s_barrier.
 // ------------------------------------------------------------------------------------------------
-template <int XB, int YB>
+#ifndef NCW_WGRAD_NBUF
+#define NCW_WGRAD_NBUF 4
+#endif
+template <int XB, int YB, int NBUF>
 __global__ __launch_bounds__(256) void wgrad_dma_kernel(const NcwWgradDesc* __restrict__ descs,
                                                         const int32_t* __restrict__ prefix, int n_desc, int ksplit,
                                                         int64_t ntiles) {
     constexpr int WI = XB / 2, WJ = YB / 2;
     constexpr int NBLK = XB + YB;
     constexpr int BUF = NBLK * 2048;          // one tile of all blocks
-    constexpr int NBUF = 4;
     constexpr int PPW = NBLK * 2 / 4;         // 1 KiB pieces per wave per tile
     __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF];
     const int d = wg_find(prefix, n_desc, blockIdx.x);
@@ -259,16 +261,15 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const NcwWgradDesc* __re
         return __builtin_bit_cast(bf16x8, w);
     };
     // ---- pipeline -------------------------------------------------------------------------------------
-    issue_tile(t_begin + 0, 0);
-    issue_tile(t_begin + 1, 1);
-    issue_tile(t_begin + 2, 2);
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) issue_tile(t_begin + i, i);
     int bufi = 0;
     for (int64_t t = t_begin; t < t_end; ++t) {
-        // tiles t, t+1, t+2 are in flight (PPW DMA ops each, issued in that order): retire tile t only
-        if (PPW == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        // tiles t .. t+NBUF-2 are in flight (PPW DMA ops each, issued in that order): retire tile t only
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PPW) : "memory");
         __builtin_amdgcn_s_barrier();
-        issue_tile(t + 3, (bufi + 3) & 3);  // the buffer read in the previous iteration (everyone passed the barrier)
+        // refill the buffer read in the previous iteration (everyone passed the barrier)
+        issue_tile(t + NBUF - 1, bufi == 0 ? NBUF - 1 : bufi - 1);
         const ncw_lchar* bufp = (const ncw_lchar*)lds + bufi * BUF;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const NcwWgradDesc* __re
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
             }
         }
-        bufi = (bufi + 1) & 3;
+        bufi = bufi + 1 == NBUF ? 0 : bufi + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy tail loads before LDS goes away
     // ---- epilogue ---------------------------------------------------------------------------------------
@@ -327,9 +328,9 @@ extern "C" int ncw_wgrad_tiled(const NcwWgradDesc* descs, const int32_t* wg_pref
     const int64_t ntiles = (n_points + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (tile == 0)
-        hipLaunchKernelGGL((wgrad_dma_kernel<4, 8>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+        hipLaunchKernelGGL((wgrad_dma_kernel<4, 8, 4>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
     else
-        hipLaunchKernelGGL((wgrad_dma_kernel<8, 8>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+        hipLaunchKernelGGL((wgrad_dma_kernel<8, 8, NCW_WGRAD_NBUF>), dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
     NCW_CHECK_LAUNCH();
     return 0;
 }
