@@ -200,3 +200,41 @@ class TrainStep:
             g2.replay()
         self.fp._epoch += 1
         return st["loss"], st["out"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# Checkpoint I/O in the reference's format.  The reference saves PyTorch-Lightning checkpoints
+# whose `state_dict` holds `embedding_a.*`, `neuconw.*`, `nerf.*` (train.py:32-38, neuconw_system.py:376-400)
+# and reads them back by prefix (utils/__init__.py:64-98 `extract_model_state_dict` / `load_ckpt`, used by
+# tools/extract_mesh.py:130-134).  These two functions write / read exactly that layout, so checkpoints move
+# between the reference and this package in both directions.
+# ---------------------------------------------------------------------------------------------------
+def save_checkpoint(path, embedding_a, neuconw, nerf, optimizer=None, global_step=0, extra=None):
+    """Writes {'state_dict': {prefix.key: tensor}, 'global_step': ..., ['optimizer_states': [...]]}."""
+    sd = {}
+    for prefix, mod in (("embedding_a", embedding_a), ("neuconw", neuconw), ("nerf", nerf)):
+        for k, v in mod.state_dict().items():
+            sd[prefix + "." + k] = v.detach().cpu().clone()   # clone: parameters may be views of the flat buffer
+    ckpt = {"state_dict": sd, "global_step": int(global_step)}
+    if optimizer is not None:
+        ckpt["optimizer_states"] = [optimizer.state_dict()]
+    if extra:
+        ckpt.update(extra)
+    torch.save(ckpt, path)
+    return ckpt
+
+
+def load_checkpoint(path, embedding_a=None, neuconw=None, nerf=None, strict=True, flat_params=None):
+    """The reference's load_ckpt (utils/__init__.py:79-98) for the three modules at once.  With `flat_params`
+    (trainer.FlatParams) the packed-weight caches are told that the parameters changed."""
+    ckpt = torch.load(path, map_location="cpu")
+    sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt  # a PL checkpoint or a bare state_dict
+    for prefix, mod in (("embedding_a", embedding_a), ("neuconw", neuconw), ("nerf", nerf)):
+        if mod is None:
+            continue
+        sub = {k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + ".")}
+        with torch.no_grad():
+            mod.load_state_dict(sub, strict=strict)  # copies INTO the existing storage (flat views stay views)
+    if flat_params is not None:
+        flat_params.mark_updated()
+    return ckpt
