@@ -27,45 +27,47 @@ __device__ __forceinline__ int find_desc(const int32_t* __restrict__ prefix, int
     return lo;
 }
 
-__device__ __forceinline__ float block_sum_256(float v, float* sm) {
+__device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm[w] = v;
-    __syncthreads();
-    return sm[0] + sm[1] + sm[2] + sm[3];
+    return v;
 }
 
+// One WAVE per matrix row (4 rows per workgroup): the row norm is a wave reduction, no LDS, no barriers.
 __global__ __launch_bounds__(256) void pack_kernel(const NcwPackDesc* __restrict__ descs,
-                                                   const int32_t* __restrict__ prefix, int n) {
-    __shared__ float sm[4];
-    const int d = find_desc(prefix, n, blockIdx.x);
-    const NcwPackDesc D = descs[d];
-    const int i = blockIdx.x - prefix[d];  // row within the descriptor
+                                                   const int32_t* __restrict__ prefix, int n, int total_rows) {
+    const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (grow >= total_rows) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int d = find_desc(prefix, n, grow);
+    const NcwPackDesc& D = descs[d];
+    const int i = grow - prefix[d];  // row within the descriptor
     const int row = D.row0 + i;
-    const float* srow = D.src + (size_t)row * D.ld;
+    const int ld = D.ld;
+    const float* srow = D.src + (size_t)row * ld;
     float coef = D.scale;
     if (D.g != nullptr) {
         float ss = 0.f;
-        for (int c = threadIdx.x; c < D.ld; c += 256) ss += srow[c] * srow[c];
-        ss = block_sum_256(ss, sm);
+        for (int c = lane; c < ld; c += 64) ss += srow[c] * srow[c];
+        ss = wave_sum(ss);
         coef *= D.g[row] / sqrtf(ss);
     }
     const int o_log = D.drow0 + i;
+    const int rb_out = D.rb_out, prec = D.prec, transpose = D.transpose;
+    void* dst_w = D.dst_w;
     for (int s = 0; s < D.nseg; ++s) {
         const NcwSeg sg = D.seg[s];
-        for (int c = threadIdx.x; c < sg.ncols; c += 256) {
+        for (int c = lane; c < sg.ncols; c += 64) {
             const float v = srow[sg.col0 + c] * coef;
             const int k_log = sg.dcol0 + c;
-            const int o = D.transpose ? k_log : o_log;
-            const int k = D.transpose ? o_log : k_log;
-            const size_t idx = packed_index(o, k, D.rb_out, D.prec);
-            if (D.prec == NCW_PREC_F32) reinterpret_cast<float*>(D.dst_w)[idx] = v;
-            else reinterpret_cast<__bf16*>(D.dst_w)[idx] = (__bf16)v;
+            const int o = transpose ? k_log : o_log;
+            const int k = transpose ? o_log : k_log;
+            const size_t idx = packed_index(o, k, rb_out, prec);
+            if (prec == NCW_PREC_F32) reinterpret_cast<float*>(dst_w)[idx] = v;
+            else reinterpret_cast<__bf16*>(dst_w)[idx] = (__bf16)v;
         }
     }
-    if (D.dst_b != nullptr && D.bias != nullptr && threadIdx.x == 0) {
+    if (D.dst_b != nullptr && D.bias != nullptr && lane == 0) {
         // packed bias [rb][h][16]: feature f = 32 rb + (r&3) + 8 (r>>2) + 4 h
         const int f = o_log, rb = f >> 5, kk = f & 31;
         const int h = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
@@ -74,22 +76,26 @@ __global__ __launch_bounds__(256) void pack_kernel(const NcwPackDesc* __restrict
 }
 
 __global__ __launch_bounds__(256) void unpack_kernel(const NcwUnpackDesc* __restrict__ descs,
-                                                     const int32_t* __restrict__ prefix, int n) {
-    __shared__ float sm[4];
-    const int d = find_desc(prefix, n, blockIdx.x);
-    const NcwUnpackDesc D = descs[d];
-    const int i = blockIdx.x - prefix[d];
+                                                     const int32_t* __restrict__ prefix, int n, int total_rows) {
+    const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (grow >= total_rows) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int d = find_desc(prefix, n, grow);
+    const NcwUnpackDesc& D = descs[d];
+    const int i = grow - prefix[d];
     const int row = D.row0 + i;
     const float* drow = D.dw + (size_t)(D.drow0 + i) * D.ldw;
     const float* vrow = D.src + (size_t)row * D.ld;
     float* out = D.d_src + (size_t)row * D.ld;
+    const float scale = D.scale;
+    const int accumulate = D.accumulate;
     if (D.g == nullptr) {
         for (int s = 0; s < D.nseg; ++s) {
             const NcwSeg sg = D.seg[s];
-            for (int c = threadIdx.x; c < sg.ncols; c += 256) {
-                const float gval = drow[sg.dcol0 + c] * D.scale;
+            for (int c = lane; c < sg.ncols; c += 64) {
+                const float gval = drow[sg.dcol0 + c] * scale;
                 float* o = out + sg.col0 + c;
-                *o = D.accumulate ? *o + gval : gval;
+                *o = accumulate ? *o + gval : gval;
             }
         }
     } else {
@@ -97,38 +103,39 @@ __global__ __launch_bounds__(256) void unpack_kernel(const NcwUnpackDesc* __rest
         float ss = 0.f, dot = 0.f;
         for (int s = 0; s < D.nseg; ++s) {
             const NcwSeg sg = D.seg[s];
-            for (int c = threadIdx.x; c < sg.ncols; c += 256) {
+            for (int c = lane; c < sg.ncols; c += 64) {
                 const float v = vrow[sg.col0 + c];
                 ss += v * v;
-                dot += drow[sg.dcol0 + c] * D.scale * v;
+                dot += drow[sg.dcol0 + c] * scale * v;
             }
         }
-        ss = block_sum_256(ss, sm);
-        dot = block_sum_256(dot, sm);
+        ss = wave_sum(ss);
+        dot = wave_sum(dot);
         const float inv = 1.f / sqrtf(ss);
         const float gbar = dot * inv;  // sum(Wbar * v_hat)
         const float gg = D.g[row];
         for (int s = 0; s < D.nseg; ++s) {
             const NcwSeg sg = D.seg[s];
-            for (int c = threadIdx.x; c < sg.ncols; c += 256) {
+            for (int c = lane; c < sg.ncols; c += 64) {
                 const float v = vrow[sg.col0 + c];
-                const float gval = gg * inv * (drow[sg.dcol0 + c] * D.scale - gbar * v * inv);
+                const float gval = gg * inv * (drow[sg.dcol0 + c] * scale - gbar * v * inv);
                 float* o = out + sg.col0 + c;
-                *o = D.accumulate ? *o + gval : gval;
+                *o = accumulate ? *o + gval : gval;
             }
         }
-        if (threadIdx.x == 0 && D.d_g != nullptr) D.d_g[row] = D.accumulate ? D.d_g[row] + gbar : gbar;
+        if (lane == 0 && D.d_g != nullptr) D.d_g[row] = accumulate ? D.d_g[row] + gbar : gbar;
     }
-    if (threadIdx.x == 0 && D.d_bias != nullptr && D.db != nullptr) {
+    if (lane == 0 && D.d_bias != nullptr && D.db != nullptr) {
         const float b = D.db[D.drow0 + i];
-        D.d_bias[row] = D.accumulate ? D.d_bias[row] + b : b;
+        D.d_bias[row] = accumulate ? D.d_bias[row] + b : b;
     }
 }
 
 extern "C" int ncw_pack_weights(const NcwPackDesc* descs, const int32_t* row_prefix, int n, int total_rows,
                                 void* stream) {
     if (n <= 0 || total_rows <= 0) return 0;
-    hipLaunchKernelGGL(pack_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, descs, row_prefix, n);
+    hipLaunchKernelGGL(pack_kernel, dim3((total_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, descs, row_prefix, n,
+                       total_rows);
     NCW_CHECK_LAUNCH();
     return 0;
 }
@@ -136,7 +143,8 @@ extern "C" int ncw_pack_weights(const NcwPackDesc* descs, const int32_t* row_pre
 extern "C" int ncw_unpack_grads(const NcwUnpackDesc* descs, const int32_t* row_prefix, int n, int total_rows,
                                 void* stream) {
     if (n <= 0 || total_rows <= 0) return 0;
-    hipLaunchKernelGGL(unpack_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, descs, row_prefix, n);
+    hipLaunchKernelGGL(unpack_kernel, dim3((total_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, descs, row_prefix, n,
+                       total_rows);
     NCW_CHECK_LAUNCH();
     return 0;
 }
