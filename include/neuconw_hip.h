@@ -273,6 +273,20 @@ int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, i
 int ncw_wgrad_tiled(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
                     int tile, int64_t n_points, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimiser step over flat fp32 buffers (16-byte aligned): global-norm clip + Adam in one launch.
+ * Replaces torch.nn.utils.clip_grad_norm_ (train.py:61) + torch.optim.Adam(eps=1e-7).step()
+ * (utils/__init__.py:23-31) for parameters re-seated into one flat buffer:
+ *   coef = total_norm ? min(max_norm / (total_norm[0] + 1e-6), 1) : 1;   g *= coef  (written back)
+ *   m += (1-beta1)(g - m);  v = beta2 v + (1-beta2) g g;
+ *   p -= step_size * m / (sqrt(v) / bias_correction2_sqrt + eps)
+ * with step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t) computed by the caller.
+ * total_norm: DEVICE scalar (the 2-norm of grad) or NULL for no clipping.
+ * ---------------------------------------------------------------------------------------- */
+int ncw_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float step_size,
+                  float beta1, float beta2, float eps, float bias_correction2_sqrt, const float* total_norm,
+                  float max_norm, void* stream);
+
 /* Layout converters between row-major f32 [n, F] and the stash layout (rb = ceil(F/32) blocks,
  * element type by prec).  Used at the module boundary (NeuconW.forward returning feature vectors,
  * tests); padded lanes / features are written as zero. */

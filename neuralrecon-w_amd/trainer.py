@@ -94,6 +94,49 @@ class FlatParams:
             dist.broadcast(self.flat.data, src=src, group=group)
 
 
+class FlatAdam:
+    """Adam over trainer.FlatParams with the global-norm clip folded in: ONE `ncw_adam_step` launch per step
+    (+ one norm reduction) instead of torch's multi-tensor norm / clamp / mul / fused-Adam sequence.  Same
+    arithmetic as torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False) after
+    torch.nn.utils.clip_grad_norm_(params, clip) (tests/test_gpu_trainer.py); bias corrections are computed in
+    double on the host like torch's non-capturable path."""
+
+    def __init__(self, flat_params, lr, betas=(0.9, 0.999), eps=1e-7, clip=None):
+        self.fp = flat_params
+        self.lr, self.betas, self.eps, self.clip = float(lr), (float(betas[0]), float(betas[1])), float(eps), clip
+        self.step_count = 0
+        self.exp_avg = torch.zeros_like(flat_params.flat_grad)
+        self.exp_avg_sq = torch.zeros_like(flat_params.flat_grad)
+
+    def step(self):
+        from . import lib as L
+
+        fp = self.fp
+        if not fp.flat_grad.is_cuda:
+            raise L.NeuconwHipError("FlatAdam: parameters are not on a GPU; there is no CPU fallback")
+        self.step_count += 1
+        b1, b2 = self.betas
+        step_size = self.lr / (1.0 - b1 ** self.step_count)
+        bc2_sqrt = (1.0 - b2 ** self.step_count) ** 0.5
+        norm = torch.linalg.vector_norm(fp.flat_grad) if self.clip is not None else None
+        L.check(L.get_lib().ncw_adam_step(L.ptr(fp.flat.data), L.ptr(fp.flat_grad), L.ptr(self.exp_avg),
+                                          L.ptr(self.exp_avg_sq), fp.flat_grad.numel(), step_size, b1, b2, self.eps,
+                                          bc2_sqrt, L.ptr(norm),
+                                          float(self.clip) if self.clip is not None else 0.0,
+                                          L.stream_ptr(fp.flat_grad.device)), "ncw_adam_step")
+        fp.mark_updated()
+        return norm
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,
+                "betas": self.betas, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
 class TrainStep:
     """render -> loss -> backward -> all-reduce -> clip -> Adam, the timed region of SURVEY 8(d).
 
@@ -109,7 +152,7 @@ class TrainStep:
     With world_size > 1 the gradient all-reduce stays an eager RCCL call between two graphs."""
 
     def __init__(self, renderer, modules, loss_fn, lr, eps=1e-7, betas=(0.9, 0.999), clip=0.99, world_size=1,
-                 group=None, capture=False, capture_warmup=3):
+                 group=None, capture=False, capture_warmup=3, native_optimizer=None):
         self.renderer, self.loss_fn, self.clip = renderer, loss_fn, clip
         self.world_size, self.group = world_size, group
         self.capture, self.capture_warmup = bool(capture), int(capture_warmup)
@@ -117,6 +160,13 @@ class TrainStep:
         self.fp = FlatParams(modules, renderer)
         self.fp.broadcast(group=group)
         kw = dict(lr=lr, eps=eps, betas=betas)
+        # eager: clip + Adam as ONE C-ABI launch (FlatAdam); captured: torch's capturable Adam (device step counter)
+        self.native = (not self.capture) if native_optimizer is None else bool(native_optimizer)
+        if self.native and self.capture:
+            raise ValueError("the native optimiser keeps its step counter on the host: not capturable")
+        if self.native:
+            self.opt = FlatAdam(self.fp, clip=clip, **kw)
+            return
         if self.capture:
             renderer.sync_free = True
             kw["capturable"] = True
@@ -135,6 +185,9 @@ class TrainStep:
         return loss, out
 
     def _update(self):
+        if self.native:
+            self.opt.step()  # clip + Adam + mark_updated
+            return
         if self.clip is not None:
             torch.nn.utils.clip_grad_norm_([self.fp.flat], self.clip)  # train.py:61
         self.opt.step()
