@@ -381,6 +381,22 @@ typedef struct NcwCompositeGrad {
 int ncw_composite_fwd(const NcwCompositeIn* in, const NcwCompositeOut* out, void* stream);
 int ncw_composite_bwd(const NcwCompositeIn* in, const NcwCompositeGrad* g, void* stream);
 
+/* Per-ray loss terms that render() itself returns (renderer.py:763-765 gradient_error, :869-877 mask_error,
+ * :892-897 sfm_depth_loss) and their backward.  All arrays [R] f32 (label int64, NULL = no masking);
+ * mask_ids (HOST, <= 4 ids): labels whose rays get mask 0.  mask_error / sfm_depth_loss may be NULL (term off).
+ * sfm_depth_loss is the sync-free form (depth-gt)^2 w [w>0] R / max(#{w>0},1): its mean over R equals the
+ * reference's mean over the selected rays.  scalars: DEVICE float[3] = {gradient_error, sum(eik_den), count}. */
+int ncw_ray_tail_fwd(const float* weights_sum, const int64_t* label, const int* mask_ids, int n_ids,
+                     const float* depth, const float* depth_gt, const float* depth_weight, const float* eik_num,
+                     const float* eik_den, int R, float* mask_error, float* sfm_depth_loss, float* scalars,
+                     void* stream);
+/* cotangents may be NULL (treated as zero); writes d_weights_sum, d_depth, d_eik_num [R] */
+int ncw_ray_tail_bwd(const float* weights_sum, const int64_t* label, const int* mask_ids, int n_ids,
+                     const float* depth, const float* depth_gt, const float* depth_weight, int R,
+                     const float* scalars, const float* d_mask_error, const float* d_sfm_depth_loss,
+                     const float* d_gradient_error, float* d_weights_sum, float* d_depth, float* d_eik_num,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -689,3 +689,133 @@ extern "C" int ncw_composite_bwd(const NcwCompositeIn* in, const NcwCompositeGra
     NCW_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Per-ray loss terms computed inside render() (renderer.py:763-765 gradient_error, :869-877 mask_error,
+// :892-897 sfm_depth_loss) and their backward: ~55 tiny torch launches per step become two.  One
+// workgroup (the work is R elements + three sums).
+//   gradient_error = sum(eik_num) / (sum(eik_den) + 1e-5)
+//   mask_error[r]  = BCE(clip(weights_sum[r], 1e-3, 1 - 1e-3), mask[r]),  mask[r] = 0 iff label[r] in ids
+//   sfm[r]         = (depth - depth_gt)^2 * w * [w > 0] * R / max(#{w > 0}, 1)   (the sync-free form: its mean
+//                    over R equals the reference's mean over the selected rays; 0 if none is selected)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__device__ __forceinline__ float tail_mask(const int64_t* label, int r, int n_ids, const int* ids) {
+    if (label == nullptr) return 1.f;
+    const int64_t l = label[r];
+    for (int i = 0; i < n_ids; ++i)
+        if (l == ids[i]) return 0.f;
+    return 1.f;
+}
+
+struct TailIds { int v[4]; };
+
+__global__ __launch_bounds__(256) void ray_tail_fwd_kernel(const float* __restrict__ wsum, const int64_t* __restrict__ label,
+                                                           const float* __restrict__ depth, const float* __restrict__ depth_gt,
+                                                           const float* __restrict__ depth_w, const float* __restrict__ eik_num,
+                                                           const float* __restrict__ eik_den, int R, int n_ids, TailIds ids,
+                                                           float* __restrict__ mask_error, float* __restrict__ sfm,
+                                                           float* __restrict__ scal) {
+    __shared__ float sm[4];
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        a += eik_num[r];
+        b += eik_den[r];
+        if (depth_w != nullptr) c += depth_w[r] > 0.f ? 1.f : 0.f;
+    }
+    a = block_sum256(a, sm);
+    b = block_sum256(b, sm);
+    c = block_sum256(c, sm);
+    const float cnt = fmaxf(c, 1.f);
+    if (threadIdx.x == 0) {
+        scal[0] = a / (b + 1e-5f);
+        scal[1] = b;
+        scal[2] = cnt;
+    }
+    const float rs = (float)R / cnt;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        if (mask_error != nullptr) {
+            const float m = tail_mask(label, r, n_ids, ids.v);
+            const float x = fminf(fmaxf(wsum[r], 1e-3f), 1.f - 1e-3f);
+            mask_error[r] = -(m * fmaxf(logf(x), -100.f) + (1.f - m) * fmaxf(logf(1.f - x), -100.f));
+        }
+        if (sfm != nullptr) {
+            const float w = depth_w[r], dd = depth[r] - depth_gt[r];
+            sfm[r] = dd * dd * w * (w > 0.f ? 1.f : 0.f) * rs;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ray_tail_bwd_kernel(const float* __restrict__ wsum, const int64_t* __restrict__ label,
+                                                           const float* __restrict__ depth, const float* __restrict__ depth_gt,
+                                                           const float* __restrict__ depth_w, int R, int n_ids, TailIds ids,
+                                                           const float* __restrict__ scal, const float* __restrict__ d_mask_error,
+                                                           const float* __restrict__ d_sfm, const float* __restrict__ d_ge,
+                                                           float* __restrict__ d_wsum, float* __restrict__ d_depth,
+                                                           float* __restrict__ d_eik_num) {
+    const float den = scal[1], cnt = scal[2];
+    const float ge = d_ge != nullptr ? d_ge[0] / (den + 1e-5f) : 0.f;
+    const float rs = (float)R / cnt;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+        d_eik_num[r] = ge;
+        float dw = 0.f;
+        if (d_mask_error != nullptr) {
+            const float w0 = wsum[r];
+            if (w0 >= 1e-3f && w0 <= 1.f - 1e-3f) {  // clamp passes the gradient on the closed interval
+                const float m = tail_mask(label, r, n_ids, ids.v);
+                dw = d_mask_error[r] * (w0 - m) / fmaxf((1.f - w0) * w0, 1e-12f);
+            }
+        }
+        d_wsum[r] = dw;
+        float dd = 0.f;
+        if (d_sfm != nullptr) {
+            const float w = depth_w[r];
+            dd = d_sfm[r] * 2.f * (depth[r] - depth_gt[r]) * w * (w > 0.f ? 1.f : 0.f) * rs;
+        }
+        d_depth[r] = dd;
+    }
+}
+
+extern "C" int ncw_ray_tail_fwd(const float* weights_sum, const int64_t* label, const int* mask_ids, int n_ids,
+                                const float* depth, const float* depth_gt, const float* depth_weight, const float* eik_num,
+                                const float* eik_den, int R, float* mask_error, float* sfm_depth_loss, float* scalars,
+                                void* stream) {
+    if (R <= 0) return 0;
+    if (!weights_sum || !eik_num || !eik_den || !scalars || n_ids < 0 || n_ids > 4 || (n_ids > 0 && !mask_ids))
+        return NCW_E_BADARG;
+    if (sfm_depth_loss && (!depth || !depth_gt || !depth_weight)) return NCW_E_BADARG;
+    TailIds ids = {{0, 0, 0, 0}};
+    for (int i = 0; i < n_ids; ++i) ids.v[i] = mask_ids[i];
+    hipLaunchKernelGGL(ray_tail_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, weights_sum, label, depth, depth_gt,
+                       sfm_depth_loss ? depth_weight : nullptr, eik_num, eik_den, R, n_ids, ids, mask_error, sfm_depth_loss,
+                       scalars);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ncw_ray_tail_bwd(const float* weights_sum, const int64_t* label, const int* mask_ids, int n_ids,
+                                const float* depth, const float* depth_gt, const float* depth_weight, int R,
+                                const float* scalars, const float* d_mask_error, const float* d_sfm_depth_loss,
+                                const float* d_gradient_error, float* d_weights_sum, float* d_depth, float* d_eik_num,
+                                void* stream) {
+    if (R <= 0) return 0;
+    if (!weights_sum || !scalars || !d_weights_sum || !d_depth || !d_eik_num || n_ids < 0 || n_ids > 4 ||
+        (n_ids > 0 && !mask_ids))
+        return NCW_E_BADARG;
+    if (d_sfm_depth_loss && (!depth || !depth_gt || !depth_weight)) return NCW_E_BADARG;
+    TailIds ids = {{0, 0, 0, 0}};
+    for (int i = 0; i < n_ids; ++i) ids.v[i] = mask_ids[i];
+    hipLaunchKernelGGL(ray_tail_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, weights_sum, label,
+                       depth, depth_gt, depth_weight, R, n_ids, ids, scalars, d_mask_error, d_sfm_depth_loss,
+                       d_gradient_error, d_weights_sum, d_depth, d_eik_num);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}

@@ -2,11 +2,12 @@
 keywords, same `render()` output dictionary, same helper methods (`sdf`, `rgb`, `get_octree`) and
 mutable attributes -- the body runs the hand-written gfx950 kernels of libneuconw_hip.so.
 
-Only per-RAY glue (ray normalisation, the embedding lookup, the BCE / depth terms on [R]-sized
-tensors) stays in torch; everything per ray-SAMPLE (sampling, the three MLPs forward and backward,
+Only per-RAY glue (ray normalisation, the embedding lookup) stays in torch; the per-ray loss terms render()
+returns (gradient_error, mask_error, sfm_depth_loss) are one C-ABI launch (`_RayTailFn`); everything per ray-SAMPLE (sampling, the three MLPs forward and backward,
 compositing) is HIP.  Autograd sees ONE node (`_RenderFn`) whose backward launches the fused
 backward kernels and returns the gradients of every parameter.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -139,6 +140,41 @@ class _RenderFn(torch.autograd.Function):
             if c is not None:
                 StashCache.release(c["lease"])
         return (None, None, None, None, None, None, None, None, d_a, d_var) + tuple(out)
+
+
+class _RayTailFn(torch.autograd.Function):
+    """gradient_error, mask_error and the sync-free sfm_depth_loss of render() (renderer.py:763-765, 869-877,
+    892-897) as one forward and one backward launch (ncw_ray_tail_fwd/bwd) instead of ~55 tiny torch kernels."""
+
+    @staticmethod
+    def forward(ctx, wsum, depth, eik_num, eik_den, label, depth_gt, depth_w, ids, has_mask, has_depth):
+        R, dev = wsum.shape[0], wsum.device
+        f = lambda t: t.detach().contiguous().float()  # noqa: E731
+        wsum_c, depth_c, num_c, den_c = f(wsum), f(depth), f(eik_num), f(eik_den)
+        label_c = label.contiguous().long() if (has_mask and label is not None) else None
+        gt_c, w_c = (f(depth_gt), f(depth_w)) if has_depth else (None, None)
+        mask_error = torch.empty(R, device=dev) if has_mask else None
+        sfm = torch.empty(R, device=dev) if has_depth else None
+        scal = torch.empty(3, device=dev)
+        ids_arr = (C.c_int * 4)(*(list(ids) + [0] * (4 - len(ids))))
+        L.check(L.get_lib().ncw_ray_tail_fwd(L.ptr(wsum_c), L.ptr(label_c), ids_arr, len(ids), L.ptr(depth_c),
+                                             L.ptr(gt_c), L.ptr(w_c), L.ptr(num_c), L.ptr(den_c), R, L.ptr(mask_error),
+                                             L.ptr(sfm), L.ptr(scal), L.stream_ptr(dev)), "ncw_ray_tail_fwd")
+        ctx.keep = (wsum_c, depth_c, label_c, gt_c, w_c, scal, ids_arr, len(ids), has_mask, has_depth)
+        return mask_error, sfm, scal[0:1]
+
+    @staticmethod
+    def backward(ctx, d_me, d_sfm, d_ge):
+        wsum_c, depth_c, label_c, gt_c, w_c, scal, ids_arr, n_ids, has_mask, has_depth = ctx.keep
+        R, dev = wsum_c.shape[0], wsum_c.device
+        g = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
+        d_me, d_sfm, d_ge = (g(d_me) if has_mask else None), (g(d_sfm) if has_depth else None), g(d_ge)
+        d_wsum, d_depth, d_num = (torch.empty(R, device=dev) for _ in range(3))
+        L.check(L.get_lib().ncw_ray_tail_bwd(L.ptr(wsum_c), L.ptr(label_c), ids_arr, n_ids, L.ptr(depth_c), L.ptr(gt_c),
+                                             L.ptr(w_c), R, L.ptr(scal), L.ptr(d_me), L.ptr(d_sfm), L.ptr(d_ge),
+                                             L.ptr(d_wsum), L.ptr(d_depth), L.ptr(d_num), L.stream_ptr(dev)),
+                "ncw_ray_tail_bwd")
+        return d_wsum, d_depth, d_num, None, None, None, None, None, None, None
 
 
 class NeuconWRenderer:
@@ -322,22 +358,18 @@ class NeuconWRenderer:
         (color, wsum, depth, eik_num, color_sphere, color_bg, weights, cdf, inside, normals, sdf, gradients, mid_z,
          dists, eik_den, inv_s) = outs
         weights_sum = wsum.unsqueeze(-1)
-        gradient_error = eik_num.sum() / (eik_den.sum() + 1e-5)  # renderer.py:763-765 (batch-global scalar)
-        if self.mesh_mask_list is not None:  # renderer.py:869-877
-            mask = torch.ones_like(near)
-            for name in self.mesh_mask_list:
-                mask[_label_id(name) == label] = 0
-            mask_error = F.binary_cross_entropy(weights_sum.clip(1e-3, 1.0 - 1e-3), mask, reduction="none")
-        else:
-            mask_error = torch.zeros_like(weights_sum)
-        if self.depth_loss and self.sync_free:
-            # Same loss, no device->host sync: the reference returns the SELECTED entries (a data-dependent
-            # shape, renderer.py:892-897) and the loss takes their mean; here every ray keeps an entry,
-            # scaled so that `.mean()` over all R entries equals the reference's mean over the selected ones
-            # (and 0 when none is selected, like the reference's zeros_like branch).
-            sel = (depth_weight > 0).to(depth.dtype)
-            cnt = sel.sum().clamp_min(1.0)
-            sfm_depth_loss = ((depth - depth_gt) ** 2) * depth_weight * sel * (float(depth.shape[0]) / cnt)
+        has_mask = self.mesh_mask_list is not None
+        dense_depth = bool(self.depth_loss and self.sync_free)
+        ids = tuple(_label_id(name) for name in self.mesh_mask_list) if has_mask else ()
+        # gradient_error (renderer.py:763-765, batch-global scalar), mask_error (:869-877) and -- in sync-free mode --
+        # sfm_depth_loss in one launch.  Sync-free sfm_depth_loss: the reference returns the SELECTED entries (a
+        # data-dependent shape, :892-897) and the loss takes their mean; here every ray keeps an entry, scaled so that
+        # `.mean()` over all R entries equals the reference's mean over the selected ones (0 when none is selected).
+        me, sfm_dense, gradient_error = _RayTailFn.apply(wsum, depth, eik_num, eik_den, label, depth_gt, depth_weight,
+                                                         ids, has_mask, dense_depth)
+        mask_error = me.unsqueeze(-1) if has_mask else torch.zeros_like(weights_sum)
+        if dense_depth:
+            sfm_depth_loss = sfm_dense
         elif self.depth_loss and torch.sum(depth_weight > 0) > 0:  # renderer.py:892-897
             sfm_depth_loss = (((depth - depth_gt) ** 2) * depth_weight)[depth_weight > 0]
         else:
@@ -346,7 +378,7 @@ class NeuconWRenderer:
             "color": color, "color_sphere": color_sphere, "color_bg": color_bg, "s_val": (1.0 / inv_s).reshape(1, 1),
             "cdf_fine": cdf, "gradients": gradients, "mask_error": mask_error, "weights": weights,
             "weights_sum": weights_sum, "weights_max": torch.max(weights, dim=-1, keepdim=True)[0],
-            "gradient_error": torch.ones(1, device=device) * gradient_error, "inside_sphere": inside,
+            "gradient_error": gradient_error, "inside_sphere": inside,
             "depth": depth, "floor_normal_error": torch.zeros_like(normals), "floor_y_error": torch.zeros_like(normals),
             "sfm_depth_loss": sfm_depth_loss,
         }
