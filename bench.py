@@ -240,12 +240,14 @@ def main():
         # of this same command, committed under profiles/ (bench.py cannot run rocprof on itself).
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_v2.json")))
-            keys = {"ncw_wgrad_tiled": "wgrad_bf16_kernel", "ncw_sdf_bwd": "sdf_bwd_kernel", "ncw_sdf_fwd": "sdf_fwd_kernel"}
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_v3.json")))
+            keys = {"ncw_wgrad_tiled": "wgrad_dma_kernel", "ncw_sdf_bwd": "sdf_bwd_kernel", "ncw_sdf_fwd": "sdf_fwd_kernel"}
             sel = [v for k, v in tj.items() if keys.get(dom, "\0") in k]
             if sel and prec == nw.PREC_BF16 and R == R_PER_GPU:
-                kb = sum((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * v["launches"] for v in sel)
-                traffic = round(kb * 1024.0 / sum(v["launches"] for v in sel), 0)  # bytes per launch (uncorrected)
+                # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts wide coalesced streaming reads (16 B/lane,
+                # global_load and LDS-DMA alike) at exactly 1/2 -> doubled; WRITE_SIZE is taken as reported.  KB.
+                kb = sum((2.0 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * v["launches"] for v in sel)
+                traffic = round(kb * 1024.0 / sum(v["launches"] for v in sel), 0)  # bytes per launch
         except Exception:
             traffic = None
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
