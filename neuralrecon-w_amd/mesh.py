@@ -1,0 +1,110 @@
+"""Mesh extraction on the GPU: the steps after the SDF grid sweep of config 5.
+
+Reference: utils/visualization.py:37-159 `extract_mesh` (rank-0 CPU `skimage.measure.marching_cubes`, vertex
+colours through `renderer.rgb`, trimesh export) driven by tools/extract_mesh.py:104-168.  Here the SDF grid never
+leaves the GPU: `grid.sdf_grid` -> `isosurface` (marching tetrahedra, csrc/ncw_mesh.hip) -> vertex welding with
+torch.unique -> optional colour pass -> binary PLY.  skimage's triangulation (Lewiner) is not reproducible
+without skimage, which is neither in the reference tree nor installable: **triangulation parity is unpinned**;
+what is kept is the vertex rule (linear zero crossing on every sign-changing grid edge), the `mask` semantics
+and the coordinate chain `verts * voxel_size + vol_origin`, `* scene_radius + scene_origin` (:116-117).
+Normals / winding point towards increasing SDF (outwards).
+"""
+import struct
+
+import numpy as np
+import torch
+
+from . import grid as _grid
+from . import lib as L
+
+
+@torch.no_grad()
+def isosurface(sdf, level=0.0, mask=None):
+    """sdf [Dx,Dy,Dz] float32 on the GPU (x slowest) -> (verts [V,3] float32 in grid-index coordinates,
+    faces [F,3] int64).  mask: bool [Dx,Dy,Dz] or None -- cube (i,j,k) is used iff mask[i+1,j+1,k+1]."""
+    if not sdf.is_cuda:
+        raise L.NeuconwHipError("mesh.isosurface: the SDF grid is not on a GPU; there is no CPU fallback")
+    sdf = sdf.contiguous().float()
+    Dx, Dy, Dz = sdf.shape
+    dev = sdf.device
+    m8 = None if mask is None else mask.to(device=dev, dtype=torch.uint8).contiguous()
+    ncubes = (Dx - 1) * (Dy - 1) * (Dz - 1)
+    counts = torch.empty(ncubes, dtype=torch.int32, device=dev)
+    lib = L.get_lib()
+    L.check(lib.ncw_mt_count(L.ptr(sdf), L.ptr(m8), Dx, Dy, Dz, float(level), L.ptr(counts), L.stream_ptr(dev)),
+            "ncw_mt_count")
+    incl = torch.cumsum(counts, 0, dtype=torch.int64)
+    T = int(incl[-1])  # one device->host read: the mesh size
+    if T == 0:
+        return torch.zeros(0, 3, device=dev), torch.zeros(0, 3, dtype=torch.int64, device=dev)
+    offsets = (incl - counts).contiguous()
+    pos = torch.empty(T, 3, 3, device=dev, dtype=torch.float32)
+    key = torch.empty(T, 3, device=dev, dtype=torch.int64)
+    L.check(lib.ncw_mt_emit(L.ptr(sdf), L.ptr(m8), Dx, Dy, Dz, float(level), L.ptr(offsets), L.ptr(pos), L.ptr(key),
+                            L.stream_ptr(dev)), "ncw_mt_emit")
+    uniq, inv = torch.unique(key.reshape(-1), return_inverse=True)  # weld: one vertex per grid edge
+    verts = torch.empty(uniq.shape[0], 3, device=dev, dtype=torch.float32)
+    verts[inv] = pos.reshape(-1, 3)  # all copies of a vertex are bit-identical (interpolated lo -> hi)
+    faces = inv.reshape(T, 3)
+    ok = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
+    return verts, faces[ok]  # a value exactly on the level collapses an edge: drop the degenerate faces
+
+
+@torch.no_grad()
+def vertex_colors(renderer, verts_training, embedding_a, chunk=1 << 16):
+    """utils/visualization.py:124-150: rgb at the vertices, viewed along +z, one appearance code for all."""
+    V = verts_training.shape[0]
+    dev = verts_training.device
+    out = torch.empty(V, 3, device=dev)
+    a = embedding_a.reshape(1, -1).to(dev).float()
+    for i in range(0, V, chunk):
+        p = verts_training[i:i + chunk].float()
+        d = torch.zeros_like(p)
+        d[:, 2] = 1
+        with torch.enable_grad():  # renderer.rgb runs NeuconW.forward, which needs the SDF gradient
+            out[i:i + chunk] = renderer.rgb(p.unsqueeze(1), d.unsqueeze(1), a.expand(p.shape[0], -1).unsqueeze(1)).detach()
+    return out * 255
+
+
+@torch.no_grad()
+def extract_mesh(renderer, dim, scene_radius, scene_origin, origin=None, radius=1.0, with_color=False, embedding_a=None,
+                 level=0.0, chunk_rgb=1 << 16):
+    """utils/visualization.py:37-159 (dense path).  Returns dict(vertices [V,3] world coordinates, faces [F,3],
+    vertices_training, colors [V,3] uint8 or None) as GPU tensors."""
+    origin = [0.0, 0.0, 0.0] if origin is None else [float(v) for v in origin]
+    lo = tuple(o - radius for o in origin)
+    hi = tuple(o + radius for o in origin)
+    sdf = _grid.sdf_grid(renderer.neuconw.sdf_net, dim, lo, hi, prec=renderer.prec).view(dim, dim, dim)
+    verts, faces = isosurface(sdf, level)
+    voxel_size = 2 * radius / (dim - 1)                                      # :44
+    vol_origin = torch.tensor(lo, device=verts.device, dtype=torch.float32)  # :43
+    verts_t = verts * voxel_size + vol_origin                                # :116
+    so = torch.as_tensor(np.asarray(scene_origin, dtype=np.float32), device=verts.device).reshape(3)
+    verts_w = verts_t * float(scene_radius) + so                             # :117
+    colors = None
+    if with_color:
+        colors = vertex_colors(renderer, verts_t, embedding_a, chunk_rgb).clamp(0, 255).to(torch.uint8)
+    return {"vertices": verts_w, "faces": faces, "vertices_training": verts_t, "colors": colors}
+
+
+def write_ply(path, vertices, faces, colors=None):
+    """Binary little-endian PLY (what trimesh's export writes for tools/extract_mesh.py:160-168)."""
+    v = vertices.detach().cpu().numpy().astype("<f4")
+    f = faces.detach().cpu().numpy().astype("<i4")
+    hdr = ["ply", "format binary_little_endian 1.0", "element vertex %d" % v.shape[0], "property float x",
+           "property float y", "property float z"]
+    if colors is not None:
+        hdr += ["property uchar red", "property uchar green", "property uchar blue"]
+    hdr += ["element face %d" % f.shape[0], "property list uchar int vertex_indices", "end_header"]
+    with open(path, "wb") as fh:
+        fh.write(("\n".join(hdr) + "\n").encode("ascii"))
+        if colors is None:
+            fh.write(v.tobytes())
+        else:
+            c = colors.detach().cpu().numpy().astype("u1")
+            rec = np.empty(v.shape[0], dtype=[("p", "<f4", 3), ("c", "u1", 3)])
+            rec["p"], rec["c"] = v, c
+            fh.write(rec.tobytes())
+        rec = np.empty(f.shape[0], dtype=[("n", "u1"), ("i", "<i4", 3)])
+        rec["n"], rec["i"] = 3, f
+        fh.write(rec.tobytes())
