@@ -239,13 +239,28 @@ struct ActB {
     NCW_DEV auto b(int rb, int sub) const { return unit_b<RB_IN_>(a, rb, sub); }
 };
 
+// B provider for a feature-axis concatenation [a | g] WITHOUT materialising it (skip connections: the copy
+// costs 8 (RA + RG) registers next to 16 RB accumulators -- at W = 512 that alone spills)
+template <class P, int RA, int RG>
+struct CatB {
+    static constexpr int RB_IN = RA + RG;
+    const Act<P, RA>& a;
+    const Act<P, RG>& g;
+    NCW_DEV CatB(const Act<P, RA>& a_, const Act<P, RG>& g_) : a(a_), g(g_) {}
+    NCW_DEV void prepare(int) {}
+    NCW_DEV auto b(int rb, int sub) const {
+        return rb < RA ? unit_b<RA>(a, rb < RA ? rb : 0, sub) : unit_b<RG>(g, rb >= RA ? rb - RA : 0, sub);
+    }
+};
+
 // acc[RB_OUT] += W . B, W streamed through the LDS ring.  ALL threads of the workgroup must call
 // this with identical (uniform) arguments.  w_next/next_bytes: first chunk of the matrix the NEXT
 // mma_stream call will consume (nullptr at the end of the kernel).
 // PIPE (explicit double-buffering of the weight fragments, +8 fragment registers) pays in the kernels that
 // own a whole SIMD (one workgroup per CU, 64 KiB slots); the two-workgroups-per-CU kernels (32 KiB slots) are
 // capped at 256 registers -- there the other workgroup's waves hide the LDS latency and PIPE only spills.
-template <int RB_OUT, int K_REAL, int SLOT, int RB_STRIDE, class P, class BP, bool PIPE = (SLOT != 32768)>
+// 16 out-blocks (W = 512): the second fragment set alone is 64 registers on top of 256 accumulators: off.
+template <int RB_OUT, int K_REAL, int SLOT, int RB_STRIDE, class P, class BP, bool PIPE = (SLOT != 32768) && (RB_OUT <= 8)>
 NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename P::welem* __restrict__ wp,
                           const void* w_next, int next_bytes, int lane) {
     constexpr int RB_IN = BP::RB_IN;
@@ -305,6 +320,9 @@ NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename
                 for (int ro = 0; ro < RB_OUT; ++ro) cur[ro] = nxt[ro];
             } else {
                 loaded = false;
+                // 16 out-blocks: keep hipcc from hoisting the fragment reads of later units above these MFMAs
+                // (64 registers per unit on top of 256 accumulators)
+                if (RB_OUT > 8) __builtin_amdgcn_sched_barrier(0);
             }
         }
         ring.cur ^= 1;

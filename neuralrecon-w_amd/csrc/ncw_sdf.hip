@@ -53,9 +53,8 @@ NCW_DEV void sdf_hidden_layer(CVec<RB>& acc, const Act<P, RB>& act, GammaFn&& ga
         // live across all layers: 16-32 registers less on the critical allocation
         Act<P, 2> gact;
         gamma_fn(gact);
-        Act<P, RB + 2> cat;
-        act_concat<RB, 2>(cat, act, gact);
-        mma_stream<RB + 2, RB, 32 * RB + 39, SLOT>(acc, cat, ring, (const WE*)net.w[l], w_next, next_bytes, lane);
+        CatB<P, RB, 2> cat(act, gact);  // [h | gamma] without a copy
+        mma_stream_b<RB, 32 * RB + 39, SLOT, RB, P>(acc, cat, ring, (const WE*)net.w[l], w_next, next_bytes, lane);
     } else {
         mma_stream<RB, RB, 32 * RB, SLOT>(acc, act, ring, (const WE*)net.w[l], w_next, next_bytes, lane);
     }
@@ -246,12 +245,13 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet ne
 // backward (second order)
 // ---------------------------------------------------------------------------------------------
 template <class P, int RB>
-__global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void sdf_bwd_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+// W = 512 (RB = 16): 256 accumulator registers alone -- one workgroup per CU like the forward
+__global__ __launch_bounds__(64 * NCW_WG_WAVES, (RB >= 16 ? 1 : 2)) void sdf_bwd_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
                                                                     const float* __restrict__ d_sdf,
                                                                     const float* __restrict__ d_grad, NcwSdfStash st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
-    typedef SdfShapes<P, RB, 2> SH;
+    typedef SdfShapes<P, RB, (RB >= 16 ? 1 : 2)> SH;
     NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
     const int h = lane >> 5;
