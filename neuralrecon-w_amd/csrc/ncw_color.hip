@@ -18,7 +18,10 @@ NCW_DEV void build_aux2(CVec<1>& aux, const float (&x)[3], const float (&nrm)[3]
 
 template <class P, int RBF, int RBH, int RBC>
 struct ColShapes {
-    static constexpr int SLOT = RingSlot<RBC, 2>::bytes;  // both colour kernels fit 256 registers: 2 workgroups / CU
+    // both colour kernels fit 256 registers at d_feature = 256: 2 workgroups / CU; with a 512-wide feature
+    // vector (RBF = 16: 256 accumulators for xyz_encoding_final alone) they own the CU like the SDF forward
+    static constexpr int OCC = RBF >= 16 ? 1 : 2;
+    static constexpr int SLOT = RingSlot<RBC, OCC>::bytes;
     static constexpr int FCB_F = ncw_first_chunk_bytes<P, RBF, 32 * RBF, RBF, SLOT>();
     static constexpr int FCB_E0 = ncw_first_chunk_bytes<P, RBF + 3, 32 * RBF + 96, RBH, SLOT>();
     static constexpr int FCB_E = ncw_first_chunk_bytes<P, RBH, 32 * RBH, RBH, SLOT>();
@@ -31,7 +34,7 @@ struct ColShapes {
 };
 
 template <class P, int RBF, int RBH, int RBC>
-__global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void color_fwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
+__global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_fwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
                                                                       const float* __restrict__ normals,
                                                                       const float* __restrict__ a,
                                                                       const void* __restrict__ feat_stash,
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void color_fwd_kernel(NcwColo
 }
 
 template <class P, int RBF, int RBH, int RBC>
-__global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void color_bwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
+__global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_bwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
                                                                       const float* __restrict__ rgb,
                                                                       const float* __restrict__ d_rgb,
                                                                       float* __restrict__ d_grad, float* __restrict__ d_a,
