@@ -14,7 +14,7 @@ PREC_F32 = 0
 PREC_BF16 = 1
 MAX_LAYERS = 12
 MAX_SEGS = 4
-ABI_VERSION = 1
+ABI_VERSION = 2  # 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
 
 
 class NcwSeg(C.Structure):
