@@ -7,6 +7,8 @@
 // One wave = 32 points, activations register-resident in MFMA C layout (ncw_common.h); every layer
 // of the network runs inside ONE launch; inter-layer activations never round-trip HBM (only the
 // stash that the backward needs is written, once, coalesced).
+#include <stdlib.h>
+
 #include "ncw_mlp.h"
 
 NCW_DEV NcwPoints points_from_x(const float* x) {
@@ -394,10 +396,14 @@ static bool sdf_net_ok(const NcwSdfNet* net) {
         } else return NCW_E_UNSUPPORTED;                                                                \
     } while (0)
 
+int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);  // ncw_sdf8.hip
+
 static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, int64_t n, float* sdf, void* stream) {
     if (!sdf_net_ok(net) || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    static const bool pilot8 = getenv("NCW_SDF_INFER8") != nullptr;  // round-2 structure pilot (ncw_sdf8.hip)
+    if (pilot8 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3) return ncw_sdf_infer8_launch(net, src, n, sdf, st);
     NCW_SDF_DISPATCH(sdf_infer_kernel, *net, src, n, sdf);
     return 0;
 }

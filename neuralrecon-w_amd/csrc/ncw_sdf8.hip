@@ -1,0 +1,175 @@
+// Pilot of the round-2 structure for the fused MLP kernels, on the simplest of them:
+// SDF inference (SDFNetwork.sdf, models/neuconw.py:281-282), bf16, W = 256.
+//   * ONE 8-wave workgroup per CU (<= 256 registers per lane): 256 points share every weight byte that is
+//     streamed L2 -> LDS (the 4-wave kernels re-stream the network for every 128 points), and two waves per
+//     SIMD overlap one wave's Softplus epilogue with the other's MFMAs;
+//   * HALF-LAYER accumulators: a 256 -> 256 layer is two passes of 4 output blocks (64 accumulator registers
+//     instead of 128), which is what makes 256 registers enough without spilling;
+//   * the existing packed layout [unit][8 out-blocks][64 lanes][16 B] is kept: the LDS-DMA gathers the
+//     4 out-blocks of a half with a strided piece list (one 1 KiB piece = one (unit, out-block) fragment set),
+//     so a 64-80 KiB slot holds one resident half-matrix and there is ONE barrier per half-layer.
+// Selected by the environment variable NCW_SDF_INFER8=1 (ncw_sdf.hip); results are identical to sdf_infer_kernel
+// up to the order of the bf16 roundings (same MFMA sequence per output block).
+#include "ncw_mlp.h"
+
+namespace {
+
+constexpr int S8_WAVES = 8;
+constexpr int S8_SLOT = 80 * 1024;  // the skip layer's half: 19 units x 4 KiB = 76 KiB
+
+// DMA `units` x NB out-blocks (starting at out-block ob0 of a packed matrix with RB_STRIDE out-blocks) into a slot
+// laid out [unit][NB][64 lanes][16 B]
+template <int NB, int RB_STRIDE>
+NCW_DEV void s8_issue(ncw_lchar* slot, const void* wbase, int units, int ob0) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const char* g = reinterpret_cast<const char*>(wbase) + lane * 16;
+    const int pieces = units * NB;
+    for (int pc = wave; pc < pieces; pc += S8_WAVES) {
+        const int u = pc / NB, ob = pc - u * NB;
+        __builtin_amdgcn_global_load_lds((ncw_gvoid*)(g + (size_t)(u * RB_STRIDE + ob0 + ob) * 1024),
+                                         (ncw_lvoid*)(slot + pc * 1024), 16, 0, 0);
+    }
+}
+
+// acc[NB] += W_half . B  with the half-matrix resident in `slot` ([unit][NB][lane]); K_REAL as in mma_stream
+#ifndef S8_HOIST
+#define S8_HOIST 2
+#endif
+template <int NB, int RB_IN, int K_REAL, class BP, int HOIST = S8_HOIST>
+NCW_DEV void s8_mma(CVec<NB>& acc, const BP& bp, const ncw_lchar* slot, int lane) {
+    typedef const __attribute__((address_space(3))) bf16x8* lfrag_t;
+    lfrag_t lw = (lfrag_t)slot + lane;
+    int uu = 0;  // units are stored densely in the order they are used
+#pragma unroll
+    for (int q = 0; q < 2 * RB_IN; ++q) {
+        if (16 * q >= K_REAL) continue;
+        const auto b = bp.b(q >> 1, q & 1);
+        bf16x8 a[NB];
+#pragma unroll
+        for (int ro = 0; ro < NB; ++ro) a[ro] = (lw + uu * NB * 64)[ro * 64];
+#pragma unroll
+        for (int ro = 0; ro < NB; ++ro) acc.v[ro] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ro], b, acc.v[ro], 0, 0, 0);
+        ++uu;
+        if (uu % HOIST == 0) __builtin_amdgcn_sched_barrier(0);  // bound how far hipcc hoists the fragment reads
+    }
+}
+
+template <int RA, int RG>
+struct S8Cat {  // [a | g] B provider without a copy
+    const Act<PrecBF16, RA>& a;
+    const Act<PrecBF16, RG>& g;
+    NCW_DEV S8Cat(const Act<PrecBF16, RA>& a_, const Act<PrecBF16, RG>& g_) : a(a_), g(g_) {}
+    NCW_DEV bf16x8 b(int rb, int sub) const { return rb < RA ? a.f[2 * (rb < RA ? rb : 0) + sub] : g.f[2 * (rb >= RA ? rb - RA : 0) + sub]; }
+};
+template <int RA>
+struct S8Act {
+    const Act<PrecBF16, RA>& a;
+    NCW_DEV explicit S8Act(const Act<PrecBF16, RA>& a_) : a(a_) {}
+    NCW_DEV bf16x8 b(int rb, int sub) const { return a.f[2 * rb + sub]; }
+};
+
+NCW_DEV void s8_bias(CVec<4>& acc, const float* __restrict__ bp, int half, int lane) {
+    load_bias(acc, bp + half * 4 * 32, lane);  // packed bias [rb][h][16]
+}
+
+// new_act blocks [4 half, 4 half + 4) = Softplus100(acc)
+NCW_DEV void s8_epilogue(Act<PrecBF16, 8>& out, const CVec<4>& acc, int half) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        f32x16 yv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float y, s;
+            softplus100<true>(acc.v[rb][r], y, s);
+            yv[r] = y;
+        }
+        to_act_block<8>(out, 4 * half + rb, yv);
+    }
+}
+
+__global__ __launch_bounds__(64 * S8_WAVES) void sdf_infer8_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                  float* __restrict__ sdf) {
+    typedef PrecBF16 P;
+    __shared__ __attribute__((aligned(16))) char ring_mem[2 * S8_SLOT];
+    ncw_lchar* slot[2] = {(ncw_lchar*)ring_mem, (ncw_lchar*)ring_mem + S8_SLOT};
+    const int lane = ncw_lane();
+    const int L = net.n_layers;
+    int64_t tile, p, ray;
+    bool valid;
+    tile_setup(n, tile, p, valid, lane);
+    float xs[3];
+    load_point(src, p, xs, ray);
+    xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+    // what the ring holds, in consumption order: W0 (whole, 3 units x 8), then (W_l, half) for l = 1..L-2, then W_{L-1}
+    auto issue_step = [&](int step, ncw_lchar* dst) {  // step 0 = W0; 1 + 2 (l-1) + half = hidden; last = sdf row
+        const int nh = 2 * (L - 2);
+        if (step == 0) s8_issue<8, 8>(dst, net.w[0], 3, 0);
+        else if (step <= nh) {
+            const int l = 1 + (step - 1) / 2, half = (step - 1) & 1;
+            s8_issue<4, 8>(dst, net.w[l], l == net.skip_layer ? 19 : 16, 4 * half);
+        } else if (step == nh + 1) s8_issue<1, 1>(dst, net.w[L - 1], 16, 0);
+    };
+    int cur = 0, step = 0;
+    issue_step(0, slot[0]);
+    Act<P, 8> act, nact;
+    Act<P, 2> gact;
+    {
+        CVec<2> gam;
+        freq_encode<2, 3, 6, true>(gam, xs, lane);
+        to_act(gact, gam);
+    }
+    // ---- layer 0: K = 39, both halves from the one resident copy of W0 ([unit][8 blocks]) ------------------
+    __syncthreads();
+    issue_step(++step, slot[cur ^ 1]);
+    {
+        typedef const __attribute__((address_space(3))) bf16x8* lfrag_t;
+        lfrag_t lw = (lfrag_t)slot[cur] + lane;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            CVec<4> acc;
+            s8_bias(acc, net.b[0], half, lane);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const bf16x8 b = gact.f[q];
+#pragma unroll
+                for (int ro = 0; ro < 4; ++ro)
+                    acc.v[ro] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((lw + q * 8 * 64)[(4 * half + ro) * 64], b, acc.v[ro], 0, 0, 0);
+            }
+            s8_epilogue(nact, acc, half);
+        }
+        act = nact;
+    }
+    cur ^= 1;
+    // ---- hidden layers -----------------------------------------------------------------------------
+    for (int l = 1; l < L - 1; ++l) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();  // slot[cur] has landed (vmcnt(0) in front of the barrier); slot[cur^1] is free
+            issue_step(++step, slot[cur ^ 1]);
+            CVec<4> acc;
+            s8_bias(acc, net.b[l], half, lane);
+            if (l == net.skip_layer) s8_mma<4, 10, 256 + 39>(acc, S8Cat<8, 2>(act, gact), slot[cur], lane);
+            else s8_mma<4, 8, 256>(acc, S8Act<8>(act), slot[cur], lane);
+            s8_epilogue(nact, acc, half);
+            cur ^= 1;
+        }
+        act = nact;
+    }
+    // ---- sdf row -----------------------------------------------------------------------------------
+    __syncthreads();
+    CVec<1> o;
+    load_bias(o, net.b[L - 1], lane);
+    s8_mma<1, 8, 256>(o, S8Act<8>(act), slot[cur], lane);
+    if (valid && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+}
+
+}  // namespace
+
+int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(sdf_infer8_kernel, dim3((unsigned)((tiles + S8_WAVES - 1) / S8_WAVES)), dim3(64 * S8_WAVES), 0, st, *net,
+                       src, n, sdf);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}

@@ -69,3 +69,18 @@ def test_sdf_infer_edge_sizes():
         if n:
             full = net.sdf(torch.cat([x, torch.rand(77, 3).cuda()]), prec=nw.PREC_F32)[:n]
             assert torch.equal(out, full)  # a point's result does not depend on its tile mates
+
+
+def test_infer8_pilot_matches_in_a_subprocess():
+    """csrc/ncw_sdf8.hip (the 8-wave / half-layer pilot, opt-in through NCW_SDF_INFER8) must give the same answers:
+    the bf16 inference tests of this file are re-run in a subprocess with the switch on."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("NCW_SDF_INFER8"):
+        pytest.skip("already inside the pilot run")
+    env = dict(os.environ, NCW_SDF_INFER8="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "not subprocess"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
