@@ -25,6 +25,9 @@ NCW_DEV void s8_issue(ncw_lchar* slot, const void* wbase, int units, int ob0) {
     const int lane = threadIdx.x & 63;
     const char* g = reinterpret_cast<const char*>(wbase) + lane * 16;
     const int pieces = units * NB;
+#ifdef S8_NODMA  // timing experiment only
+    return;
+#endif
     for (int pc = wave; pc < pieces; pc += S8_WAVES) {
         const int u = pc / NB, ob = pc - u * NB;
         __builtin_amdgcn_global_load_lds((ncw_gvoid*)(g + (size_t)(u * RB_STRIDE + ob0 + ob) * 1024),
@@ -81,7 +84,11 @@ NCW_DEV void s8_epilogue(Act<PrecBF16, 8>& out, const CVec<4>& acc, int half) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float y, s;
+#ifdef S8_NOSP  // timing experiment only
+            y = __builtin_fmaxf(acc.v[rb][r], 0.f);
+#else
             softplus100<true>(acc.v[rb][r], y, s);
+#endif
             yv[r] = y;
         }
         to_act_block<8>(out, 4 * half + rb, yv);
@@ -145,7 +152,9 @@ __global__ __launch_bounds__(64 * S8_WAVES) void sdf_infer8_kernel(NcwSdfNet net
     for (int l = 1; l < L - 1; ++l) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+#ifndef S8_NOBAR  // timing experiment only
             __syncthreads();  // slot[cur] has landed (vmcnt(0) in front of the barrier); slot[cur^1] is free
+#endif
             issue_step(++step, slot[cur ^ 1]);
             CVec<4> acc;
             s8_bias(acc, net.b[l], half, lane);
