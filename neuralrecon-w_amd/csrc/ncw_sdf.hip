@@ -396,14 +396,17 @@ static bool sdf_net_ok(const NcwSdfNet* net) {
         } else return NCW_E_UNSUPPORTED;                                                                \
     } while (0)
 
-int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);  // ncw_sdf8.hip
+int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant);  // ncw_sdf8.hip
 
 static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, int64_t n, float* sdf, void* stream) {
     if (!sdf_net_ok(net) || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    static const bool pilot8 = getenv("NCW_SDF_INFER8") != nullptr;  // round-2 structure pilot (ncw_sdf8.hip)
-    if (pilot8 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3) return ncw_sdf_infer8_launch(net, src, n, sdf, st);
+    // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (variant 2; 0.20 vs 0.26 ms per 131,072 points).
+    // NCW_SDF_INFER8 = 0 selects the weights-through-LDS kernel below, 1 the 8-wave / half-layer pilot.
+    static const int variant8 = getenv("NCW_SDF_INFER8") ? atoi(getenv("NCW_SDF_INFER8")) : 2;
+    if (variant8 > 0 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
+        return ncw_sdf_infer8_launch(net, src, n, sdf, st, variant8);
     NCW_SDF_DISPATCH(sdf_infer_kernel, *net, src, n, sdf);
     return 0;
 }

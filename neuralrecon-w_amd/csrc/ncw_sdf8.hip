@@ -1,5 +1,7 @@
-// Pilot of the round-2 structure for the fused MLP kernels, on the simplest of them:
-// SDF inference (SDFNetwork.sdf, models/neuconw.py:281-282), bf16, W = 256.
+// SDF inference (SDFNetwork.sdf, models/neuconw.py:281-282), bf16, W = 256: the two structures tried for round 2 of
+// the fused MLP kernels on the simplest of them.  Variant 2 (weights stationary in registers,
+// activations through LDS -- second half of this file) is the DEFAULT inference kernel at W = 256 bf16; variant 1
+// (below) is kept as the measured alternative:
 //   * ONE 8-wave workgroup per CU (<= 256 registers per lane): 256 points share every weight byte that is
 //     streamed L2 -> LDS (the 4-wave kernels re-stream the network for every 128 points), and two waves per
 //     SIMD overlap one wave's Softplus epilogue with the other's MFMAs;
@@ -173,10 +175,155 @@ __global__ __launch_bounds__(64 * S8_WAVES) void sdf_infer8_kernel(NcwSdfNet net
     if (valid && lane < 32) sdf[p] = o.v[0][0] / net.scale;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Variant 2 (default; NCW_SDF_INFER8=2): WEIGHTS STATIONARY IN REGISTERS, ACTIVATIONS THROUGH LDS.
+// A workgroup of 8 waves owns 128 points (4 tiles of 32).  Wave w owns OUTPUT BLOCK w of every hidden layer:
+// its slice of the layer's packed matrix (16 k-units x 1 KiB = 64 registers per lane) is loaded global -> registers,
+// the NEXT layer's slice while the current one is being used (the loads have a whole layer to land), and is reused
+// for the 4 tiles.  The activations of the 128 points live in LDS in B-FRAGMENT form ([tile][k-unit][64 lanes][16 B],
+// 64 KiB, double-buffered): every wave reads all of them (16 ds_read_b128 per tile) and writes the two units of its
+// own output block.  No LDS-DMA, no per-chunk barriers (one barrier per layer), the same LDS read bytes per MFMA
+// as the weights-through-LDS kernels.  The unit order of the packed weights is unchanged: unit 2 rb + t of the
+// next layer IS the bf16 image of registers 8t..8t+7 of C-layout block rb (ncw_common.h), which is what a wave
+// holds in its accumulator.
+// ------------------------------------------------------------------------------------------------
+constexpr int SB_WAVES = 8, SB_TILES = 4;
+constexpr int SB_ACT = SB_TILES * 16 * 1024;   // one activation buffer: 4 tiles x 16 units x 1 KiB
+constexpr int SB_GAM = SB_TILES * 3 * 1024;    // gamma: 3 units per tile
+
+typedef __attribute__((address_space(3))) bf16x8 sb_lfrag;
+
+template <int NU>
+NCW_DEV void sb_load_slice(bf16x8 (&a)[NU], const void* w, int rb_stride, int ob, int u0, int lane) {
+    typedef const __attribute__((address_space(1))) bf16x8* gp;
+    gp g = (gp)w + lane;
+#pragma unroll
+    for (int q = 0; q < NU; ++q) a[q] = g[((size_t)(u0 + q) * rb_stride + ob) * 64];
+}
+
+__global__ __launch_bounds__(64 * SB_WAVES) void sdf_inferB_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                  float* __restrict__ sdf) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_GAM];
+    sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
+    sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
+    sb_lfrag* const gbuf = abuf0 + 2 * SB_ACT / 16;
+    const int lane = ncw_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int L = net.n_layers;
+    const int64_t tile0 = (int64_t)blockIdx.x * SB_TILES;
+    // ---- gamma of the 4 tiles (waves 0..3), straight into LDS as k-units 0..2 --------------------------------
+    if (wave < SB_TILES) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        if (p >= n) p = n - 1;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+        CVec<2> gam;
+        freq_encode<2, 3, 6, true>(gam, xs, lane);
+        Act<PrecBF16, 2> ga;
+        to_act(ga, gam);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gbuf[(wave * 3 + q) * 64 + lane] = ga.f[q];
+    }
+    // ---- layer 0 slice (3 units) and the prefetch of layer 1 ----------------------------------------------
+    bf16x8 wa[16], wb[16], wg[3];      // current slice, next slice, gamma part of the skip layer
+    {
+        bf16x8 w0[3];
+        sb_load_slice<3>(w0, net.w[0], 8, wave, 0, lane);
+        if (L - 1 > 1) sb_load_slice<16>(wa, net.w[1], 8, wave, 0, lane);
+        f32x16 bias;
+        {
+            CVec<1> b1;
+            load_bias(b1, net.b[0] + wave * 32, lane);
+            bias = b1.v[0];
+        }
+        __syncthreads();  // gamma visible
+#pragma unroll
+        for (int t = 0; t < SB_TILES; ++t) {
+            f32x16 acc = bias;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[q], gbuf[(t * 3 + q) * 64 + lane], acc, 0, 0, 0);
+            Act<PrecBF16, 1> o;
+            f32x16 yv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[r], y, s); yv[r] = y; }
+            to_act_block<1>(o, 0, yv);
+            abuf0[(t * 16 + 2 * wave) * 64 + lane] = o.f[0];
+            abuf0[(t * 16 + 2 * wave + 1) * 64 + lane] = o.f[1];
+        }
+    }
+    int cur = 0;
+    // ---- hidden layers 1 .. L-2 ---------------------------------------------------------------------------
+    for (int l = 1; l < L - 1; ++l) {
+        const bool skip = (l == net.skip_layer);
+        if (skip) sb_load_slice<3>(wg, net.w[l], 8, wave, 16, lane);       // units 16..18 = gamma columns
+        if (l + 1 < L - 1) sb_load_slice<16>(wb, net.w[l + 1], 8, wave, 0, lane);  // prefetch the next layer's slice
+        f32x16 bias;
+        {
+            CVec<1> b1;
+            load_bias(b1, net.b[l] + wave * 32, lane);
+            bias = b1.v[0];
+        }
+        __syncthreads();  // layer l-1 outputs of all waves are in abuf[cur]; abuf[cur^1] is free
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {  // two tiles at a time: two independent accumulator chains
+            f32x16 acc0 = bias, acc1 = bias;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+            if (skip) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[(tp * 3 + q) * 64 + lane], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[((tp + 1) * 3 + q) * 64 + lane], acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16& acc = j ? acc1 : acc0;
+                Act<PrecBF16, 1> o;
+                f32x16 yv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[r], y, s); yv[r] = y; }
+                to_act_block<1>(o, 0, yv);
+                out[((tp + j) * 16 + 2 * wave) * 64 + lane] = o.f[0];
+                out[((tp + j) * 16 + 2 * wave + 1) * 64 + lane] = o.f[1];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- sdf row: wave t < 4 takes tile t ------------------------------------------------------------------
+    __syncthreads();
+    if (wave < SB_TILES) {
+        bf16x8 w1[16];
+        sb_load_slice<16>(w1, net.w[L - 1], 1, 0, 0, lane);
+        CVec<1> o;
+        load_bias(o, net.b[L - 1], lane);
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
+        const int64_t p = (tile0 + wave) * 32 + (lane & 31);
+        if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+    }
+}
+
 }  // namespace
 
-int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
+int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant) {
     const int64_t tiles = (n + 31) / 32;
+    if (variant == 2) {
+        hipLaunchKernelGGL(sdf_inferB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st,
+                           *net, src, n, sdf);
+        NCW_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(sdf_infer8_kernel, dim3((unsigned)((tiles + S8_WAVES - 1) / S8_WAVES)), dim3(64 * S8_WAVES), 0, st, *net,
                        src, n, sdf);
     NCW_CHECK_LAUNCH();

@@ -71,16 +71,18 @@ def test_sdf_infer_edge_sizes():
             assert torch.equal(out, full)  # a point's result does not depend on its tile mates
 
 
-def test_infer8_pilot_matches_in_a_subprocess():
-    """csrc/ncw_sdf8.hip (the 8-wave / half-layer pilot, opt-in through NCW_SDF_INFER8) must give the same answers:
-    the bf16 inference tests of this file are re-run in a subprocess with the switch on."""
+@pytest.mark.parametrize("variant", ["0", "1"])
+def test_other_infer_kernels_match_in_a_subprocess(variant):
+    """W = 256 bf16 inference defaults to the weights-stationary kernel (csrc/ncw_sdf8.hip, variant 2); the
+    weights-through-LDS kernel (NCW_SDF_INFER8=0) and the 8-wave / half-layer pilot (=1) must give the same answers:
+    the tests of this file are re-run in a subprocess with the switch set (it is read once per process)."""
     import os
     import subprocess
     import sys
 
-    if os.environ.get("NCW_SDF_INFER8"):
-        pytest.skip("already inside the pilot run")
-    env = dict(os.environ, NCW_SDF_INFER8="1")
+    if os.environ.get("NCW_SDF_INFER8") is not None:
+        pytest.skip("already inside a variant run")
+    env = dict(os.environ, NCW_SDF_INFER8=variant)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "not subprocess"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
