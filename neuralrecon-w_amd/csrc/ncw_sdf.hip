@@ -398,6 +398,9 @@ static bool sdf_net_ok(const NcwSdfNet* net) {
 
 int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant);  // ncw_sdf8.hip
 
+int ncw_sdf_fwd8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
+                        hipStream_t st);  // ncw_sdf8.hip
+
 static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, int64_t n, float* sdf, void* stream) {
     if (!sdf_net_ok(net) || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
@@ -438,6 +441,11 @@ extern "C" int ncw_sdf_fwd(const NcwSdfNet* net, int prec, const NcwPoints* pts,
     if (!sdf_net_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (0.57 vs 0.67 ms per 131,072 points);
+    // NCW_SDF_FWD8=0 selects the weights-through-LDS kernel below
+    static const int fwd8 = getenv("NCW_SDF_FWD8") ? atoi(getenv("NCW_SDF_FWD8")) : 1;
+    if (fwd8 > 0 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
+        return ncw_sdf_fwd8_launch(net, *pts, n, sdf, grad, *stash, st);
     NCW_SDF_DISPATCH(sdf_fwd_kernel, *net, *pts, n, sdf, grad, *stash);
     return 0;
 }

@@ -189,6 +189,13 @@ __global__ __launch_bounds__(64 * S8_WAVES) void sdf_infer8_kernel(NcwSdfNet net
 // holds in its accumulator.
 // ------------------------------------------------------------------------------------------------
 constexpr int SB_WAVES = 8, SB_TILES = 4;
+
+// phi'(z) = 1 - exp(-100 h) from the stashed post-activation h (ncw_sdf.hip load_sprime_block)
+NCW_DEV void load_sprime_block_bf16(f32x16& sv, const __bf16* __restrict__ st_h, size_t tile, int RB, int rb, int lane) {
+    stash_load_block(sv, st_h, tile, RB, rb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = 1.f - __builtin_amdgcn_exp2f(sv[r] * -144.26950408889634f);
+}
 constexpr int SB_ACT = SB_TILES * 16 * 1024;   // one activation buffer: 4 tiles x 16 units x 1 KiB
 constexpr int SB_GAM = SB_TILES * 3 * 1024;    // gamma: 3 units per tile
 
@@ -314,6 +321,248 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_inferB_kernel(NcwSdfNet net
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// sdf_fwd in the weights-stationary structure (NCW_SDF_FWD8): forward chain with the activation stash, feature
+// layer, sdf row, then the analytic adjoint pass a_{l-1} = W_l^T (a_l * phi'(z_l)) with the t_l stash and
+// grad = J_gamma^T g_gamma -- the same arithmetic as sdf_fwd_kernel (ncw_sdf.hip), W = 256 bf16.
+// The two gamma output blocks of the transposed skip layer and of W_0^T are 2 blocks x 4 tiles = 8 jobs:
+// wave w takes block (w & 1) of tile (w >> 1) and keeps that g_gamma block (16 registers) to the end.
+// ------------------------------------------------------------------------------------------------
+NCW_DEV void sb_store_units(sb_lfrag* buf, int t, int ob, const f32x16& v, int lane) {
+    Act<PrecBF16, 1> o;
+    to_act_block<1>(o, 0, v);
+    buf[(t * 16 + 2 * ob) * 64 + lane] = o.f[0];
+    buf[(t * 16 + 2 * ob + 1) * 64 + lane] = o.f[1];
+}
+
+__global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                float* __restrict__ sdf, float* __restrict__ grad,
+                                                                NcwSdfStash st) {
+    typedef __bf16 SE;
+    __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_GAM];
+    sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
+    sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
+    sb_lfrag* const gbuf = abuf0 + 2 * SB_ACT / 16;
+    const int lane = ncw_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int L = net.n_layers;
+    const int64_t tile0 = (int64_t)blockIdx.x * SB_TILES;
+    const int jb = wave & 1, jt = wave >> 1;  // this wave's gamma job: block jb of tile jt
+    if (wave < SB_TILES) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        if (p >= n) p = n - 1;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+        CVec<2> gam;
+        freq_encode<2, 3, 6, true>(gam, xs, lane);
+        stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        Act<PrecBF16, 2> ga;
+        to_act(ga, gam);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gbuf[(wave * 3 + q) * 64 + lane] = ga.f[q];
+    }
+    bf16x8 wa[16], wb[16], wg[3];
+    auto bias_block = [&](const float* bp) {
+        CVec<1> b1;
+        load_bias(b1, bp + wave * 32, lane);
+        return b1.v[0];
+    };
+    // ---- layer 0 ------------------------------------------------------------------------------------
+    {
+        bf16x8 w0[3];
+        sb_load_slice<3>(w0, net.w[0], 8, wave, 0, lane);
+        sb_load_slice<16>(wa, L - 1 > 1 ? net.w[1] : net.w_feat, 8, wave, 0, lane);
+        const f32x16 bias = bias_block(net.b[0]);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < SB_TILES; ++t) {
+            f32x16 acc = bias;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[q], gbuf[(t * 3 + q) * 64 + lane], acc, 0, 0, 0);
+            f32x16 yv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[r], y, s); yv[r] = y; }
+            stash_store_block((SE*)st.h[1], (size_t)(tile0 + t), 8, wave, yv, lane);
+            sb_store_units(abuf0, t, wave, yv, lane);
+        }
+    }
+    int cur = 0;
+    // ---- hidden layers 1 .. L-2 (wa = slice of w[l]) ---------------------------------------------------
+    for (int l = 1; l < L - 1; ++l) {
+        const bool skip = (l == net.skip_layer);
+        if (skip) sb_load_slice<3>(wg, net.w[l], 8, wave, 16, lane);
+        sb_load_slice<16>(wb, l + 1 < L - 1 ? net.w[l + 1] : net.w_feat, 8, wave, 0, lane);  // next: hidden or feature layer
+        const f32x16 bias = bias_block(net.b[l]);
+        __syncthreads();
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 acc0 = bias, acc1 = bias;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+            if (skip) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[(tp * 3 + q) * 64 + lane], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[((tp + 1) * 3 + q) * 64 + lane], acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16& acc = j ? acc1 : acc0;
+                f32x16 yv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[r], y, s); yv[r] = y; }
+                stash_store_block((SE*)st.h[l + 1], (size_t)(tile0 + tp + j), 8, wave, yv, lane);
+                sb_store_units(out, tp + j, wave, yv, lane);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- feature layer (wa = slice of w_feat) and sdf row; prefetch the adjoint's first slice ---------------
+    {
+        bf16x8 wt1 = ((const __attribute__((address_space(1))) bf16x8*)net.wt[L - 1])[(size_t)wave * 64 + lane];  // unit 0, block ob
+        if (L - 2 >= 1) sb_load_slice<16>(wb, net.wt[L - 2], (L - 2 == net.skip_layer) ? 10 : 8, wave, 0, lane);
+        const f32x16 bias = bias_block(net.b_feat);
+        __syncthreads();  // h_{L-1} complete in abuf[cur]
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 acc0 = bias, acc1 = bias;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+            stash_store_block((SE*)st.feat, (size_t)(tile0 + tp), 8, wave, acc0, lane);
+            stash_store_block((SE*)st.feat, (size_t)(tile0 + tp + 1), 8, wave, acc1, lane);
+        }
+        if (wave < SB_TILES) {
+            bf16x8 w1[16];
+            sb_load_slice<16>(w1, net.w[L - 1], 1, 0, 0, lane);
+            CVec<1> o;
+            load_bias(o, net.b[L - 1], lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
+            const int64_t p = (tile0 + wave) * 32 + (lane & 31);
+            if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+        }
+        // ---- adjoint start: a_{L-2} = W_{L-1}^T e_0 (the same for every point); t_{L-2} = a * phi'(z_{L-2}) ----
+        bf16x8 e0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) e0f[e] = (__bf16)0.f;
+        e0f[0] = (__bf16)(lane < 32 ? 1.f : 0.f);
+        f32x16 a0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0[r] = 0.f;
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt1, e0f, a0, 0, 0, 0);
+        sb_lfrag* out = cur ? abuf0 : abuf1;  // free: its readers finished before the barrier above
+#pragma unroll
+        for (int t = 0; t < SB_TILES; ++t) {
+            f32x16 sv;
+            load_sprime_block_bf16(sv, (const SE*)st.h[L - 1], (size_t)(tile0 + t), 8, wave, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] *= a0[r];
+            stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 8, wave, sv, lane);
+            sb_store_units(out, t, wave, sv, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- adjoint layers l = L-2 .. 1: t_{l-1} = (W_l^T t_l) * phi'(z_{l-1});  wa = slice of wt[l] ---------------
+    f32x16 gg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gg[r] = 0.f;
+    for (int l = L - 2; l >= 1; --l) {
+        const bool skip = (l == net.skip_layer);
+        const int stride = skip ? 10 : 8;
+        (void)stride;
+        if (!skip && l - 1 >= 1) sb_load_slice<16>(wb, net.wt[l - 1], (l - 1 == net.skip_layer) ? 10 : 8, wave, 0, lane);
+        __syncthreads();  // t_l complete in abuf[cur]
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16& acc = j ? acc1 : acc0;
+                f32x16 sv;
+                load_sprime_block_bf16(sv, (const SE*)st.h[l], (size_t)(tile0 + tp + j), 8, wave, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[r] *= acc[r];
+                stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + tp + j), 8, wave, sv, lane);
+                sb_store_units(out, tp + j, wave, sv, lane);
+            }
+        }
+        if (skip) {  // the gamma columns of the transposed skip layer: out-blocks 8, 9 (one (block, tile) job per wave)
+            sb_load_slice<16>(wb, net.wt[l], 10, 8 + jb, 0, lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) gg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[q], in[(jt * 16 + q) * 64 + lane], gg, 0, 0, 0);
+            if (l - 1 >= 1) sb_load_slice<16>(wb, net.wt[l - 1], (l - 1 == net.skip_layer) ? 10 : 8, wave, 0, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- adjoint layer 0: g_gamma += W_0^T t_0 (2 out-blocks), then grad = J_gamma^T g_gamma -----------------------
+    sb_load_slice<16>(wb, net.wt[0], 2, jb, 0, lane);
+    __syncthreads();
+    {
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) gg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[q], in[(jt * 16 + q) * 64 + lane], gg, 0, 0, 0);
+    }
+    int64_t p = (tile0 + jt) * 32 + (lane & 31), ray;
+    const bool valid = p < n;
+    if (!valid) p = n - 1;
+    float xs[3];
+    load_point(src, p, xs, ray);
+    xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f0 = 32 * jb + ncw_feat_of(r, 0);
+        if (f0 >= 39) continue;  // (block 1 holds features 32..38 only)
+        int comp;
+        const float dv = freq_feature_deriv<3, 6, true>(xs, f0 + 4 * h, comp);
+        const float c = gg[r] * dv;
+        nx += comp == 0 ? c : 0.f;
+        ny += comp == 1 ? c : 0.f;
+        nz += comp == 2 ? c : 0.f;
+    }
+    nx = half_pair_sum(nx); ny = half_pair_sum(ny); nz = half_pair_sum(nz);
+    // combine the two blocks of a tile (waves 2 jt and 2 jt + 1) through LDS (the gamma region is free now)
+    typedef __attribute__((address_space(3))) float lfloat;
+    lfloat* part = (lfloat*)gbuf;
+    if (jb == 1 && lane < 32) {
+        part[(jt * 32 + lane) * 3 + 0] = nx; part[(jt * 32 + lane) * 3 + 1] = ny; part[(jt * 32 + lane) * 3 + 2] = nz;
+    }
+    __syncthreads();
+    if (jb == 0 && lane < 32 && valid) {
+        grad[p * 3 + 0] = nx + part[(jt * 32 + lane) * 3 + 0];
+        grad[p * 3 + 1] = ny + part[(jt * 32 + lane) * 3 + 1];
+        grad[p * 3 + 2] = nz + part[(jt * 32 + lane) * 3 + 2];
+    }
+}
+
 }  // namespace
 
 int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant) {
@@ -326,6 +575,15 @@ int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n,
     }
     hipLaunchKernelGGL(sdf_infer8_kernel, dim3((unsigned)((tiles + S8_WAVES - 1) / S8_WAVES)), dim3(64 * S8_WAVES), 0, st, *net,
                        src, n, sdf);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+int ncw_sdf_fwd8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
+                        hipStream_t st) {
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(sdf_fwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src,
+                       n, sdf, grad, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }

@@ -67,3 +67,19 @@ def test_sdf_train_bf16(W, n_layers, skip):
     worst = max(rel_err(got[k], gref[k]) for k in gref)
     print("bf16 W=%d worst param-grad rel err %.3e" % (W, worst))
     assert worst < 0.25
+
+
+def test_weights_through_lds_forward_kernel_in_a_subprocess():
+    """W = 256 bf16 defaults to the weights-stationary sdf_fwd (csrc/ncw_sdf8.hip); the weights-through-LDS kernel
+    (NCW_SDF_FWD8=0, the only one for f32 and other widths) must stay correct at that shape too: the tests of this
+    file are re-run in a subprocess with the switch set (it is read once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("NCW_SDF_FWD8") is not None:
+        pytest.skip("already inside a variant run")
+    env = dict(os.environ, NCW_SDF_FWD8="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "not subprocess"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
