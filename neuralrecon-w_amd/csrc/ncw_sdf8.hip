@@ -563,6 +563,226 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// nerf_fwd (models/nerf.py:86-183 on the inverted-sphere points of renderer.py:176-186) in the weights-stationary
+// structure, W = 256 bf16 (NCW_NERF_FWD8): trunk with the gamma(p) skip, density, feature layer, appearance head,
+// raw rgb -- the same arithmetic and stash as nerf_fwd_kernel (ncw_nerf.hip).  The 128-wide head layers are
+// 4 output blocks x 4 tiles: wave w takes block (w & 3) for the tile pair (w >> 2).
+// xbuf ([4 tiles][6 units]) holds gamma(p) during the trunk and AUX1 = [gamma(dir) | appearance code] for the head.
+// ------------------------------------------------------------------------------------------------
+constexpr int SB_X = SB_TILES * 6 * 1024;
+
+NCW_DEV void inverted_sphere8(const float (&x)[3], float (&p4)[4]) {  // renderer.py:181-186
+    float r = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    r = fminf(fmaxf(r, 1.0f), 1e10f);
+    p4[0] = x[0] / r; p4[1] = x[1] / r; p4[2] = x[2] / r; p4[3] = 1.0f / r;
+}
+
+__global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net, NcwPoints src, const float* __restrict__ x4,
+                                                                 int64_t n, const float* __restrict__ a,
+                                                                 float* __restrict__ density, float* __restrict__ rgb,
+                                                                 NcwNerfStash st) {
+    typedef __bf16 SE;
+    __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_X];
+    sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
+    sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
+    sb_lfrag* const xbuf = abuf0 + 2 * SB_ACT / 16;
+    const int lane = ncw_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile0 = (int64_t)blockIdx.x * SB_TILES;
+    const int D = net.D;
+    int64_t pp = 0;
+    bool pvalid = false;
+    if (wave < SB_TILES) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        pvalid = p < n;
+        if (!pvalid) p = n - 1;
+        pp = p;
+        float p4[4];
+        if (x4) {
+            p4[0] = x4[p * 4 + 0]; p4[1] = x4[p * 4 + 1]; p4[2] = x4[p * 4 + 2]; p4[3] = x4[p * 4 + 3];
+            ray = p;
+        } else {
+            float xs[3];
+            load_point(src, p, xs, ray);
+            inverted_sphere8(xs, p4);
+        }
+        const float dir[3] = {src.rays_d[ray * 3 + 0], src.rays_d[ray * 3 + 1], src.rays_d[ray * 3 + 2]};
+        CVec<3> gp;
+        freq_encode<3, 4, 10, true>(gp, p4, lane);
+        stash_store<3>((SE*)st.gp, (size_t)(tile0 + wave), gp, lane);
+        Act<PrecBF16, 3> gpa;
+        to_act(gpa, gp);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) xbuf[(wave * 6 + q) * 64 + lane] = gpa.f[q];
+        CVec<3> aux1;
+        build_aux1<true>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
+        stash_store<3>((SE*)st.aux1, (size_t)(tile0 + wave), aux1, lane);  // re-read for the head (same bf16 values)
+    }
+    bf16x8 wa[16], wb[16], wx[6];
+    auto bias_of = [&](const float* bp, int ob) {
+        CVec<1> b1;
+        load_bias(b1, bp + ob * 32, lane);
+        return b1.v[0];
+    };
+    auto relu16 = [](const f32x16& v) {
+        f32x16 y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = fmaxf(v[r], 0.f);
+        return y;
+    };
+    // ---- trunk layer 0 (K = 84: the 6 units of gamma(p)) ---------------------------------------------------
+    {
+        bf16x8 w0[6];
+        sb_load_slice<6>(w0, net.w_p[0], 8, wave, 0, lane);
+        sb_load_slice<16>(wa, D > 1 ? net.w_p[1] : net.w_feat, 8, wave, 0, lane);
+        const f32x16 bias = bias_of(net.b_p[0], wave);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < SB_TILES; ++t) {
+            f32x16 acc = bias;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[q], xbuf[(t * 6 + q) * 64 + lane], acc, 0, 0, 0);
+            const f32x16 y = relu16(acc);
+            stash_store_block((SE*)st.h[1], (size_t)(tile0 + t), 8, wave, y, lane);
+            sb_store_units(abuf0, t, wave, y, lane);
+        }
+    }
+    int cur = 0;
+    // ---- trunk layers 1 .. D-1 -----------------------------------------------------------------------------
+    for (int i = 1; i < D; ++i) {
+        const bool skip = (i == net.skip + 1);
+        if (skip) sb_load_slice<6>(wx, net.w_p[i], 8, wave, 16, lane);  // units 16..21 = the gamma(p) columns
+        sb_load_slice<16>(wb, i + 1 < D ? net.w_p[i + 1] : net.w_feat, 8, wave, 0, lane);
+        const f32x16 bias = bias_of(net.b_p[i], wave);
+        __syncthreads();
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 acc0 = bias, acc1 = bias;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+            if (skip) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], xbuf[(tp * 6 + q) * 64 + lane], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], xbuf[((tp + 1) * 6 + q) * 64 + lane], acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 y = relu16(j ? acc1 : acc0);
+                stash_store_block((SE*)st.h[i + 1], (size_t)(tile0 + tp + j), 8, wave, y, lane);
+                sb_store_units(out, tp + j, wave, y, lane);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- density (waves 0..3), feature layer (wa = slice of w_feat), AUX1 into xbuf -------------------------------
+    const int hb = wave & 3, hp = wave >> 2;  // head job: block hb, tiles 2 hp and 2 hp + 1
+    {
+        sb_load_slice<16>(wb, net.w_a[0], 4, hb, 0, lane);   // head layer 0: feature columns
+        sb_load_slice<6>(wx, net.w_a[0], 4, hb, 16, lane);   //               AUX1 columns (units 16..21)
+        const f32x16 bias = bias_of(net.b_feat, wave);
+        __syncthreads();  // h_D complete in abuf[cur]; nobody reads gamma(p) in xbuf any more
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+        if (wave < SB_TILES) {
+            {
+                CVec<3> aux1;
+                stash_load<3>(aux1, (const SE*)st.aux1, (size_t)(tile0 + wave), lane);
+                Act<PrecBF16, 3> aux1a;
+                to_act(aux1a, aux1);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) xbuf[(wave * 6 + q) * 64 + lane] = aux1a.f[q];
+            }
+            bf16x8 w1[16];
+            sb_load_slice<16>(w1, net.w_alpha, 1, 0, 0, lane);
+            CVec<1> o;
+            load_bias(o, net.b_alpha, lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
+            if (pvalid && lane < 32) density[pp] = o.v[0][0];
+        }
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 acc0 = bias, acc1 = bias;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+            stash_store_block((SE*)st.featn, (size_t)(tile0 + tp), 8, wave, acc0, lane);
+            stash_store_block((SE*)st.featn, (size_t)(tile0 + tp + 1), 8, wave, acc1, lane);
+            sb_store_units(out, tp, wave, acc0, lane);
+            sb_store_units(out, tp + 1, wave, acc1, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- appearance head (nerf.py:131-139,173-174): layer 0 takes [feature | AUX1], the others 128 -> 128 ---------
+    for (int i = 0; i < net.n_head; ++i) {
+        bf16x8 wn[8];
+        if (i + 1 < net.n_head) sb_load_slice<8>(wn, net.w_a[i + 1], 4, hb, 0, lane);
+        const f32x16 bias = bias_of(net.b_a[i], hb);
+        __syncthreads();
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+        const int ta = 2 * hp, tb = 2 * hp + 1;
+        f32x16 acc0 = bias, acc1 = bias;
+        if (i == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(ta * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tb * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], xbuf[(ta * 6 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], xbuf[(tb * 6 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(ta * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tb * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+        }
+        const f32x16 y0 = relu16(acc0), y1 = relu16(acc1);
+        stash_store_block((SE*)st.e[i], (size_t)(tile0 + ta), 4, hb, y0, lane);
+        stash_store_block((SE*)st.e[i], (size_t)(tile0 + tb), 4, hb, y1, lane);
+        sb_store_units(out, ta, hb, y0, lane);
+        sb_store_units(out, tb, hb, y1, lane);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wa[q] = wn[q];
+        cur ^= 1;
+    }
+    // ---- raw rgb (nerf.py:181), waves 0..3 ---------------------------------------------------------------------
+    __syncthreads();
+    if (wave < SB_TILES) {
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        bf16x8 w1[8];
+        sb_load_slice<8>(w1, net.w_rgb, 1, 0, 0, lane);
+        CVec<1> o;
+        load_bias(o, net.b_rgb, lane);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
+        if (pvalid && lane < 32) {
+            rgb[pp * 3 + 0] = o.v[0][0];
+            rgb[pp * 3 + 1] = o.v[0][1];
+            rgb[pp * 3 + 2] = o.v[0][2];
+        }
+    }
+}
+
 }  // namespace
 
 int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant) {
@@ -584,6 +804,15 @@ int ncw_sdf_fwd8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, f
     const int64_t tiles = (n + 31) / 32;
     hipLaunchKernelGGL(sdf_fwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src,
                        n, sdf, grad, stash);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+int ncw_nerf_fwd8_launch(const NcwNerfNet* net, const NcwPoints& src, const float* x4, int64_t n, const float* a, float* density,
+                         float* rgb, const NcwNerfStash& stash, hipStream_t st) {
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(nerf_fwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src,
+                       x4, n, a, density, rgb, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }
