@@ -6,6 +6,8 @@
 
 int ncw_nerf_fwd8_launch(const NcwNerfNet* net, const NcwPoints& src, const float* x4, int64_t n, const float* a, float* density,
                          float* rgb, const NcwNerfStash& stash, hipStream_t st);  // ncw_sdf8.hip
+int ncw_nerf_bwd8_launch(const NcwNerfNet* net, const NcwPoints& src, int64_t n, const float* d_density, const float* d_rgb,
+                         float* d_a, const NcwNerfStash& stash, hipStream_t st);
 
 // 4-D inverted-sphere point (renderer.py:181-186): r = clip(|p|, 1, 1e10); p4 = [p / r, 1 / r]
 NCW_DEV void inverted_sphere(const float (&x)[3], float (&p4)[4]) {
@@ -261,6 +263,11 @@ extern "C" int ncw_nerf_bwd(const NcwNerfNet* net, int prec, const NcwPoints* pt
     if (!nerf_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (0.44 vs 0.49 ms per 135,168 points);
+    // NCW_NERF_BWD8=0 selects the weights-through-LDS kernel below
+    static const int bwd8 = getenv("NCW_NERF_BWD8") ? atoi(getenv("NCW_NERF_BWD8")) : 1;
+    if (bwd8 > 0 && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 && net->n_head <= 4)
+        return ncw_nerf_bwd8_launch(net, *pts, n, d_density, d_rgb, d_a, *stash, st);
     NCW_NERF_DISPATCH(nerf_bwd_kernel, *net, *pts, n, d_density, d_rgb, d_a, *stash);
     return 0;
 }

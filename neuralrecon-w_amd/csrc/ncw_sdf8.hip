@@ -202,7 +202,7 @@ constexpr int SB_GAM = SB_TILES * 3 * 1024;    // gamma: 3 units per tile
 typedef __attribute__((address_space(3))) bf16x8 sb_lfrag;
 
 template <int NU>
-NCW_DEV void sb_load_slice(bf16x8 (&a)[NU], const void* w, int rb_stride, int ob, int u0, int lane) {
+NCW_DEV void sb_load_slice(bf16x8* a, const void* w, int rb_stride, int ob, int u0, int lane) {
     typedef const __attribute__((address_space(1))) bf16x8* gp;
     gp g = (gp)w + lane;
 #pragma unroll
@@ -783,6 +783,214 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// nerf_bwd in the weights-stationary structure (NCW_NERF_BWD8), W = 256 bf16: the data-gradient chain of
+// nerf_bwd_kernel (ncw_nerf.hip) -- rgb head reversed, appearance head, feature / density, trunk -- emitting the
+// z-bar stashes the weight-gradient GEMMs read and the per-ray appearance-code gradient d_a.
+// ------------------------------------------------------------------------------------------------
+NCW_DEV f32x16 sb_relu_bwd(const f32x16& u, const __bf16* __restrict__ st_y, size_t tile, int RB, int rb, int lane) {
+    f32x16 y, z;
+    stash_load_block(y, st_y, tile, RB, rb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = y[r] > 0.f ? u[r] : 0.f;
+    return z;
+}
+
+// d_a[ray][j] += sum over the tile's points of block rb of the AUX1 adjoint (features 27 .. 27 + n_a), as accumulate_d_a
+NCW_DEV void sb_accumulate_d_a(int rb, const f32x16& q, float* __restrict__ d_a, int64_t ray, int n_a, bool valid, int lane) {
+    const int h = lane >> 5;
+    const int64_t r0 = __shfl(ray, 0, 64);
+    const bool uniform = __all((ray == r0) ? 1 : 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = 32 * rb + ncw_feat_of(r, 0) + 4 * h;
+        const int j = f - 27;
+        float v = valid ? q[r] : 0.f;
+        if (uniform) {
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o, 64);
+            if ((lane & 31) == 0 && j >= 0 && j < n_a) atomicAdd(d_a + ray * n_a + j, v);
+        } else {
+            if (valid && j >= 0 && j < n_a) atomicAdd(d_a + ray * n_a + j, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net, NcwPoints src, int64_t n,
+                                                                 const float* __restrict__ d_density,
+                                                                 const float* __restrict__ d_rgb, float* __restrict__ d_a,
+                                                                 NcwNerfStash st) {
+    typedef __bf16 SE;
+    __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_X];
+    sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
+    sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
+    sb_lfrag* const xbuf = abuf0 + 2 * SB_ACT / 16;   // unit 0 of a tile: d_rgb block, unit 1: d_density block
+    const int lane = ncw_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile0 = (int64_t)blockIdx.x * SB_TILES;
+    const int D = net.D, NH = net.n_head;
+    const int hb = wave & 3, hp = wave >> 2, ta = 2 * hp, tb = 2 * hp + 1;
+    typedef const __attribute__((address_space(1))) bf16x8* gfrag;
+    if (wave < SB_TILES) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31);
+        const bool valid = p < n;
+        if (!valid) p = n - 1;
+        const float vm = valid ? 1.f : 0.f;
+        CVec<1> zr, zal;
+        cvec_zero(zr);
+        cvec_zero(zal);
+        if (lane < 32) {
+            zr.v[0][0] = d_rgb[p * 3 + 0] * vm;
+            zr.v[0][1] = d_rgb[p * 3 + 1] * vm;
+            zr.v[0][2] = d_rgb[p * 3 + 2] * vm;
+            zal.v[0][0] = d_density[p] * vm;
+        }
+        stash_store<1>((SE*)st.zrgb, (size_t)(tile0 + wave), zr, lane);
+        stash_store<1>((SE*)st.zalpha, (size_t)(tile0 + wave), zal, lane);
+        Act<PrecBF16, 1> za1;
+        to_act(za1, zr);
+        xbuf[(wave * 6 + 0) * 64 + lane] = za1.f[0];
+        to_act(za1, zal);
+        xbuf[(wave * 6 + 1) * 64 + lane] = za1.f[0];
+    }
+    bf16x8 wa[16], wb[16];
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    int cur = 0;
+    // ---- appearance head reversed: wave = (block hb, tiles ta, tb) -------------------------------------------------
+    f32x16 ue0, ue1;
+    {
+        const bf16x8 wr = ((gfrag)net.wt_rgb)[(size_t)hb * 64 + lane];  // wt_rgb: 4 out-blocks, unit 0 (K = 3)
+        if (NH > 1) sb_load_slice<8>(wa, net.wt_a[NH - 1], 4, hb, 0, lane);
+        else sb_load_slice<8>(wa, net.wt_a[0], 11, wave, 0, lane);
+        __syncthreads();  // d_rgb / d_density units visible
+        ue0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr, xbuf[(ta * 6 + 0) * 64 + lane], zero16, 0, 0, 0);
+        ue1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr, xbuf[(tb * 6 + 0) * 64 + lane], zero16, 0, 0, 0);
+    }
+    for (int i = NH - 1; i >= 1; --i) {
+        sb_lfrag* out = cur ? abuf1 : abuf0;
+        const f32x16 z0 = sb_relu_bwd(ue0, (const SE*)st.e[i], (size_t)(tile0 + ta), 4, hb, lane);
+        const f32x16 z1 = sb_relu_bwd(ue1, (const SE*)st.e[i], (size_t)(tile0 + tb), 4, hb, lane);
+        stash_store_block((SE*)st.ze[i], (size_t)(tile0 + ta), 4, hb, z0, lane);
+        stash_store_block((SE*)st.ze[i], (size_t)(tile0 + tb), 4, hb, z1, lane);
+        sb_store_units(out, ta, hb, z0, lane);
+        sb_store_units(out, tb, hb, z1, lane);
+        if (i - 1 >= 1) sb_load_slice<8>(wb, net.wt_a[i - 1], 4, hb, 0, lane);
+        else sb_load_slice<8>(wb, net.wt_a[0], 11, wave, 0, lane);  // next: q = wt_a[0] ze_0, block = wave
+        __syncthreads();
+        ue0 = zero16; ue1 = zero16;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            ue0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], out[(ta * 16 + q) * 64 + lane], ue0, 0, 0, 0);
+            ue1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], out[(tb * 16 + q) * 64 + lane], ue1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- ze_0, then q = wt_a[0] ze_0: blocks 0..7 = d(feature) (block = wave), blocks 8..10 = AUX1 adjoint -> d_a -----
+    {
+        sb_lfrag* out = cur ? abuf1 : abuf0;
+        const f32x16 z0 = sb_relu_bwd(ue0, (const SE*)st.e[0], (size_t)(tile0 + ta), 4, hb, lane);
+        const f32x16 z1 = sb_relu_bwd(ue1, (const SE*)st.e[0], (size_t)(tile0 + tb), 4, hb, lane);
+        stash_store_block((SE*)st.ze[0], (size_t)(tile0 + ta), 4, hb, z0, lane);
+        stash_store_block((SE*)st.ze[0], (size_t)(tile0 + tb), 4, hb, z1, lane);
+        sb_store_units(out, ta, hb, z0, lane);
+        sb_store_units(out, tb, hb, z1, lane);
+        sb_load_slice<16>(wb, net.wt_feat, 8, wave, 0, lane);  // next: u = wt_feat zf
+        __syncthreads();
+        const sb_lfrag* in = out;
+        sb_lfrag* out2 = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 a0 = zero16, a1 = zero16;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], a1, 0, 0, 0);
+            }
+            stash_store_block((SE*)st.zfeat, (size_t)(tile0 + tp), 8, wave, a0, lane);
+            stash_store_block((SE*)st.zfeat, (size_t)(tile0 + tp + 1), 8, wave, a1, lane);
+            sb_store_units(out2, tp, wave, a0, lane);
+            sb_store_units(out2, tp + 1, wave, a1, lane);
+        }
+        // the 3 AUX1 blocks x 4 tiles = 12 jobs: wave w takes jobs w and w + 8
+        for (int j = wave; j < 12; j += SB_WAVES) {
+            const int b = j % 3, t = j / 3;
+            bf16x8 wq[8];
+            sb_load_slice<8>(wq, net.wt_a[0], 11, 8 + b, 0, lane);
+            f32x16 qa = zero16;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) qa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[q], in[(t * 16 + q) * 64 + lane], qa, 0, 0, 0);
+            int64_t p = (tile0 + t) * 32 + (lane & 31);
+            const bool valid = p < n;
+            if (!valid) p = n - 1;
+            const int64_t ray = (src.mode == 0) ? p : p / src.per_ray;
+            sb_accumulate_d_a(b, qa, d_a, ray, net.n_a, valid, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;  // zf lives in out2
+    }
+    // ---- u = wt_feat zf + wt_alpha d_density;  za_{D-1} = relu'(h_D) u --------------------------------------------
+    {
+        const bf16x8 wal = ((gfrag)net.wt_alpha)[(size_t)wave * 64 + lane];  // wt_alpha: 8 out-blocks, unit 0 (K = 1)
+        if (D - 1 > 0) sb_load_slice<16>(wb, net.wt_p[D - 1], (D - 1 == net.skip + 1) ? 11 : 8, wave, 0, lane);
+        __syncthreads();  // zf complete
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 u0 = zero16, u1 = zero16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], u1, 0, 0, 0);
+            }
+            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wal, xbuf[(tp * 6 + 1) * 64 + lane], u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wal, xbuf[((tp + 1) * 6 + 1) * 64 + lane], u1, 0, 0, 0);
+            const f32x16 z0 = sb_relu_bwd(u0, (const SE*)st.h[D], (size_t)(tile0 + tp), 8, wave, lane);
+            const f32x16 z1 = sb_relu_bwd(u1, (const SE*)st.h[D], (size_t)(tile0 + tp + 1), 8, wave, lane);
+            stash_store_block((SE*)st.zp[D - 1], (size_t)(tile0 + tp), 8, wave, z0, lane);
+            stash_store_block((SE*)st.zp[D - 1], (size_t)(tile0 + tp + 1), 8, wave, z1, lane);
+            sb_store_units(out, tp, wave, z0, lane);
+            sb_store_units(out, tp + 1, wave, z1, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- trunk reversed: za_{i-1} = relu'(h_i) (wt_p[i] za_i), i = D-1 .. 1 (wa = slice of wt_p[i]) ----------------------
+    for (int i = D - 1; i >= 1; --i) {
+        if (i - 1 >= 1) sb_load_slice<16>(wb, net.wt_p[i - 1], (i - 1 == net.skip + 1) ? 11 : 8, wave, 0, lane);
+        __syncthreads();
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 u0 = zero16, u1 = zero16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], u1, 0, 0, 0);
+            }
+            const f32x16 z0 = sb_relu_bwd(u0, (const SE*)st.h[i], (size_t)(tile0 + tp), 8, wave, lane);
+            const f32x16 z1 = sb_relu_bwd(u1, (const SE*)st.h[i], (size_t)(tile0 + tp + 1), 8, wave, lane);
+            stash_store_block((SE*)st.zp[i - 1], (size_t)(tile0 + tp), 8, wave, z0, lane);
+            stash_store_block((SE*)st.zp[i - 1], (size_t)(tile0 + tp + 1), 8, wave, z1, lane);
+            if (i - 1 >= 1) {
+                sb_store_units(out, tp, wave, z0, lane);
+                sb_store_units(out, tp + 1, wave, z1, lane);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+}
+
 }  // namespace
 
 int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant) {
@@ -813,6 +1021,15 @@ int ncw_nerf_fwd8_launch(const NcwNerfNet* net, const NcwPoints& src, const floa
     const int64_t tiles = (n + 31) / 32;
     hipLaunchKernelGGL(nerf_fwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src,
                        x4, n, a, density, rgb, stash);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+int ncw_nerf_bwd8_launch(const NcwNerfNet* net, const NcwPoints& src, int64_t n, const float* d_density, const float* d_rgb,
+                         float* d_a, const NcwNerfStash& stash, hipStream_t st) {
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(nerf_bwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src, n,
+                       d_density, d_rgb, d_a, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }
