@@ -991,6 +991,196 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// sdf_bwd in the weights-stationary structure (NCW_SDF_BWD8), W = 256 bf16: (1) backward of the adjoint pass
+// l = 0 .. L-2 (tbar = W qbar, abar = tbar phi', zbar2 = tbar 100 t (1 - phi')), (2) backward of the forward pass
+// l = L-1 .. 0 (ubar = W^T zbar, zbar = ubar phi' + zbar2) -- the arithmetic and the stash of sdf_bwd_kernel.
+// gbuf: units 0..2 of a tile = qbar_0 = J_gamma nbar, unit 3 = the d_sdf block.
+// ------------------------------------------------------------------------------------------------
+constexpr int SB_G4 = SB_TILES * 4 * 1024;
+
+__global__ __launch_bounds__(64 * SB_WAVES) void sdf_bwdB_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                const float* __restrict__ d_sdf,
+                                                                const float* __restrict__ d_grad, NcwSdfStash st) {
+    typedef __bf16 SE;
+    __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_G4];
+    sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
+    sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
+    sb_lfrag* const gbuf = abuf0 + 2 * SB_ACT / 16;
+    const int lane = ncw_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int L = net.n_layers;
+    const int64_t tile0 = (int64_t)blockIdx.x * SB_TILES;
+    typedef const __attribute__((address_space(1))) bf16x8* gfrag;
+    if (wave < SB_TILES) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        const bool valid = p < n;
+        if (!valid) p = n - 1;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+        const float vmask = valid ? 1.f : 0.f;  // padded lanes must contribute nothing to weight grads
+        const float nb[3] = {d_grad[p * 3 + 0] * vmask, d_grad[p * 3 + 1] * vmask, d_grad[p * 3 + 2] * vmask};
+        const float dsdf = d_sdf[p] * vmask / net.scale;
+        const int h = lane >> 5;
+        CVec<2> q0;  // qbar_0 = J_gamma nbar
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (32 * rb + ncw_feat_of(r, 0) >= 39) {
+                    q0.v[rb][r] = 0.f;
+                    continue;
+                }
+                int comp;
+                const float dv = freq_feature_deriv<3, 6, true>(xs, 32 * rb + ncw_feat_of(r, 0) + 4 * h, comp);
+                q0.v[rb][r] = dv * (comp == 0 ? nb[0] : (comp == 1 ? nb[1] : nb[2]));
+            }
+        stash_store<2>((SE*)st.qbar[0], (size_t)(tile0 + wave), q0, lane);
+        Act<PrecBF16, 2> q0a;
+        to_act(q0a, q0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gbuf[(wave * 4 + q) * 64 + lane] = q0a.f[q];
+        CVec<1> zs, one;
+        cvec_zero(zs);
+        cvec_zero(one);
+        zs.v[0][0] = (lane < 32) ? dsdf : 0.f;
+        one.v[0][0] = (lane < 32) ? vmask : 0.f;
+        stash_store<1>((SE*)st.zsdf, (size_t)(tile0 + wave), zs, lane);
+        stash_store<1>((SE*)st.one, (size_t)(tile0 + wave), one, lane);
+        Act<PrecBF16, 1> zsa;
+        to_act(zsa, zs);
+        gbuf[(wave * 4 + 3) * 64 + lane] = zsa.f[0];
+    }
+    bf16x8 wa[16], wb[16], wg[3];
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    // one output block of a tile pair: (tbar) -> zbar2_l (temporarily in zbar[l]), abar_l = qbar_{l+1} (stash + LDS)
+    auto adj_epilogue = [&](const f32x16& tbar, int l, int t, sb_lfrag* out) {
+        f32x16 sv, tv, z2, ab;
+        load_sprime_block_bf16(sv, (const SE*)st.h[l + 1], (size_t)(tile0 + t), 8, wave, lane);
+        stash_load_block(tv, (const SE*)st.t[l], (size_t)(tile0 + t), 8, wave, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            z2[r] = tbar[r] * 100.f * tv[r] * (1.f - sv[r]);  // a_l phi''(z_l) = 100 t_l (1 - s_l)
+            ab[r] = tbar[r] * sv[r];
+        }
+        stash_store_block((SE*)st.zbar[l], (size_t)(tile0 + t), 8, wave, z2, lane);
+        stash_store_block((SE*)st.qbar[l + 1], (size_t)(tile0 + t), 8, wave, ab, lane);
+        sb_store_units(out, t, wave, ab, lane);
+    };
+    // ---- (1) layer 0: tbar = W_0 qbar_0 (3 units) ----------------------------------------------------------
+    {
+        bf16x8 w0[3];
+        sb_load_slice<3>(w0, net.w[0], 8, wave, 0, lane);
+        if (1 <= L - 2) sb_load_slice<16>(wa, net.w[1], 8, wave, 0, lane);
+        else sb_load_slice<16>(wa, net.wt_feat, 8, wave, 0, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < SB_TILES; ++t) {
+            f32x16 acc = zero16;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[q], gbuf[(t * 4 + q) * 64 + lane], acc, 0, 0, 0);
+            adj_epilogue(acc, 0, t, abuf0);
+        }
+    }
+    int cur = 0;
+    for (int l = 1; l <= L - 2; ++l) {  // wa = slice of w[l]
+        const bool skip = (l == net.skip_layer);
+        if (skip) sb_load_slice<3>(wg, net.w[l], 8, wave, 16, lane);
+        sb_load_slice<16>(wb, l + 1 <= L - 2 ? net.w[l + 1] : net.wt_feat, 8, wave, 0, lane);
+        __syncthreads();
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 acc0 = zero16, acc1 = zero16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+            if (skip) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[(tp * 4 + q) * 64 + lane], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[((tp + 1) * 4 + q) * 64 + lane], acc1, 0, 0, 0);
+                }
+            }
+            adj_epilogue(acc0, l, tp, out);
+            adj_epilogue(acc1, l, tp + 1, out);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- (2) u = wt_feat dfeat + wt[L-1] d_sdf  (wa = slice of wt_feat) ---------------------------------------------
+    // zbar_l = u phi'(z_l) + zbar2_l  -> stash zbar[l] (+ LDS when a further layer consumes it)
+    auto fwd_epilogue = [&](const f32x16& u, int l, int t, sb_lfrag* out) {
+        f32x16 sv, z2;
+        load_sprime_block_bf16(sv, (const SE*)st.h[l + 1], (size_t)(tile0 + t), 8, wave, lane);
+        stash_load_block(z2, (const SE*)st.zbar[l], (size_t)(tile0 + t), 8, wave, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z2[r] = u[r] * sv[r] + z2[r];
+        stash_store_block((SE*)st.zbar[l], (size_t)(tile0 + t), 8, wave, z2, lane);
+        if (l > 0) sb_store_units(out, t, wave, z2, lane);
+    };
+    {
+        // dfeat block `wave` of the 4 tiles: stash -> B fragments, INTO abuf[cur]: that buffer holds qbar_{L-1}, which
+        // nobody reads (it only goes to the stash) and of which this wave owns exactly the units it overwrites; the
+        // other buffer may still be being read by slower waves (it was the input of the last layer of pass 1)
+        sb_lfrag* dbuf = cur ? abuf1 : abuf0;
+#pragma unroll
+        for (int t = 0; t < SB_TILES; ++t) {
+            f32x16 df;
+            stash_load_block(df, (const SE*)st.dfeat, (size_t)(tile0 + t), 8, wave, lane);
+            sb_store_units(dbuf, t, wave, df, lane);
+        }
+        const bf16x8 wl = ((gfrag)net.wt[L - 1])[(size_t)wave * 64 + lane];  // wt[L-1]: 8 out-blocks, unit 0 (K = 1)
+        if (L - 2 > 0) sb_load_slice<16>(wb, net.wt[L - 2], (L - 2 == net.skip_layer) ? 10 : 8, wave, 0, lane);
+        __syncthreads();  // dfeat complete in dbuf; every wave is done with the other buffer
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 u0 = zero16, u1 = zero16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], dbuf[(tp * 16 + q) * 64 + lane], u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], dbuf[((tp + 1) * 16 + q) * 64 + lane], u1, 0, 0, 0);
+            }
+            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, gbuf[(tp * 4 + 3) * 64 + lane], u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, gbuf[((tp + 1) * 4 + 3) * 64 + lane], u1, 0, 0, 0);
+            fwd_epilogue(u0, L - 2, tp, out);
+            fwd_epilogue(u1, L - 2, tp + 1, out);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;  // zbar_{L-2} lives in abuf[cur]
+    }
+    for (int l = L - 2; l >= 1; --l) {  // u = wt[l] zbar_l (wa), zbar_{l-1} = u phi'(z_{l-1}) + zbar2_{l-1}
+        if (l - 1 > 0) sb_load_slice<16>(wb, net.wt[l - 1], (l - 1 == net.skip_layer) ? 10 : 8, wave, 0, lane);
+        __syncthreads();
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 u0 = zero16, u1 = zero16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], u1, 0, 0, 0);
+            }
+            fwd_epilogue(u0, l - 1, tp, out);
+            fwd_epilogue(u1, l - 1, tp + 1, out);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+}
+
 }  // namespace
 
 int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant) {
@@ -1030,6 +1220,15 @@ int ncw_nerf_bwd8_launch(const NcwNerfNet* net, const NcwPoints& src, int64_t n,
     const int64_t tiles = (n + 31) / 32;
     hipLaunchKernelGGL(nerf_bwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src, n,
                        d_density, d_rgb, d_a, stash);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+int ncw_sdf_bwd8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, const float* d_sdf, const float* d_grad,
+                        const NcwSdfStash& stash, hipStream_t st) {
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(sdf_bwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src, n,
+                       d_sdf, d_grad, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }
