@@ -1181,6 +1181,201 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_bwdB_kernel(NcwSdfNet net, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// color_fwd (RenderingNetwork, models/neuconw.py:59-170) in the weights-stationary structure (NCW_COLOR_FWD8),
+// d_feature = 256, head 128, trunk 256, bf16: f = xyz_encoding_final(feat), the appearance head on [f | AUX1],
+// the trunk on [e | AUX2], sigmoid rgb -- the arithmetic and stash of color_fwd_kernel (ncw_color.hip).
+// cbuf ([4 tiles][7 units]): units 0..5 = AUX1 = [gamma(dir) | appearance code], unit 6 = AUX2 = [point | normal].
+// ------------------------------------------------------------------------------------------------
+constexpr int SB_C7 = SB_TILES * 7 * 1024;
+
+NCW_DEV void sb_build_aux2(CVec<1>& aux, const float (&x)[3], const float (&nrm)[3], int lane) {  // neuconw.py:147-148
+    const int h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = 0.f;
+        if (ncw_feat_of(r, 0) < 6) {
+            const int f = ncw_feat_of(r, 0) + 4 * h;
+            v = f == 0 ? x[0] : f == 1 ? x[1] : f == 2 ? x[2] : f == 3 ? nrm[0] : f == 4 ? nrm[1] : f == 5 ? nrm[2] : 0.f;
+        }
+        aux.v[0][r] = v;
+    }
+}
+
+__global__ __launch_bounds__(64 * SB_WAVES) void color_fwdB_kernel(NcwColorNet net, NcwPoints src, int64_t n,
+                                                                  const float* __restrict__ normals,
+                                                                  const float* __restrict__ a,
+                                                                  const void* __restrict__ feat_stash, float* __restrict__ rgb,
+                                                                  NcwColorStash st) {
+    typedef __bf16 SE;
+    __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_C7];
+    sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
+    sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
+    sb_lfrag* const cbuf = abuf0 + 2 * SB_ACT / 16;
+    const int lane = ncw_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile0 = (int64_t)blockIdx.x * SB_TILES;
+    const int hb = wave & 3, hp = wave >> 2, ta = 2 * hp, tb = 2 * hp + 1;
+    int64_t pp = 0;
+    bool pvalid = false;
+    if (wave < SB_TILES) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        pvalid = p < n;
+        if (!pvalid) p = n - 1;
+        pp = p;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        const float dir[3] = {src.rays_d[ray * 3 + 0], src.rays_d[ray * 3 + 1], src.rays_d[ray * 3 + 2]};
+        const float nrm[3] = {normals[p * 3 + 0], normals[p * 3 + 1], normals[p * 3 + 2]};
+        CVec<3> aux1;
+        build_aux1<true>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
+        stash_store<3>((SE*)st.aux1, (size_t)(tile0 + wave), aux1, lane);
+        Act<PrecBF16, 3> a1;
+        to_act(a1, aux1);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) cbuf[(wave * 7 + q) * 64 + lane] = a1.f[q];
+        CVec<1> aux2;
+        sb_build_aux2(aux2, xs, nrm, lane);
+        stash_store<1>((SE*)st.aux2, (size_t)(tile0 + wave), aux2, lane);
+        Act<PrecBF16, 1> a2;
+        to_act(a2, aux2);
+        cbuf[(wave * 7 + 6) * 64 + lane] = a2.f[0];
+    }
+    // the SDF net's feature vector: block `wave` of the 4 tiles, stash -> B fragments
+#pragma unroll
+    for (int t = 0; t < SB_TILES; ++t) {
+        f32x16 v;
+        stash_load_block(v, (const SE*)feat_stash, (size_t)(tile0 + t), 8, wave, lane);
+        sb_store_units(abuf0, t, wave, v, lane);
+    }
+    bf16x8 wa[16], wb[16], wx[6];
+    auto bias_of = [&](const float* bp, int ob) {
+        CVec<1> b1;
+        load_bias(b1, bp + ob * 32, lane);
+        return b1.v[0];
+    };
+    auto relu16 = [](const f32x16& v) {
+        f32x16 y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = fmaxf(v[r], 0.f);
+        return y;
+    };
+    int cur = 0;
+    // ---- f = xyz_encoding_final(feat): no activation (neuconw.py:128,136) ----------------------------------------
+    {
+        sb_load_slice<16>(wa, net.w_f, 8, wave, 0, lane);
+        sb_load_slice<16>(wb, net.w_e[0], 4, hb, 0, lane);   // head layer 0: f columns
+        sb_load_slice<6>(wx, net.w_e[0], 4, hb, 16, lane);   //               AUX1 columns (units 16..21)
+        const f32x16 bias = bias_of(net.b_f, wave);
+        __syncthreads();  // feat, AUX1, AUX2 visible
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 acc0 = bias, acc1 = bias;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], abuf0[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], abuf0[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+            stash_store_block((SE*)st.f, (size_t)(tile0 + tp), 8, wave, acc0, lane);
+            stash_store_block((SE*)st.f, (size_t)(tile0 + tp + 1), 8, wave, acc1, lane);
+            sb_store_units(abuf1, tp, wave, acc0, lane);
+            sb_store_units(abuf1, tp + 1, wave, acc1, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur = 1;
+    }
+    // ---- appearance head (neuconw.py:111-127,137-140): wave = (block hb, tiles ta, tb) ----------------------------
+    for (int i = 0; i < net.n_head; ++i) {
+        if (i + 1 < net.n_head) sb_load_slice<8>(wb, net.w_e[i + 1], 4, hb, 0, lane);
+        else sb_load_slice<9>(wb, net.w_l[0], 8, wave, 0, lane);  // trunk layer 0: 8 units of e + the AUX2 unit
+        const f32x16 bias = bias_of(net.b_e[i], hb);
+        __syncthreads();
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+        f32x16 acc0 = bias, acc1 = bias;
+        if (i == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(ta * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tb * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], cbuf[(ta * 7 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], cbuf[(tb * 7 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(ta * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tb * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+        }
+        const f32x16 y0 = relu16(acc0), y1 = relu16(acc1);
+        stash_store_block((SE*)st.e[i], (size_t)(tile0 + ta), 4, hb, y0, lane);
+        stash_store_block((SE*)st.e[i], (size_t)(tile0 + tb), 4, hb, y1, lane);
+        sb_store_units(out, ta, hb, y0, lane);
+        sb_store_units(out, tb, hb, y1, lane);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- trunk (neuconw.py:158-166): layer 0 on [e | AUX2] (wa = 9 units of w_l[0]), then 256 -> 256 ---------------------
+    const int last = net.n_lin - 1;
+    for (int l = 0; l < last; ++l) {
+        if (l + 1 < last) sb_load_slice<16>(wb, net.w_l[l + 1], 8, wave, 0, lane);
+        const f32x16 bias = bias_of(net.b_l[l], wave);
+        __syncthreads();
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SB_TILES; tp += 2) {
+            f32x16 acc0 = bias, acc1 = bias;
+            if (l == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[8], cbuf[(tp * 7 + 6) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[8], cbuf[((tp + 1) * 7 + 6) * 64 + lane], acc1, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+                }
+            }
+            const f32x16 y0 = relu16(acc0), y1 = relu16(acc1);
+            stash_store_block((SE*)st.x[l], (size_t)(tile0 + tp), 8, wave, y0, lane);
+            stash_store_block((SE*)st.x[l], (size_t)(tile0 + tp + 1), 8, wave, y1, lane);
+            sb_store_units(out, tp, wave, y0, lane);
+            sb_store_units(out, tp + 1, wave, y1, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- rgb = sigmoid(lin_last(x)) (neuconw.py:168-169), waves 0..3 --------------------------------------------
+    __syncthreads();
+    if (wave < SB_TILES) {
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        bf16x8 w1[16];
+        sb_load_slice<16>(w1, net.w_l[last], 1, 0, 0, lane);
+        CVec<1> o;
+        load_bias(o, net.b_l[last], lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
+        if (pvalid && lane < 32) {
+            rgb[pp * 3 + 0] = sigmoidf_<true>(o.v[0][0]);
+            rgb[pp * 3 + 1] = sigmoidf_<true>(o.v[0][1]);
+            rgb[pp * 3 + 2] = sigmoidf_<true>(o.v[0][2]);
+        }
+    }
+}
+
 }  // namespace
 
 int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant) {
@@ -1229,6 +1424,15 @@ int ncw_sdf_bwd8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, c
     const int64_t tiles = (n + 31) / 32;
     hipLaunchKernelGGL(sdf_bwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src, n,
                        d_sdf, d_grad, stash);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+int ncw_color_fwd8_launch(const NcwColorNet* net, const NcwPoints& src, int64_t n, const float* normals, const float* a,
+                          const void* feat_stash, float* rgb, const NcwColorStash& stash, hipStream_t st) {
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(color_fwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src,
+                       n, normals, a, feat_stash, rgb, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }
