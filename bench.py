@@ -153,7 +153,24 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="record the step into HIP graphs and replay it (trainer.TrainStep(capture=True)); measured "
                          "4.78 vs 4.80 ms eager on one MI355X -- the step is not host-launch-bound -- so eager is the default")
+    ap.add_argument("--dist-check", action="store_true",
+                    help="initialise the process group, print {world, ranks, devices} from rank 0 and exit (launcher test; "
+                         "needs no GPU with NCW_DIST_BACKEND=gloo)")
     args = ap.parse_args()
+    # ---- self-launch: `python bench.py --gpus N` (N > 1) outside torch.distributed.run starts the N ranks itself,
+    # one process per GPU over RCCL (train.py:53-55: gpus=N, accelerator='ddp'); under torchrun WORLD_SIZE is set
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execvp(sys.executable, cmd)
     if args.config == "shipped":  # config/train_brandenburg_gate.yaml: SDF 8x512, N_SAMPLES 8, N_IMPORTANCE 16
         globals().update(W_SDF=512, N_SAMPLES=8, N_IMPORTANCE=16, M_SDF=2097664, M_SDF1=1835520, M_COL=585344)
 
@@ -169,13 +186,30 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if os.environ.get("NCW_BENCH_ONE_GPU_TEST"):  # plumbing test: N ranks share GPU 0 over gloo
             local_rank = 0
-        torch.cuda.set_device(local_rank)
         backend = os.environ.get("NCW_DIST_BACKEND", "nccl")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch N>1 through torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (torch.distributed.run --nproc-per-node must equal --gpus)"
+                         % (args.gpus, world))
+    rank_info = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(),
+                 "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"),
+                 "device": (torch.cuda.get_device_name(local_rank) if torch.cuda.is_available() else None)}
+    ranks = [rank_info]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, rank_info)
+    if args.dist_check:
+        if rank == 0:
+            print(json.dumps({"dist_check": True, "world": dist.get_world_size() if world > 1 else 1,
+                              "backend": dist.get_backend() if world > 1 else None, "ranks": ranks}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     prec = nw.PREC_BF16 if args.prec == "bf16" else nw.PREC_F32
@@ -302,6 +336,7 @@ def main():
                                    % ("BASELINE.json configs[1]" if args.config == "headline" else "shipped yaml shape, secondary",
                                       R, N_SAMPLES, N_IMPORTANCE, W_SDF),
                        "rays_per_gpu": R, "samples_per_ray": S, "global_rays": world * R, "parallelism": "dp%d" % world,
+                       "world_size": world, "ranks": ranks,
                        "submission": "hip-graph replay" if args.graph else "eager",
                        "final_loss": float(loss.detach())},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -207,10 +207,13 @@ typedef struct NcwColorStash {
 int ncw_color_fwd(const NcwColorNet* net, int prec, const NcwPoints* pts, int64_t n, const float* normals,
                   const float* a, const void* feat_stash, float* rgb, const NcwColorStash* stash, void* stream);
 /* d_rgb [n,3] -> d_grad[n,3] += d(normals), d_a [R,n_a] += (atomics; zero it first), dfeat stash (rbf),
+ * d_a_rows: NULL, or [n,n_a] -- then every point's appearance-code adjoint is STORED as its row instead of being
+ * added to d_a with atomics, and ncw_ray_sum_rows reduces the rows of a ray in sample order (reproducible; the
+ * fp32 parity mode uses it).
  * and the z-stashes for ncw_wgrad. */
 int ncw_color_bwd(const NcwColorNet* net, int prec, const NcwPoints* pts, int64_t n, const float* rgb,
-                  const float* d_rgb, float* d_grad, float* d_a, void* dfeat_stash, const NcwColorStash* stash,
-                  void* stream);
+                  const float* d_rgb, float* d_grad, float* d_a, float* d_a_rows, void* dfeat_stash,
+                  const NcwColorStash* stash, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Background NeRF -- models/nerf.py:86-183 (use_viewdirs, encode_appearance) evaluated on the
@@ -246,7 +249,9 @@ typedef struct NcwNerfStash {
 int ncw_nerf_fwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, const float* x4, int64_t n, const float* a,
                  float* density, float* rgb, const NcwNerfStash* stash, void* stream);
 int ncw_nerf_bwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_density,
-                 const float* d_rgb, float* d_a, const NcwNerfStash* stash, void* stream);
+                 const float* d_rgb, float* d_a, float* d_a_rows, const NcwNerfStash* stash, void* stream);
+/* out[R,n_cols] (+)= per-ray sums of rows[R*per_ray, n_cols] in sample order (see d_a_rows above). */
+int ncw_ray_sum_rows(const float* rows, int64_t R, int per_ray, int n_cols, float* out, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight-gradient GEMMs: dense[32*rbx, ld] (f32, forward orientation) += X^T Y over all points,
@@ -266,6 +271,13 @@ typedef struct NcwWgradDesc {
  * ceil(rbx/4)*ceil(rby/4)*ksplit workgroups per product; total_wgs = wg_prefix[n_desc]. */
 int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
               int prec, int64_t n_points, void* stream);
+/* Run-to-run reproducible variant (the fp32 parity mode uses it): every K-slice writes its 128 x 128 partial into its
+ * own slab of `partials` (DEVICE scratch of ncw_wgrad_ordered_scratch_floats(total_wgs) floats, contents
+ * irrelevant on entry) and a second launch adds the slabs of a quadrant in slice order.  The autograd GEMMs it
+ * replaces (torch `mm` backward of F.linear, models/neuconw.py:269-278) are deterministic on the reference's CPU path. */
+int64_t ncw_wgrad_ordered_scratch_floats(int total_wgs);
+int ncw_wgrad_ordered(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
+                      int prec, int64_t n_points, float* partials, void* stream);
 /* bf16 only, explicit workgroup tile: tile 0 = 128 x 256 features (wg_prefix counts ceil(rbx/4)*ceil(rby/8)*ksplit),
  * tile 1 = 256 x 256 (ceil(rbx/8)*ceil(rby/8)*ksplit): every stash element is read once per product.
  * A product's own ksplit / n_points (when > 0) replace the launch-wide values, so products of different
@@ -375,7 +387,7 @@ typedef struct NcwCompositeGrad {
     float* d_rgb;      /* [R,S,3]   */
     float* d_density;  /* [R,S+O]   */
     float* d_bg_rgb;   /* [R,S+O,3] */
-    float* d_inv_s;    /* [1], accumulated with atomics: zero it first */
+    float* d_inv_s;    /* [R]: every ray's term of d loss / d inv_s; the caller sums them (order-fixed) */
 } NcwCompositeGrad;
 
 int ncw_composite_fwd(const NcwCompositeIn* in, const NcwCompositeOut* out, void* stream);

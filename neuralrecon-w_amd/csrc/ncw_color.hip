@@ -140,6 +140,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
                                                                       const float* __restrict__ rgb,
                                                                       const float* __restrict__ d_rgb,
                                                                       float* __restrict__ d_grad, float* __restrict__ d_a,
+                                                                      float* __restrict__ d_a_rows,
                                                                       void* __restrict__ dfeat_stash, NcwColorStash st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
         mma_stream<RBH, RBF + 3, 32 * RBH, SH::SLOT>(q, zea, ring, (const WE*)net.wt_e[0], net.wt_f, SH::FCB_F, lane);
         CVec<3> qa;
         qa.v[0] = q.v[RBF]; qa.v[1] = q.v[RBF + 1]; qa.v[2] = q.v[RBF + 2];
-        accumulate_d_a(qa, d_a, ray, net.n_a, valid, lane);
+        accumulate_d_a(qa, d_a, ray, net.n_a, valid, lane, d_a_rows, p);
         CVec<RBF> zf;
 #pragma unroll
         for (int rb = 0; rb < RBF; ++rb) zf.v[rb] = q.v[rb];
@@ -264,11 +265,11 @@ extern "C" int ncw_color_fwd(const NcwColorNet* net, int prec, const NcwPoints* 
 }
 
 extern "C" int ncw_color_bwd(const NcwColorNet* net, int prec, const NcwPoints* pts, int64_t n, const float* rgb,
-                             const float* d_rgb, float* d_grad, float* d_a, void* dfeat_stash,
+                             const float* d_rgb, float* d_grad, float* d_a, float* d_a_rows, void* dfeat_stash,
                              const NcwColorStash* stash, void* stream) {
     if (!color_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    NCW_COLOR_DISPATCH(color_bwd_kernel, *net, *pts, n, rgb, d_rgb, d_grad, d_a, dfeat_stash, *stash);
+    NCW_COLOR_DISPATCH(color_bwd_kernel, *net, *pts, n, rgb, d_rgb, d_grad, d_a, d_a_rows, dfeat_stash, *stash);
     return 0;
 }

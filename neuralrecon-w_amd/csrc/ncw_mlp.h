@@ -283,8 +283,22 @@ NCW_DEV void build_aux1(CVec<3>& aux, const float (&dir)[3], const float* __rest
 }
 
 // d_a[ray][j] += sum over the wave's points of the AUX1-part adjoint (features 27 .. 27+n_a)
-NCW_DEV void accumulate_d_a(const CVec<3>& q, float* __restrict__ d_a, int64_t ray, int n_a, bool valid, int lane) {
+// rows != nullptr: store this point's adjoint as row p of rows[n][n_a] instead (no atomics; ncw_ray_sum_rows adds a
+// ray's rows in sample order -- the reproducible path of the fp32 parity mode)
+NCW_DEV void accumulate_d_a(const CVec<3>& q, float* __restrict__ d_a, int64_t ray, int n_a, bool valid, int lane,
+                            float* __restrict__ rows = nullptr, int64_t p = 0) {
     const int h = lane >> 5;
+    if (rows != nullptr) {
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (32 * rb + ncw_feat_of(r, 0) + 4 < 27) continue;
+                const int j = 32 * rb + ncw_feat_of(r, 0) + 4 * h - 27;
+                if (valid && j >= 0 && j < n_a) rows[p * n_a + j] = q.v[rb][r];
+            }
+        return;
+    }
     const int64_t r0 = __shfl(ray, 0, 64);
     const bool uniform = __all((ray == r0) ? 1 : 0);
 #pragma unroll

@@ -150,7 +150,8 @@ template <class P, int RBN, int RBH>
 __global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void nerf_bwd_kernel(NcwNerfNet net, NcwPoints src, int64_t n,
                                                                      const float* __restrict__ d_density,
                                                                      const float* __restrict__ d_rgb,
-                                                                     float* __restrict__ d_a, NcwNerfStash st) {
+                                                                     float* __restrict__ d_a, float* __restrict__ d_a_rows,
+                                                                     NcwNerfStash st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
     typedef NerfShapes<P, RBN, RBH, 2> SH;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void nerf_bwd_kernel(NcwNerfN
         mma_stream<RBH, RBN + 3, 32 * RBH, SH::SLOT>(q, zea, ring, (const WE*)net.wt_a[0], net.wt_feat, SH::FCB_P, lane);
         CVec<3> qa;
         qa.v[0] = q.v[RBN]; qa.v[1] = q.v[RBN + 1]; qa.v[2] = q.v[RBN + 2];
-        accumulate_d_a(qa, d_a, ray, net.n_a, valid, lane);
+        accumulate_d_a(qa, d_a, ray, net.n_a, valid, lane, d_a_rows, p);
         CVec<RBN> zf;
 #pragma unroll
         for (int rb = 0; rb < RBN; ++rb) zf.v[rb] = q.v[rb];
@@ -259,15 +260,16 @@ extern "C" int ncw_nerf_fwd(const NcwNerfNet* net, int prec, const NcwPoints* pt
 }
 
 extern "C" int ncw_nerf_bwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_density,
-                            const float* d_rgb, float* d_a, const NcwNerfStash* stash, void* stream) {
+                            const float* d_rgb, float* d_a, float* d_a_rows, const NcwNerfStash* stash, void* stream) {
     if (!nerf_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (0.44 vs 0.49 ms per 135,168 points);
     // NCW_NERF_BWD8=0 selects the weights-through-LDS kernel below
     static const int bwd8 = getenv("NCW_NERF_BWD8") ? atoi(getenv("NCW_NERF_BWD8")) : 1;
-    if (bwd8 > 0 && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 && net->n_head <= 4)
+    if (bwd8 > 0 && d_a_rows == nullptr && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 &&
+        net->n_head <= 4)
         return ncw_nerf_bwd8_launch(net, *pts, n, d_density, d_rgb, d_a, *stash, st);
-    NCW_NERF_DISPATCH(nerf_bwd_kernel, *net, *pts, n, d_density, d_rgb, d_a, *stash);
+    NCW_NERF_DISPATCH(nerf_bwd_kernel, *net, *pts, n, d_density, d_rgb, d_a, d_a_rows, *stash);
     return 0;
 }

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs A, CompBwd 
         G.d_grad[q * 3 + 2] = dtc * dz + ek * gz;
     }
     ds_acc = wave_sum(ds_acc);
-    if (lane == 0) atomicAdd(G.d_inv_s, ds_acc);
+    if (lane == 0) G.d_inv_s[r] = ds_acc;  // per-ray term; the caller sums them (no atomics: reproducible)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,6 +686,31 @@ extern "C" int ncw_composite_bwd(const NcwCompositeIn* in, const NcwCompositeGra
     G.d_sdf = g->d_sdf; G.d_grad = g->d_grad; G.d_rgb = g->d_rgb; G.d_density = g->d_density; G.d_bg_rgb = g->d_bg_rgb;
     G.d_inv_s = g->d_inv_s;
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((in->R + 3) / 4), dim3(256), 0, (hipStream_t)stream, A, G);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[r][j] (+)= sum_i rows[r * per_ray + i][j], i ascending: the order-fixed reduction of the per-point appearance-code
+// adjoints (ncw_color_bwd / ncw_nerf_bwd with d_a_rows) to the per-ray gradient of the embedding lookup
+// (models/neuconw.py:131-139, nerf.py:159-160: `a` is repeated over a ray's samples, so autograd sums over them).
+__global__ __launch_bounds__(256) void ray_sum_rows_kernel(const float* __restrict__ rows, int64_t R, int per_ray, int n_cols,
+                                                           float* __restrict__ out, int accumulate) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= R * n_cols) return;
+    const int64_t r = e / n_cols;
+    const int j = (int)(e - r * n_cols);
+    const float* src = rows + (size_t)r * per_ray * n_cols + j;
+    float s = 0.f;
+    for (int i = 0; i < per_ray; ++i) s += src[(size_t)i * n_cols];
+    out[e] = accumulate ? out[e] + s : s;
+}
+
+extern "C" int ncw_ray_sum_rows(const float* rows, int64_t R, int per_ray, int n_cols, float* out, int accumulate,
+                                void* stream) {
+    if (R <= 0 || n_cols <= 0) return 0;
+    if (!rows || !out || per_ray < 1) return NCW_E_BADARG;
+    hipLaunchKernelGGL(ray_sum_rows_kernel, dim3((unsigned)((R * n_cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rows, R, per_ray, n_cols, out, accumulate);
     NCW_CHECK_LAUNCH();
     return 0;
 }

@@ -62,10 +62,13 @@ NCW_DEV void stage_transposed(typename P::selem* T, const typename P::selem* __r
     }
 }
 
+// ordered (run-to-run reproducible) split-K: slab of one workgroup = 128 x 128 partial + 128 bias partials
+constexpr int WG_SLAB = 128 * 128 + 128;
+
 template <class P>
 __global__ __launch_bounds__(256) void wgrad_kernel(const NcwWgradDesc* __restrict__ descs,
                                                     const int32_t* __restrict__ prefix, int n_desc, int ksplit,
-                                                    int64_t ntiles) {
+                                                    int64_t ntiles, float* __restrict__ partials) {
     typedef typename P::selem SE;
     constexpr int CH = WgT<P>::CH, LDT = WgT<P>::LDT;
     __shared__ __attribute__((aligned(16))) SE XT[128 * LDT];
@@ -134,6 +137,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const NcwWgradDesc* __restri
             }
         }
     }
+    // ---- ordered mode: this K-slice's 128 x 128 partial (+ 128 bias sums) goes to its own slab; the slices are
+    // combined in slice order by wgrad_reduce_kernel, so the result does not depend on the arrival order ----------
+    if (partials != nullptr) {
+        float* slab = partials + (size_t)blockIdx.x * WG_SLAB;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ib = 2 * wi + a, jb = 2 * wj + b;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slab[(ib * 32 + ncw_feat_of(r, lane >> 5)) * 128 + jb * 32 + (lane & 31)] = acc[a][b][r];
+            }
+        if (tid < 128) slab[128 * 128 + tid] = do_bias ? bsum : 0.f;
+        return;
+    }
     // ---- epilogue: f32 atomics into the dense gradient (row = X feature, col = Y feature) ------------
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -149,6 +168,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const NcwWgradDesc* __restri
             }
         }
     if (do_bias) atomicAdd(&D.dbias[4 * qi * 32 + tid], bsum);
+}
+
+// One workgroup per (product, 128 x 128 quadrant): sums the quadrant's K-slice slabs IN SLICE ORDER and adds the
+// total to the dense gradient.  A dense element receives at most two such totals per step (the first-order product
+// z-bar_l (x) h_{l-1} and the second-order product t_l (x) q-bar_{l-1} of the same Linear) on top of the zero fill, and
+// 0 + a + b == 0 + b + a exactly, so the f32 atomics here cannot introduce an order dependence.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const NcwWgradDesc* __restrict__ descs,
+                                                           const int32_t* __restrict__ prefix, int n_desc, int ksplit,
+                                                           const float* __restrict__ partials) {
+    const int d = wg_find(prefix, n_desc, blockIdx.x);
+    const int local = blockIdx.x - prefix[d];
+    const int quad = local / ksplit, ks = local - quad * ksplit;
+    if (ks != 0) return;
+    const NcwWgradDesc D = descs[d];
+    const int nqj = (D.rby + 3) >> 2;
+    const int qi = quad / nqj, qj = quad - qi * nqj;
+    const int nbi = min(4, D.rbx - 4 * qi), nbj = min(4, D.rby - 4 * qj);
+    const float* slab0 = partials + (size_t)blockIdx.x * WG_SLAB;
+    for (int e = threadIdx.x; e < 128 * 128; e += 256) {
+        const int row = e >> 7, col = e & 127;
+        if (row >= 32 * nbi || col >= 32 * nbj) continue;
+        float s = 0.f;
+        for (int k = 0; k < ksplit; ++k) s += slab0[(size_t)k * WG_SLAB + e];
+        atomicAdd(&D.dense[(size_t)(4 * qi * 32 + row) * D.ld + 4 * qj * 32 + col], s);
+    }
+    if (D.dbias != nullptr && qj == 0 && threadIdx.x < 32 * nbi) {
+        float s = 0.f;
+        for (int k = 0; k < ksplit; ++k) s += slab0[(size_t)k * WG_SLAB + 128 * 128 + threadIdx.x];
+        atomicAdd(&D.dbias[4 * qi * 32 + threadIdx.x], s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -342,10 +391,33 @@ extern "C" int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, in
     const int64_t ntiles = (n_points + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (prec == NCW_PREC_BF16)
-        hipLaunchKernelGGL(wgrad_kernel<PrecBF16>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+        hipLaunchKernelGGL(wgrad_kernel<PrecBF16>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles,
+                           (float*)nullptr);
     else if (prec == NCW_PREC_F32)
-        hipLaunchKernelGGL(wgrad_kernel<PrecF32>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles);
+        hipLaunchKernelGGL(wgrad_kernel<PrecF32>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles,
+                           (float*)nullptr);
     else return NCW_E_BADARG;
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int64_t ncw_wgrad_ordered_scratch_floats(int total_wgs) { return (int64_t)total_wgs * WG_SLAB; }
+
+extern "C" int ncw_wgrad_ordered(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
+                                 int prec, int64_t n_points, float* partials, void* stream) {
+    if (n_desc <= 0 || total_wgs <= 0 || n_points <= 0) return 0;
+    if (ksplit < 1 || partials == nullptr) return NCW_E_BADARG;
+    const int64_t ntiles = (n_points + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (prec == NCW_PREC_BF16)
+        hipLaunchKernelGGL(wgrad_kernel<PrecBF16>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles,
+                           partials);
+    else if (prec == NCW_PREC_F32)
+        hipLaunchKernelGGL(wgrad_kernel<PrecF32>, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, ntiles,
+                           partials);
+    else return NCW_E_BADARG;
+    NCW_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(total_wgs), dim3(256), 0, st, descs, wg_prefix, n_desc, ksplit, partials);
     NCW_CHECK_LAUNCH();
     return 0;
 }

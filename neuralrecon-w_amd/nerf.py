@@ -125,12 +125,15 @@ class NeRF(_PackedNet):
         return density, rgb, dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, keep=(a, x4c),
                                   lease=ent)
 
-    def bwd_stash(self, ctx, d_density, d_rgb, d_a):
+    def bwd_stash(self, ctx, d_density, d_rgb, d_a, d_a_rows=None):
+        """d_a [R,n_a] accumulates with atomics -- or, with d_a_rows [n,n_a], every point's row is stored instead
+        (the caller reduces them in order: ncw_ray_sum_rows)."""
         dev = self._first_param().device
         d_density = d_density.contiguous().float()
         d_rgb = d_rgb.contiguous().float()
         L.check(L.get_lib().ncw_nerf_bwd(ctx["plan"].net, ctx["prec"], ctx["pts"], ctx["n"], L.ptr(d_density),
-                                         L.ptr(d_rgb), L.ptr(d_a), ctx["stash"], L.stream_ptr(dev)), "ncw_nerf_bwd")
+                                         L.ptr(d_rgb), L.ptr(d_a), L.ptr(d_a_rows), ctx["stash"], L.stream_ptr(dev)),
+                "ncw_nerf_bwd")
         ctx["_keep_bwd"] = (d_density, d_rgb)
 
     def add_wgrads(self, ctx, batch):

@@ -407,13 +407,14 @@ class RenderingNetwork(_PackedNet):
         return rgb, dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, rgb=rgb, feat_ptr=feat_ptr,
                          keep=(normals, a), lease=ent)
 
-    def bwd_stash(self, ctx, d_rgb, d_grad, d_a, dfeat_ptr):
-        """d_grad [n,3] is updated in place (+= d normals); d_a [R,n_a] accumulates (atomics)."""
+    def bwd_stash(self, ctx, d_rgb, d_grad, d_a, dfeat_ptr, d_a_rows=None):
+        """d_grad [n,3] is updated in place (+= d normals); d_a [R,n_a] accumulates (atomics) -- or, with
+        d_a_rows [n,n_a], every point's row is stored instead (the caller reduces them: ncw_ray_sum_rows)."""
         dev = self._first_param().device
         d_rgb = d_rgb.contiguous().float()
         assert d_grad.is_contiguous() and d_a.is_contiguous()
         L.check(L.get_lib().ncw_color_bwd(ctx["plan"].net, ctx["prec"], ctx["pts"], ctx["n"], L.ptr(ctx["rgb"]),
-                                          L.ptr(d_rgb), L.ptr(d_grad), L.ptr(d_a), dfeat_ptr, ctx["stash"],
+                                          L.ptr(d_rgb), L.ptr(d_grad), L.ptr(d_a), L.ptr(d_a_rows), dfeat_ptr, ctx["stash"],
                                           L.stream_ptr(dev)), "ncw_color_bwd")
         ctx["_keep_bwd"] = d_rgb
 

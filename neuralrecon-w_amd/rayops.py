@@ -119,11 +119,12 @@ class CompositeCtx:
                  d_rgb=torch.empty(R, S, 3, device=dev),
                  d_density=torch.empty(R, M, device=dev) if self.has_bg else None,
                  d_bg_rgb=torch.empty(R, M, 3, device=dev) if self.has_bg else None,
-                 d_inv_s=torch.zeros(1, device=dev))
+                 d_inv_s=torch.empty(R, device=dev))
         s = L.NcwCompositeGrad()
         for k, v in list(ups.items()) + list(g.items()):
             setattr(s, k, v.data_ptr() if v is not None else 0)
         lib = L.get_lib()
         L.check(lib.ncw_composite_bwd(self.cin, s, L.stream_ptr(dev)), "ncw_composite_bwd")
         self._keep = ups
+        g["d_inv_s"] = g["d_inv_s"].sum().reshape(1)  # per-ray terms -> scalar (torch's reduction order is fixed)
         return g

@@ -81,15 +81,32 @@ class _RenderFn(torch.autograd.Function):
         dev = ctx.inv_s.device
         g = comp.backward(d_color, d_wsum, d_depth, d_eik)
         R, S = comp.R, comp.S
-        d_a = torch.zeros(ctx.a_shape, device=dev, dtype=torch.float32)
         d_grad = g["d_grad"].view(R * S, 3)
         dfeat_ptr = sctx["arena"].ptr(sctx["ids"]["dfeat"])
-        neuconw.color_net.bwd_stash(cctx, g["d_rgb"].view(R * S, 3), d_grad, d_a, dfeat_ptr)
+        n_a = int(ctx.a_shape[-1])
+        # reproducible mode (default in fp32): per-point appearance-code adjoints + an order-fixed per-ray sum
+        # instead of f32 atomics (the weight-gradient split-K is order-fixed in fp32 too, stash.WgradBatch.run)
+        ordered = rdr.reproducible if rdr.reproducible is not None else (prec == L.PREC_F32)
+        lib = L.get_lib()
+        if ordered:
+            d_a = torch.empty(ctx.a_shape, device=dev, dtype=torch.float32)
+            rows = torch.empty(R * S, n_a, device=dev, dtype=torch.float32)
+            neuconw.color_net.bwd_stash(cctx, g["d_rgb"].view(R * S, 3), d_grad, None, dfeat_ptr, d_a_rows=rows)
+            L.check(lib.ncw_ray_sum_rows(L.ptr(rows), R, S, n_a, L.ptr(d_a), 0, L.stream_ptr(dev)), "ncw_ray_sum_rows")
+        else:
+            d_a = torch.zeros(ctx.a_shape, device=dev, dtype=torch.float32)
+            neuconw.color_net.bwd_stash(cctx, g["d_rgb"].view(R * S, 3), d_grad, d_a, dfeat_ptr)
         neuconw.sdf_net.bwd_stash(sctx, g["d_sdf"].view(R * S), d_grad)
         plans = [sctx["plan"], cctx["plan"]]
         if ctx.use_bg:
             M = comp.S + comp.O
-            nerf.bwd_stash(nctx, g["d_density"].view(R * M), g["d_bg_rgb"].view(R * M, 3), d_a)
+            if ordered:
+                rows_bg = torch.empty(R * M, n_a, device=dev, dtype=torch.float32)
+                nerf.bwd_stash(nctx, g["d_density"].view(R * M), g["d_bg_rgb"].view(R * M, 3), None, d_a_rows=rows_bg)
+                L.check(lib.ncw_ray_sum_rows(L.ptr(rows_bg), R, M, n_a, L.ptr(d_a), 1, L.stream_ptr(dev)),
+                        "ncw_ray_sum_rows")
+            else:
+                nerf.bwd_stash(nctx, g["d_density"].view(R * M), g["d_bg_rgb"].view(R * M, 3), d_a)
             plans.append(nctx["plan"])
         # every weight-gradient product of the step (SDF, colour, background NeRF) in ONE launch; the product
         # list only depends on the (cached) stash arenas: build it once per lease combination
@@ -108,20 +125,20 @@ class _RenderFn(torch.autograd.Function):
         for p in plans:
             p.g_arena.zero_()
         batch.run()
-        # parameter gradients land in ONE persistent flat fp32 buffer whose views ARE the parameters'
-        # .grad (the DDP all-reduce operand, ddp.py): no per-parameter copies, no per-step allocation.
-        flat, views = rdr._grad_views(ctx.params)
-        fresh = all(p.grad is None for p in ctx.params)
-        ours = (not fresh) and all(p.grad is not None and p.grad.data_ptr() == views[id(p)].data_ptr()
-                                   for p in ctx.params)
+        # Parameter gradients.  Default: returned THROUGH autograd (AccumulateGrad runs, so DistributedDataParallel /
+        # Lightning reducer hooks, torch.autograd.grad and post-accumulate hooks all see them -- the reference trains
+        # under accelerator='ddp', train.py:53-55).  Only when a trainer has adopted a flat gradient buffer
+        # (trainer.FlatParams -> adopt_grad_buffer) and every .grad still IS its view of that buffer does the
+        # weight-norm backward write straight into it (one launch, no per-parameter adds).
         out = [None] * len(ctx.params)
-        if fresh or ours:
-            keep = [pl.unpack_grads(views, accumulate=ours) for pl in plans]
-            if fresh:
-                for p in ctx.params:
-                    p.grad = views[id(p)]
-        else:  # foreign .grad tensors present: hand the gradients to autograd instead
-            tmp = torch.zeros_like(flat)
+        direct = False
+        if rdr.__dict__.get("_gv_adopted", False):
+            flat, views = rdr._grad_views(ctx.params)
+            direct = all(p.grad is not None and p.grad.data_ptr() == views[id(p)].data_ptr() for p in ctx.params)
+        if direct:
+            keep = [pl.unpack_grads(views, accumulate=True) for pl in plans]
+        else:
+            tmp = torch.zeros(sum(p.numel() for p in ctx.params), device=dev, dtype=torch.float32)
             tviews, off = {}, 0
             out = []
             for p in ctx.params:
@@ -214,6 +231,9 @@ class NeuconWRenderer:
         # sync_free=True keeps render() free of device->host synchronisations (see sfm_depth_loss below);
         # the default reproduces the reference's output shapes exactly.
         self.sync_free = False
+        # reproducible: None = on in fp32 (the parity mode is bitwise run-to-run reproducible), off in bf16 (f32 atomics
+        # for the appearance-code gradient); True / False force it
+        self.reproducible = None
 
     # ---- sampler (renderer.py:458-568, under no_grad) -------------------------------------------
     def _sdf_rays(self, rays_o, rays_d, z):
@@ -317,6 +337,7 @@ class NeuconWRenderer:
             views[id(p)] = flat[off:off + p.numel()].view(p.shape)
             off += p.numel()
         self._gv = (tuple(id(p) for p in params), flat, views)
+        self._gv_adopted = True
 
     def flat_grad_buffer(self):
         """The persistent flat gradient buffer of (sdf, colour, background) parameters, or None."""

@@ -76,6 +76,7 @@ class WgradBatch:
         """Take over another batch's products (they keep their own point count)."""
         self.items.extend(other.items)
 
+    _scratch = {}  # device -> K-slice slabs of the ordered (fp32) weight-gradient launches
     _cache = {}  # content-addressed device tables: (items, prec, tile) -> (table, prefix, n_desc, wgs, ksplit, n)
 
     @staticmethod
@@ -137,8 +138,13 @@ class WgradBatch:
         lib = L.get_lib()
         for tile, tab, pre, nd, wgs, ks, n in groups:
             if tile is None:
-                L.check(lib.ncw_wgrad(L.ptr(tab), L.ptr(pre), nd, wgs, ks, self.prec, n, L.stream_ptr(self.device)),
-                        "ncw_wgrad")
+                # fp32 parity mode: order-fixed split-K (run-to-run reproducible); one scratch per process, grown on demand
+                need = int(lib.ncw_wgrad_ordered_scratch_floats(wgs))
+                scr = WgradBatch._scratch.get(str(self.device))
+                if scr is None or scr.numel() < need:
+                    scr = WgradBatch._scratch[str(self.device)] = torch.empty(need, device=self.device, dtype=torch.float32)
+                L.check(lib.ncw_wgrad_ordered(L.ptr(tab), L.ptr(pre), nd, wgs, ks, self.prec, n, L.ptr(scr),
+                                              L.stream_ptr(self.device)), "ncw_wgrad_ordered")
             else:
                 L.check(lib.ncw_wgrad_tiled(L.ptr(tab), L.ptr(pre), nd, wgs, ks, tile, n,
                                             L.stream_ptr(self.device)), "ncw_wgrad_tiled")

@@ -22,7 +22,7 @@ def test_train_step_matches_per_tensor_recipe():
     emb, neuconw, nerf, rdr = sys_a
     params = [p for m in (emb, neuconw, nerf) for p in m.parameters()]
     opt = torch.optim.Adam(params, lr=1e-3, eps=1e-7)
-    losses_a = []
+    losses_a, first_a = [], None
     for i in range(steps):
         opt.zero_grad(set_to_none=True)
         out = rdr.render(rays, ts, label, perturb_overwrite=0, background_rgb=bg, cos_anneal_ratio=0.1 * i)
@@ -31,21 +31,35 @@ def test_train_step_matches_per_tensor_recipe():
         torch.nn.utils.clip_grad_norm_(params, 0.99)
         opt.step()
         losses_a.append(float(loss))
+        if i == 0:
+            first_a = {k: p.detach().clone() for k, p in named_params(emb, neuconw, nerf).items()}
     # b) flat
     emb2, neuconw2, nerf2, rdr2 = sys_b
     keys = list(neuconw2.state_dict()) + list(nerf2.state_dict())
     train = nw.TrainStep(rdr2, [emb2, neuconw2, nerf2], loss_from_outputs, lr=1e-3, eps=1e-7, clip=0.99)
     assert list(neuconw2.state_dict()) + list(nerf2.state_dict()) == keys
-    losses_b = []
+    losses_b, first_b = [], None
     for i in range(steps):
         loss, _ = train(rays, ts, label, rgbs, background_rgb=bg, cos_anneal_ratio=0.1 * i, perturb_overwrite=0)
         losses_b.append(float(loss))
+        if i == 0:
+            first_b = {k: p.detach().clone() for k, p in named_params(emb2, neuconw2, nerf2).items()}
     assert rdr2.flat_grad_buffer().data_ptr() == train.fp.flat_grad.data_ptr()  # renderer writes into the flat buffer
     for a, b in zip(losses_a, losses_b):
         assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (losses_a, losses_b)
+    # Step 1: both runs start from the same parameters and the fp32 mode is bitwise reproducible
+    # (tests/test_gpu_repro.py), so they see IDENTICAL gradients; what separates them is the last bit of torch's
+    # per-tensor clip / Adam vs the flat C-ABI update (3e-7 per step, test_flat_adam_matches_torch_adam).
+    worst1 = max(float((first_a[k] - first_b[k]).abs().max()) for k in first_a)
+    assert worst1 < 2e-6, worst1
+    # Steps 2..4: the 1e-7 parameter differences re-enter the gradients, and Adam turns a ~0 gradient whose SIGN
+    # they decide into a +-lr-sized step (the round-1 flake: 3.9e-5 on one element).  A bookkeeping error (stale packed
+    # weights, wrong step count, a lost gradient slice) moves the BULK by >= 1e-4: bound the distribution, not the max.
     pa, pb = named_params(emb, neuconw, nerf), named_params(emb2, neuconw2, nerf2)
-    worst = max(float((pa[k] - pb[k]).abs().max()) for k in pa)
-    assert worst < 2e-5, worst  # 4 Adam steps of lr 1e-3: any bookkeeping error would show at 1e-3
+    diffs = torch.cat([(pa[k] - pb[k]).abs().reshape(-1) for k in pa])
+    assert float(diffs.max()) < 1e-3, float(diffs.max())
+    assert float(diffs.median()) < 2e-6, float(diffs.median())
+    assert float((diffs > 2e-5).float().mean()) < 2e-3, float((diffs > 2e-5).float().mean())
 
 
 def test_captured_step_replays_like_eager():
