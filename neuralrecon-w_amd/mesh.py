@@ -74,7 +74,7 @@ def extract_mesh(renderer, dim, scene_radius, scene_origin, origin=None, radius=
     origin = [0.0, 0.0, 0.0] if origin is None else [float(v) for v in origin]
     lo = tuple(o - radius for o in origin)
     hi = tuple(o + radius for o in origin)
-    sdf = _grid.sdf_grid(renderer.neuconw.sdf_net, dim, lo, hi, prec=renderer.prec).view(dim, dim, dim)
+    sdf = _grid.sdf_grid(renderer.neuconw.sdf_net, dim, lo, hi, prec=renderer.infer_prec).view(dim, dim, dim)
     verts, faces = isosurface(sdf, level)
     voxel_size = 2 * radius / (dim - 1)                                      # :44
     vol_origin = torch.tensor(lo, device=verts.device, dtype=torch.float32)  # :43

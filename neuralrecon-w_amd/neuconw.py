@@ -62,11 +62,25 @@ def _wvb(m):
     return m.weight, None, m.bias
 
 
+def _prec_of(v):
+    return L.PREC_F32 if v.lower() in ("f32", "fp32", "0") else L.PREC_BF16
+
+
 def default_prec():
+    """Precision of the TRAINING passes (the three MLPs forward/backward, the sampler's SDF queries)."""
     import os
 
-    v = os.environ.get("NEUCONW_PREC", "bf16").lower()
-    return L.PREC_F32 if v in ("f32", "fp32", "0") else L.PREC_BF16
+    return _prec_of(os.environ.get("NEUCONW_PREC", "bf16"))
+
+
+def default_infer_prec():
+    """Precision of the geometry-critical inference-only entry points (`sdf()`, `gradient()`, `NeuconW.forward`,
+    grid.sdf_grid, voxel.surface_selection, mesh.extract_mesh): fp32 like the reference evaluates them, unless
+    NEUCONW_INFER_PREC says otherwise.  bf16 SDF values carry ~5e-3 absolute error (tests/test_gpu_sdf.py), which
+    moves a zero level set / an `sdf <= threshold` selection by a fraction of a 512^3 voxel (~4e-3)."""
+    import os
+
+    return _prec_of(os.environ.get("NEUCONW_INFER_PREC", "f32"))
 
 
 class SDFNetwork(nn.Module):
@@ -195,7 +209,7 @@ class SDFNetwork(nn.Module):
     def sdf(self, x, prec=None):
         """SDFNetwork.sdf (neuconw.py:281-282): x[..., 3] -> [N, 1]; no autograd (the reference only
         calls it under no_grad: renderer.py:825, neuconw_system.py:245-249, visualization.py:75-80)."""
-        prec = default_prec() if prec is None else prec
+        prec = default_infer_prec() if prec is None else prec
         if not x.is_cuda:
             raise L.NeuconwHipError("SDFNetwork.sdf: input is not on a GPU; the hot path has no CPU fallback")
         xf = x.reshape(-1, 3).float().contiguous()
@@ -478,7 +492,7 @@ class NeuconW(nn.Module):
 
     @torch.no_grad()
     def gradient(self, x, prec=None):
-        prec = default_prec() if prec is None else prec
+        prec = default_infer_prec() if prec is None else prec
         xf = x.reshape(-1, 3).float().contiguous()
         _, grad, c = self.sdf_net.fwd_stash(points_struct(x=xf), xf.shape[0], prec)
         StashCache.release(c["lease"])
@@ -488,7 +502,7 @@ class NeuconW(nn.Module):
     def forward(self, x, prec=None):
         """x [R,S,3+3+A] -> (rgb [R,S,3], inv_s [1,1], sdf [R,S], grad [R,S,3]) -- inference
         (renderer.rgb(), visualisation).  The differentiable training path is NeuconWRenderer.render."""
-        prec = default_prec() if prec is None else prec
+        prec = default_infer_prec() if prec is None else prec
         R, S, _ = x.shape
         n = R * S
         xyz = x[..., 0:3].reshape(n, 3).float().contiguous()

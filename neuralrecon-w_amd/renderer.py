@@ -17,8 +17,8 @@ import yaml
 
 from . import lib as L
 from . import rayops
-from .neuconw import default_prec, points_struct
-from .stash import StashCache, WgradBatch
+from .neuconw import default_infer_prec, default_prec, points_struct
+from .stash import LeaseGuard, StashCache, WgradBatch
 
 SKY_LABEL_ID = 2  # datasets/mask_utils.py: get_label_id_mapping()["sky"]
 LABEL_IDS = {"sky": 2}
@@ -67,10 +67,10 @@ class _RenderFn(torch.autograd.Function):
         extras = (o["color_sphere"], o["color_bg"], o["weights"], o["cdf"], o["inside"], o["normals"],
                   sdf.view(R, S), grad.view(R, S, 3), o["mid_z"], o["dists"], o["eik"][:, 1].contiguous(), inv_s)
         ctx.mark_non_differentiable(*extras)
+        # the leases live exactly as long as this autograd node: returned by backward(), or when the node is dropped
+        ctx.guard = LeaseGuard([c["lease"] for c in (sctx, cctx, nctx) if c is not None])
         if not any(ctx.needs_input_grad):  # inference: nobody will come back for the stashes
-            for c in (sctx, cctx, nctx):
-                if c is not None:
-                    StashCache.release(c["lease"])
+            ctx.guard.release()
         return (o["color"], o["weights_sum"], o["depth"], o["eik"][:, 0].contiguous()) + extras
 
     @staticmethod
@@ -79,6 +79,7 @@ class _RenderFn(torch.autograd.Function):
         neuconw, nerf = rdr.neuconw, rdr.nerf
         prec = rdr.prec
         dev = ctx.inv_s.device
+        ctx.guard.consume()
         g = comp.backward(d_color, d_wsum, d_depth, d_eik)
         R, S = comp.R, comp.S
         d_grad = g["d_grad"].view(R * S, 3)
@@ -110,7 +111,7 @@ class _RenderFn(torch.autograd.Function):
             plans.append(nctx["plan"])
         # every weight-gradient product of the step (SDF, colour, background NeRF) in ONE launch; the product
         # list only depends on the (cached) stash arenas: build it once per lease combination
-        tag = (id(cctx["lease"]), id(nctx["lease"]) if ctx.use_bg else None, prec)
+        tag = (cctx["arena"].buf.data_ptr(), nctx["arena"].buf.data_ptr() if ctx.use_bg else None, prec)
         batch = sctx["lease"].get("wgrad_batch")
         if batch is None or batch.tag != tag:
             batch = WgradBatch(dev, prec, R * S)
@@ -153,9 +154,7 @@ class _RenderFn(torch.autograd.Function):
         d_var = (g["d_inv_s"] * 10.0 * inv_s * live).reshape(ctx.variance.shape)
         if not ctx.use_bg:  # background parameters were passed but unused
             pass
-        for c in (sctx, cctx, nctx):
-            if c is not None:
-                StashCache.release(c["lease"])
+        ctx.guard.release()
         return (None, None, None, None, None, None, None, None, d_a, d_var) + tuple(out)
 
 
@@ -199,7 +198,7 @@ class NeuconWRenderer:
                  origin, radius, s_val_base=0, spc_options=None, sample_range=None, boundary_samples=None,
                  nerf_far_override=False, render_bg=True, trim_sphere=True, save_sample=False,
                  save_step_sample=False, mesh_mask_list=None, floor_normal=False, depth_loss=False,
-                 floor_labels=None, prec=None):
+                 floor_labels=None, prec=None, infer_prec=None):
         self.nerf, self.neuconw, self.embeddings = nerf, neuconw, embeddings
         self.n_samples, self.n_importance, self.n_outside = n_samples, n_importance, n_outside
         self.up_sample_steps, self.perturb, self.s_val_base = up_sample_steps, perturb, s_val_base
@@ -228,6 +227,14 @@ class NeuconWRenderer:
         if save_sample or save_step_sample:
             raise NotImplementedError("debug PLY dumps (open3d) are out of scope")
         self.prec = default_prec() if prec is None else prec
+        # inference-only helpers (sdf(), rgb(): octree refresh, grid sweep, mesh colours) run in fp32 like the
+        # reference unless told otherwise; the training passes and the sampler follow `prec`
+        self.infer_prec = default_infer_prec() if infer_prec is None else infer_prec
+        if self.n_samples + self.n_importance + (self.boundary_samples or 0) + self.n_outside > 512:
+            raise ValueError("n_samples + n_importance + boundary_samples + n_outside = %d > 512: the per-ray kernels keep a "
+                             "ray's samples in LDS (RAY_MAXN 512).  Note config/defaults.py's N_SAMPLES = N_IMPORTANCE = "
+                             "512 is overridden by every shipped scene yaml (8 + 16)."
+                             % (self.n_samples + self.n_importance + (self.boundary_samples or 0) + self.n_outside))
         # sync_free=True keeps render() free of device->host synchronisations (see sfm_depth_loss below);
         # the default reproduces the reference's output shapes exactly.
         self.sync_free = False
@@ -372,7 +379,12 @@ class NeuconWRenderer:
         a_embedded = self.embeddings["a"](ts)
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
         n_samples, z_vals, z_vals_outside, sample_dist = self.sparse_sampler(rays_o, rays_d, near, far, perturb, _rand)
-        bgc = background_rgb.reshape(-1)[:3] if background_rgb is not None else None
+        bgc = None
+        if background_rgb is not None:
+            if background_rgb.numel() != 3:
+                raise ValueError("background_rgb must hold ONE colour (3 values; every reference call site passes "
+                                 "torch.ones/zeros([1, 3])): got shape %s" % (tuple(background_rgb.shape),))
+            bgc = background_rgb.reshape(3)
         outs = _RenderFn.apply(self, rays_o, rays_d, z_vals, z_vals_outside, sample_dist,
                                cos_anneal_ratio if torch.is_tensor(cos_anneal_ratio) else float(cos_anneal_ratio), bgc,
                                a_embedded, self.neuconw.deviation_network.variance, *self._params())
@@ -406,9 +418,9 @@ class NeuconWRenderer:
 
     # ---- helpers used by NeuconWSystem / extract_mesh (renderer.py:947-961) ---------------------------
     def sdf(self, pts):
-        return self.neuconw.sdf(pts, self.prec)
+        return self.neuconw.sdf(pts, self.infer_prec)
 
     def rgb(self, pts, rays_d, a_embedded):
         num_points = pts.shape[0]
-        rgb, _, _, _ = self.neuconw(torch.cat([pts, rays_d, a_embedded], -1), self.prec)
+        rgb, _, _, _ = self.neuconw(torch.cat([pts, rays_d, a_embedded], -1), self.infer_prec)
         return rgb.reshape(num_points, 3)

@@ -172,3 +172,32 @@ class StashCache:
     def release(e):
         if e is not None:
             e["busy"] = False
+
+
+class LeaseGuard:
+    """Owns the stash leases of ONE forward.  The autograd node keeps it alive; when the node dies without a
+    backward (a grad-enabled validation render, a skipped step) the leases are returned instead of staying busy
+    forever -- the next forward would otherwise allocate a fresh multi-GB arena every step.  `consume()` is the
+    backward: a second backward over the same stashes (retain_graph=True) would read buffers a later forward may
+    already have overwritten, so it raises."""
+
+    def __init__(self, leases):
+        self.leases = [l for l in leases if l is not None]
+        self.consumed = False
+
+    def consume(self):
+        if self.consumed:
+            raise RuntimeError("NeuconWRenderer: backward called twice over one render(); the activation stashes are "
+                               "released after the first backward (retain_graph=True is not supported)")
+        self.consumed = True
+
+    def release(self):
+        for l in self.leases:
+            StashCache.release(l)
+        self.leases = []
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass

@@ -41,11 +41,75 @@ def occupancy_from_dense(dense_bool, scene_origin, scale, voxel_size=None):
     return occupancy_from_points(centres * float(scale) + origin, scene_origin, scale, level, voxel_size)
 
 
-def octree_from_sfm(recontruct_path, min_track_length, voxel_size, device):
-    raise NotImplementedError(
-        "building the coarse octree from a COLMAP reconstruction (generate_voxel.py:41-73) needs the dataset "
-        "readers, which are out of the hot-path scope; build octree_data with voxel.occupancy_from_points(...) "
-        "from the SfM points and assign it to renderer.octree_data")
+def read_points3d_xyz(path, min_track_length):
+    """COLMAP `points3D.bin` (utils/colmap_utils.py:264-291: u64 count, then per point `<QdddBBBd` + u64 track
+    length + that many `<ii` track elements) -> float64 [N,3] xyz of the points whose track is LONGER than
+    `min_track_length` (generate_voxel.py:55-58: `p.point2D_idxs.shape[0] > min_track_length`), file order."""
+    import struct
+
+    import numpy as np
+
+    with open(path, "rb") as f:
+        buf = f.read()
+    (n,) = struct.unpack_from("<Q", buf, 0)
+    off, keep = 8, []
+    for _ in range(n):
+        x, y, z = struct.unpack_from("<ddd", buf, off + 8)
+        (track,) = struct.unpack_from("<Q", buf, off + 43)
+        off += 51 + 8 * track
+        if track > min_track_length:
+            keep.append((x, y, z))
+    if off != len(buf):
+        raise ValueError("%s: %d trailing bytes after %d points (not a COLMAP points3D.bin?)" % (path, len(buf) - off, n))
+    return np.asarray(keep, dtype=np.float64).reshape(-1, 3)
+
+
+def sfm_cube(scene_config, radius=1.0):
+    """generate_voxel.py:87-118: the evaluation box of the scene's config.yaml carried into SfM space by
+    inv(sfm2gt); scene cube = centre +- scale with scale = (longest box edge) / 2 * radius.  float64 numpy."""
+    import numpy as np
+
+    gt_to_sfm = np.linalg.inv(np.array(scene_config["sfm2gt"], dtype=np.float64))
+    v1 = gt_to_sfm[:3, :3] @ np.array(scene_config["eval_bbx"][0], dtype=np.float64) + gt_to_sfm[:3, 3]
+    v2 = gt_to_sfm[:3, :3] @ np.array(scene_config["eval_bbx"][1], dtype=np.float64) + gt_to_sfm[:3, 3]
+    lo, hi = np.minimum(v1, v2), np.maximum(v1, v2)
+    return lo + (hi - lo) / 2, float(np.max(hi - lo) / 2 * radius)
+
+
+def dilate_points(points, voxel_size):
+    """generate_voxel.py:24-38 `expand_points`: every point plus its 26 neighbours at +-voxel_size (float64)."""
+    import itertools
+
+    import numpy as np
+
+    offs = np.array(list(itertools.product((-1.0, 0.0, 1.0), repeat=3)), dtype=np.float64) * float(voxel_size)
+    return (points[None, :, :] + offs[:, None, :]).reshape(-1, 3)
+
+
+def octree_from_sfm(recontruct_path, min_track_length, voxel_size, device, sfm_path="sparse", expand=1, radius=1.0):
+    """NeuconWRenderer.get_octree (renderer.py:137-155) -> generate_voxel.py:41-73 `gen_octree_from_sfm` + :75-171
+    `gen_octree`: COLMAP points with a track longer than `min_track_length`, dilated once by +-voxel_size, cropped
+    to the scene cube, voxelised at level floor(log2(2 scale / voxel_size)).  The file reading and the float64
+    geometry are numpy like the reference; the voxelisation is `ncw_voxel_build` (octree_from_points).  The
+    returned octree_data carries the keys the renderer and the octree refresh read (`scene_origin`, `scale`,
+    `level`) with the kaolin SPC tensors replaced by the `occ` / `brick` bit masks."""
+    import os
+
+    import numpy as np
+    import yaml
+
+    with open(os.path.join(recontruct_path, "config.yaml"), "r") as f:
+        scene_config = yaml.load(f, Loader=yaml.FullLoader)
+    pts = read_points3d_xyz(os.path.join(recontruct_path, "dense", sfm_path, "points3D.bin"), min_track_length)
+    if pts.shape[0] == 0:
+        raise ValueError("no SfM point has a track longer than %d" % min_track_length)
+    for _ in range(int(expand)):
+        pts = dilate_points(pts, voxel_size)
+    scene_origin, scale = sfm_cube(scene_config, radius)
+    dev = torch.device(device if not isinstance(device, int) else "cuda:%d" % device)
+    data = octree_from_points(torch.from_numpy(np.ascontiguousarray(pts)).to(dev), voxel_size, scene_origin, scale)
+    data["scene_origin"] = torch.from_numpy(scene_origin).to(dev)  # float64, like renderer.py:144
+    return data
 
 
 def get_near_far(rays_o_sfm, rays_d, octree_data):
@@ -143,11 +207,10 @@ def surface_selection(renderer, train_level, threshold, chunk=1 << 22, group=Non
 
 
 @torch.no_grad()
-def octree_from_points(points_sfm, voxel_size, scene_origin, scale):
-    """generate_voxel.py:75-171 `gen_octree(expand=False)` for points already in SfM space: normalise into the
-    cube, keep the points STRICTLY inside (-1,1)^3, level = floor(log2(2 scale / voxel_size)), quantise with
-    kaolin's documented rule floor(clamp(2^level (x+1)/2, 0, 2^level - 1)) -- all in float64 as numpy does.
-    The kaolin octree/SPC tensors are replaced by the dense bit mask the ray kernel reads."""
+def quantise_points(points_sfm, voxel_size, scene_origin, scale):
+    """generate_voxel.py:113-150: normalise into the cube (float64 as numpy does), keep the points STRICTLY
+    inside (-1,1)^3, level = floor(log2(2 scale / voxel_size)), kaolin's documented quantisation rule
+    floor(clamp(2^level (x+1)/2, 0, 2^level - 1)).  Returns (q [K,3] int64, level).  Runs on any device."""
     dev = points_sfm.device
     origin64 = torch.as_tensor(scene_origin, dtype=torch.float64, device=dev).reshape(3)
     level = int(math.floor(math.log2(2 * float(scale) / float(voxel_size))))
@@ -157,6 +220,17 @@ def octree_from_points(points_sfm, voxel_size, scene_origin, scale):
     inside = (pn > -1).all(-1) & (pn < 1).all(-1)
     res = 2 ** level
     q = torch.floor(torch.clamp(res * (pn[inside] + 1.0) / 2.0, 0, res - 1.0)).long()
+    return q, level
+
+
+@torch.no_grad()
+def octree_from_points(points_sfm, voxel_size, scene_origin, scale):
+    """generate_voxel.py:75-171 `gen_octree(expand=False)` for points already in SfM space (quantise_points).
+    The kaolin octree/SPC tensors are replaced by the dense bit mask the ray kernel reads."""
+    dev = points_sfm.device
+    origin64 = torch.as_tensor(scene_origin, dtype=torch.float64, device=dev).reshape(3)
+    q, level = quantise_points(points_sfm, voxel_size, scene_origin, scale)
+    res = 2 ** level
     centres = ((q.float() + 0.5) * (2.0 / res) - 1.0)          # voxel centres quantise back to q exactly
     data = occupancy_from_points(centres * float(scale) + origin64.float(), origin64.float(), float(scale), level,
                                  voxel_size)

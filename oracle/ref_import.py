@@ -24,9 +24,73 @@ REFERENCE_ROOT = os.environ.get("NEUCONW_REFERENCE_ROOT", "/root/reference")
 _STUBS = [
     "open3d", "kaolin", "kaolin.ops", "kaolin.ops.spc", "kaolin.render", "kaolin.render.spc",
     "cv2", "torchvision", "torchvision.transforms", "h5py", "torch_optimizer", "trimesh",
-    "skimage", "skimage.measure", "loguru", "kornia", "kornia.losses", "lpips", "yacs",
-    "yacs.config", "test_tube", "pytorch_lightning.loggers", "pytorch_lightning.callbacks",
+    "skimage", "skimage.measure", "loguru", "kornia", "kornia.losses", "lpips",
+    "test_tube", "pytorch_lightning.loggers", "pytorch_lightning.callbacks",
 ]
+
+
+class CfgNode(dict):
+    """Stand-in for yacs.config.CfgNode (yacs is not installed): a dict with attribute access, `clone()` and
+    `merge_from_file()` with yacs' value decoding (strings go through literal_eval: "(4,)" -> (4,), "1e-4" ->
+    1e-4).  Enough for the reference's config/defaults.py + config/*.yaml."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def clone(self):
+        import copy
+
+        return copy.deepcopy(self)
+
+    @staticmethod
+    def _decode(v):
+        import ast
+
+        if isinstance(v, dict):
+            n = CfgNode()
+            for k, x in v.items():
+                n[k] = CfgNode._decode(x)
+            return n
+        if isinstance(v, str):
+            try:
+                return ast.literal_eval(v)
+            except (ValueError, SyntaxError):
+                return v
+        return v
+
+    def _merge(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict) and isinstance(self.get(k), dict):
+                self[k]._merge(v)
+            else:
+                self[k] = v
+
+    def merge_from_file(self, path):
+        import yaml
+
+        with open(path, "r") as f:
+            self._merge(CfgNode._decode(yaml.safe_load(f)))
+
+    def freeze(self):
+        pass
+
+    def defrost(self):
+        pass
+
+
+def _install_yacs():
+    if "yacs.config" in sys.modules and getattr(sys.modules["yacs.config"], "CfgNode", None) is CfgNode:
+        return
+    y, yc = types.ModuleType("yacs"), types.ModuleType("yacs.config")
+    yc.CfgNode = CfgNode
+    y.config = yc
+    sys.modules["yacs"], sys.modules["yacs.config"] = y, yc
 
 
 def available() -> bool:
@@ -48,6 +112,7 @@ def load():
     for name in _STUBS:
         if name not in sys.modules:
             sys.modules[name] = mock.MagicMock()
+    _install_yacs()
     if "pytorch_lightning" not in sys.modules:
         pl = types.ModuleType("pytorch_lightning")
 
@@ -90,3 +155,19 @@ def load():
     )
     _loaded["ns"] = ns
     return ns
+
+
+def load_system():
+    """Returns (module lightning_modules.neuconw_system, function get_cfg_defaults) of the real reference.  The
+    drop-in test swaps the three classes the module imported (neuconw_system.py:7-12) for ours -- the same edit
+    INTEGRATION.md section 1 asks a maintainer to make in the import lines."""
+    load()
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        import importlib
+
+        sysmod = importlib.import_module("lightning_modules.neuconw_system")
+        defaults = importlib.import_module("config.defaults")
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
+    return sysmod, defaults.get_cfg_defaults

@@ -13,7 +13,7 @@ from tests._util import ROOT, load_golden
 
 def _header_symbols():
     src = open(os.path.join(ROOT, "include", "neuconw_hip.h")).read()
-    return sorted(set(re.findall(r"^int\s+(ncw_\w+)\s*\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|int64_t)\s+(ncw_\w+)\s*\(", src, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():
