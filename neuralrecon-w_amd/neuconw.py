@@ -426,7 +426,8 @@ class RenderingNetwork(_PackedNet):
         d_a_rows [n,n_a], every point's row is stored instead (the caller reduces them: ncw_ray_sum_rows)."""
         dev = self._first_param().device
         d_rgb = d_rgb.contiguous().float()
-        assert d_grad.is_contiguous() and d_a.is_contiguous()
+        assert d_grad.is_contiguous() and (d_a is None or d_a.is_contiguous())
+        assert (d_a is None) != (d_a_rows is None), "exactly one of d_a / d_a_rows"
         L.check(L.get_lib().ncw_color_bwd(ctx["plan"].net, ctx["prec"], ctx["pts"], ctx["n"], L.ptr(ctx["rgb"]),
                                           L.ptr(d_rgb), L.ptr(d_grad), L.ptr(d_a), L.ptr(d_a_rows), dfeat_ptr, ctx["stash"],
                                           L.stream_ptr(dev)), "ncw_color_bwd")

@@ -59,10 +59,12 @@ def test_max_samples_per_ray_and_one_past():
                    torch.zeros(1, 3, dtype=torch.float64))
     for k in ("color", "depth", "weights_sum"):
         assert rel_err(out[k].detach().cpu(), ref[k]) < 5e-4, (k, rel_err(out[k].detach().cpu(), ref[k]))
-    emb, neuconw, nerf, rdr = build_system(seed=3, prec=nw.PREC_F32, n_samples=256, n_importance=256)
+    with pytest.raises(ValueError, match="512"):  # refused at construction, with the reason (config/defaults.py's 512 + 512)
+        build_system(seed=3, prec=nw.PREC_F32, n_samples=256, n_importance=256)
+    # ... and the C ABI itself refuses an over-long ray instead of truncating it
+    from neuralrecon_w_amd import rayops
     with pytest.raises(nw.NeuconwHipError):
-        rdr.render(rays.cuda(), ts.cuda(), label.cuda(), perturb_overwrite=0,
-                   background_rgb=torch.zeros(1, 3).cuda(), cos_anneal_ratio=0.5)
+        rayops.sort_merge(torch.rand(4, 300, device="cuda"), torch.rand(4, 300, device="cuda"))
     torch.cuda.synchronize()
 
 
