@@ -17,6 +17,15 @@ LIB = os.path.join(HERE, "libneuconw_hip%s.so" % ("_" + TAG if TAG else ""))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
 FLAGS += os.environ.get("NCW_EXTRA_HIPCC_FLAGS", "").split()
+# The fine-interleaved MLP kernels (ncw_pp.hip) are VALU-issue-bound next to their MFMAs.  IEEE mode
+# makes hipcc quiet every fmin/fmax input with an extra `v_max_f32 x, x, x`, and the SLP vectoriser forms v_pk_fma_f32 /
+# v_pk_mul_f32, which cost ~10 issue cycles each beside MFMAs (scripts/probes/issue_probe.hip): both are switched off
+# for that file only (measured on the older kernels: sdf_infer -20 %, but sdf_bwd +24 % and nerf_fwd +10 %, so they keep
+# the defaults).  Nothing in it branches on NaNs.
+MLP_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee", "-fno-slp-vectorize"]
+MLP_FILES = {"ncw_pp.hip"}
+if "NCW_MLP_FLAGS" in os.environ:  # A/B builds (scripts/): e.g. NCW_MLP_FLAGS="" NCW_BUILD_TAG=plain
+    MLP_FLAGS = os.environ["NCW_MLP_FLAGS"].split()
 
 
 def _sources():
@@ -34,7 +43,7 @@ def _compile(src):
     srcp = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), _deps_mtime()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", srcp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + (MLP_FLAGS if src in MLP_FILES else []) + ["-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -4,8 +4,6 @@
 
 #include "ncw_mlp.h"
 
-int ncw_color_fwd8_launch(const NcwColorNet* net, const NcwPoints& src, int64_t n, const float* normals, const float* a,
-                          const void* feat_stash, float* rgb, const NcwColorStash& stash, hipStream_t st);  // ncw_sdf8.hip
 
 // AUX2 (1 block): [points (3) | normals (3) | 0...]   (neuconw.py:147-148)
 NCW_DEV void build_aux2(CVec<1>& aux, const float (&x)[3], const float (&nrm)[3], int lane) {
@@ -254,12 +252,6 @@ extern "C" int ncw_color_fwd(const NcwColorNet* net, int prec, const NcwPoints* 
     if (!color_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    // d_feature = 256 bf16: NCW_COLOR_FWD8=1 selects the weights-stationary kernel of ncw_sdf8.hip (correct; measured
-    // equal to this two-workgroups-per-CU kernel, 0.17 ms, so it is not the default)
-    static const int fwd8 = getenv("NCW_COLOR_FWD8") ? atoi(getenv("NCW_COLOR_FWD8")) : 0;
-    if (fwd8 > 0 && net->rbf == 8 && net->rbh == 4 && net->rbc == 8 && prec == NCW_PREC_BF16 && net->n_head >= 1 &&
-        net->n_head <= 4 && net->n_lin >= 2)
-        return ncw_color_fwd8_launch(net, *pts, n, normals, a, feat_stash, rgb, *stash, st);
     NCW_COLOR_DISPATCH(color_fwd_kernel, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
     return 0;
 }

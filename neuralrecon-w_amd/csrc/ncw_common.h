@@ -386,14 +386,26 @@ NCW_DEV void softplus100(float z, float& y, float& s) {
     return;
 #endif
     if (FAST) {
-        // overflow-free form, 6 VALU ops (2 transcendental) for y and 3 more (1 transcendental) for s:
-        //   w = exp(-|100 z|) in (0,1];  y = max(z,0) + log(1+w)/100;  s = 1 - exp(-100 y)  (== sigmoid(100 z)).
-        // Above torch's threshold (100 z > 20) w < 2.1e-9, so y = z and s = 1 to f32 rounding -- the same
-        // values the thresholded reference form returns.
+        // bf16 kernels: y = max(z, 0) + c(|z|) with the correction c(a) = log1p(exp(-100 a)) / 100 evaluated as a
+        // degree-4 polynomial on [0, 0.06] and held constant beyond (there c < 2.5e-5): max abs error 8.4e-6 inside,
+        // <= 3.3e-5 everywhere = 1/12 of a bf16 ulp at 0.1, far below the bf16 rounding the value gets next.
+        // 7 plain VALU instead of 4 plain + 2 transcendentals: at W = 256 every MFMA produces one accumulator register
+        // per lane and these kernels are bound by VALU issue next to the MFMAs (scripts/probes/issue_probe.hip), so
+        // the epilogue's instruction count IS the kernel time.  s = 1 - exp(-100 y) (== sigmoid(100 z)) as before; it is
+        // dead code wherever Softplus' is recomputed from the stashed h.  The fp32 kernels keep the exact form below.
+#ifdef NCW_EXACT_SOFTPLUS  // A/B switch: the exact 2-transcendental form
         const float t = z * 144.26950408889634f;  // 100 z log2(e)
         const float w = __builtin_amdgcn_exp2f(-__builtin_fabsf(t));
         const float l = __builtin_amdgcn_logf(1.f + w);  // log2(1 + w)
         y = __builtin_fmaf(l, 0.6931471805599453f * 0.01f, __builtin_fmaxf(z, 0.f));
+#else
+        const float a = __builtin_fminf(__builtin_fabsf(z), 0.06f);
+        float r = __builtin_fmaf(1067.48234f, a, -204.559567f);
+        r = __builtin_fmaf(r, a, 15.0247592f);
+        r = __builtin_fmaf(r, a, -0.510720189f);
+        r = __builtin_fmaf(r, a, 0.00693755643f);
+        y = __builtin_fmaxf(z, 0.f) + r;
+#endif
         s = 1.f - __builtin_amdgcn_exp2f(y * -144.26950408889634f);
     } else {
         const float bz = 100.f * z;

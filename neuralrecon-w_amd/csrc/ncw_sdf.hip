@@ -401,18 +401,20 @@ int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n,
 int ncw_sdf_fwd8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
                         hipStream_t st);  // ncw_sdf8.hip
 
-int ncw_sdf_bwd8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, const float* d_sdf, const float* d_grad,
-                        const NcwSdfStash& stash, hipStream_t st);  // ncw_sdf8.hip
+int ncw_sdf_inferC_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);  // ncw_pp.hip
 
 static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, int64_t n, float* sdf, void* stream) {
     if (!sdf_net_ok(net) || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (variant 2; 0.20 vs 0.26 ms per 131,072 points).
-    // NCW_SDF_INFER8 = 0 selects the weights-through-LDS kernel below, 1 the 8-wave / half-layer pilot.
-    static const int variant8 = getenv("NCW_SDF_INFER8") ? atoi(getenv("NCW_SDF_INFER8")) : 2;
+    // W = 256 bf16: variant 3 = the fine-interleaved kernel of ncw_pp.hip (default: 0.165 ms per 131,072 points),
+    // 2 = the weights-stationary burst kernel of ncw_sdf8.hip (0.170 ms with the polynomial Softplus, 0.198 before it),
+    // 0 = the weights-through-LDS kernel below (0.26 ms).
+    static const int variant8 = getenv("NCW_SDF_INFER8") ? atoi(getenv("NCW_SDF_INFER8")) : 3;
+    if (variant8 == 3 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3 && net->n_layers <= 12)
+        return ncw_sdf_inferC_launch(net, src, n, sdf, st);
     if (variant8 > 0 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
-        return ncw_sdf_infer8_launch(net, src, n, sdf, st, variant8);
+        return ncw_sdf_infer8_launch(net, src, n, sdf, st, variant8 == 3 ? 2 : variant8);
     NCW_SDF_DISPATCH(sdf_infer_kernel, *net, src, n, sdf);
     return 0;
 }
@@ -458,10 +460,6 @@ extern "C" int ncw_sdf_bwd(const NcwSdfNet* net, int prec, const NcwPoints* pts,
     if (!sdf_net_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    // W = 256 bf16: NCW_SDF_BWD8 selects the weights-stationary kernel of ncw_sdf8.hip
-    static const int bwd8 = getenv("NCW_SDF_BWD8") ? atoi(getenv("NCW_SDF_BWD8")) : 0;
-    if (bwd8 > 0 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
-        return ncw_sdf_bwd8_launch(net, *pts, n, d_sdf, d_grad, *stash, st);
     NCW_SDF_DISPATCH(sdf_bwd_kernel, *net, *pts, n, d_sdf, d_grad, *stash);
     return 0;
 }

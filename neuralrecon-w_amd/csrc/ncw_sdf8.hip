@@ -1,180 +1,9 @@
-// SDF inference (SDFNetwork.sdf, models/neuconw.py:281-282), bf16, W = 256: the two structures tried for round 2 of
-// the fused MLP kernels on the simplest of them.  Variant 2 (weights stationary in registers,
-// activations through LDS -- second half of this file) is the DEFAULT inference kernel at W = 256 bf16; variant 1
-// (below) is kept as the measured alternative:
-//   * ONE 8-wave workgroup per CU (<= 256 registers per lane): 256 points share every weight byte that is
-//     streamed L2 -> LDS (the 4-wave kernels re-stream the network for every 128 points), and two waves per
-//     SIMD overlap one wave's Softplus epilogue with the other's MFMAs;
-//   * HALF-LAYER accumulators: a 256 -> 256 layer is two passes of 4 output blocks (64 accumulator registers
-//     instead of 128), which is what makes 256 registers enough without spilling;
-//   * the existing packed layout [unit][8 out-blocks][64 lanes][16 B] is kept: the LDS-DMA gathers the
-//     4 out-blocks of a half with a strided piece list (one 1 KiB piece = one (unit, out-block) fragment set),
-//     so a 64-80 KiB slot holds one resident half-matrix and there is ONE barrier per half-layer.
-// Selected by the environment variable NCW_SDF_INFER8=1 (ncw_sdf.hip); results are identical to sdf_infer_kernel
-// up to the order of the bf16 roundings (same MFMA sequence per output block).
+// Weights-stationary fused MLP kernels, W = 256 bf16: sdf_inferB, sdf_fwdB, nerf_fwdB, nerf_bwdB.
+// (The 8-wave / half-layer pilot of round 1 and the sdf_bwd / color_fwd ports that did not beat the
+// two-workgroups-per-CU kernels were removed in round 2; numbers in DESIGN.md.)
 #include "ncw_mlp.h"
 
 namespace {
-
-constexpr int S8_WAVES = 8;
-constexpr int S8_SLOT = 80 * 1024;  // the skip layer's half: 19 units x 4 KiB = 76 KiB
-
-// DMA `units` x NB out-blocks (starting at out-block ob0 of a packed matrix with RB_STRIDE out-blocks) into a slot
-// laid out [unit][NB][64 lanes][16 B]
-template <int NB, int RB_STRIDE>
-NCW_DEV void s8_issue(ncw_lchar* slot, const void* wbase, int units, int ob0) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const char* g = reinterpret_cast<const char*>(wbase) + lane * 16;
-    const int pieces = units * NB;
-#ifdef S8_NODMA  // timing experiment only
-    return;
-#endif
-    for (int pc = wave; pc < pieces; pc += S8_WAVES) {
-        const int u = pc / NB, ob = pc - u * NB;
-        __builtin_amdgcn_global_load_lds((ncw_gvoid*)(g + (size_t)(u * RB_STRIDE + ob0 + ob) * 1024),
-                                         (ncw_lvoid*)(slot + pc * 1024), 16, 0, 0);
-    }
-}
-
-// acc[NB] += W_half . B  with the half-matrix resident in `slot` ([unit][NB][lane]); K_REAL as in mma_stream
-#ifndef S8_HOIST
-#define S8_HOIST 2
-#endif
-template <int NB, int RB_IN, int K_REAL, class BP, int HOIST = S8_HOIST>
-NCW_DEV void s8_mma(CVec<NB>& acc, const BP& bp, const ncw_lchar* slot, int lane) {
-    typedef const __attribute__((address_space(3))) bf16x8* lfrag_t;
-    lfrag_t lw = (lfrag_t)slot + lane;
-    int uu = 0;  // units are stored densely in the order they are used
-#pragma unroll
-    for (int q = 0; q < 2 * RB_IN; ++q) {
-        if (16 * q >= K_REAL) continue;
-        const auto b = bp.b(q >> 1, q & 1);
-        bf16x8 a[NB];
-#pragma unroll
-        for (int ro = 0; ro < NB; ++ro) a[ro] = (lw + uu * NB * 64)[ro * 64];
-#pragma unroll
-        for (int ro = 0; ro < NB; ++ro) acc.v[ro] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ro], b, acc.v[ro], 0, 0, 0);
-        ++uu;
-        if (uu % HOIST == 0) __builtin_amdgcn_sched_barrier(0);  // bound how far hipcc hoists the fragment reads
-    }
-}
-
-template <int RA, int RG>
-struct S8Cat {  // [a | g] B provider without a copy
-    const Act<PrecBF16, RA>& a;
-    const Act<PrecBF16, RG>& g;
-    NCW_DEV S8Cat(const Act<PrecBF16, RA>& a_, const Act<PrecBF16, RG>& g_) : a(a_), g(g_) {}
-    NCW_DEV bf16x8 b(int rb, int sub) const { return rb < RA ? a.f[2 * (rb < RA ? rb : 0) + sub] : g.f[2 * (rb >= RA ? rb - RA : 0) + sub]; }
-};
-template <int RA>
-struct S8Act {
-    const Act<PrecBF16, RA>& a;
-    NCW_DEV explicit S8Act(const Act<PrecBF16, RA>& a_) : a(a_) {}
-    NCW_DEV bf16x8 b(int rb, int sub) const { return a.f[2 * rb + sub]; }
-};
-
-NCW_DEV void s8_bias(CVec<4>& acc, const float* __restrict__ bp, int half, int lane) {
-    load_bias(acc, bp + half * 4 * 32, lane);  // packed bias [rb][h][16]
-}
-
-// new_act blocks [4 half, 4 half + 4) = Softplus100(acc)
-NCW_DEV void s8_epilogue(Act<PrecBF16, 8>& out, const CVec<4>& acc, int half) {
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-        f32x16 yv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float y, s;
-#ifdef S8_NOSP  // timing experiment only
-            y = __builtin_fmaxf(acc.v[rb][r], 0.f);
-#else
-            softplus100<true>(acc.v[rb][r], y, s);
-#endif
-            yv[r] = y;
-        }
-        to_act_block<8>(out, 4 * half + rb, yv);
-    }
-}
-
-__global__ __launch_bounds__(64 * S8_WAVES) void sdf_infer8_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
-                                                                  float* __restrict__ sdf) {
-    typedef PrecBF16 P;
-    __shared__ __attribute__((aligned(16))) char ring_mem[2 * S8_SLOT];
-    ncw_lchar* slot[2] = {(ncw_lchar*)ring_mem, (ncw_lchar*)ring_mem + S8_SLOT};
-    const int lane = ncw_lane();
-    const int L = net.n_layers;
-    int64_t tile, p, ray;
-    bool valid;
-    tile_setup(n, tile, p, valid, lane);
-    float xs[3];
-    load_point(src, p, xs, ray);
-    xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
-    // what the ring holds, in consumption order: W0 (whole, 3 units x 8), then (W_l, half) for l = 1..L-2, then W_{L-1}
-    auto issue_step = [&](int step, ncw_lchar* dst) {  // step 0 = W0; 1 + 2 (l-1) + half = hidden; last = sdf row
-        const int nh = 2 * (L - 2);
-        if (step == 0) s8_issue<8, 8>(dst, net.w[0], 3, 0);
-        else if (step <= nh) {
-            const int l = 1 + (step - 1) / 2, half = (step - 1) & 1;
-            s8_issue<4, 8>(dst, net.w[l], l == net.skip_layer ? 19 : 16, 4 * half);
-        } else if (step == nh + 1) s8_issue<1, 1>(dst, net.w[L - 1], 16, 0);
-    };
-    int cur = 0, step = 0;
-    issue_step(0, slot[0]);
-    Act<P, 8> act, nact;
-    Act<P, 2> gact;
-    {
-        CVec<2> gam;
-        freq_encode<2, 3, 6, true>(gam, xs, lane);
-        to_act(gact, gam);
-    }
-    // ---- layer 0: K = 39, both halves from the one resident copy of W0 ([unit][8 blocks]) ------------------
-    __syncthreads();
-    issue_step(++step, slot[cur ^ 1]);
-    {
-        typedef const __attribute__((address_space(3))) bf16x8* lfrag_t;
-        lfrag_t lw = (lfrag_t)slot[cur] + lane;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            CVec<4> acc;
-            s8_bias(acc, net.b[0], half, lane);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const bf16x8 b = gact.f[q];
-#pragma unroll
-                for (int ro = 0; ro < 4; ++ro)
-                    acc.v[ro] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((lw + q * 8 * 64)[(4 * half + ro) * 64], b, acc.v[ro], 0, 0, 0);
-            }
-            s8_epilogue(nact, acc, half);
-        }
-        act = nact;
-    }
-    cur ^= 1;
-    // ---- hidden layers -----------------------------------------------------------------------------
-    for (int l = 1; l < L - 1; ++l) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#ifndef S8_NOBAR  // timing experiment only
-            __syncthreads();  // slot[cur] has landed (vmcnt(0) in front of the barrier); slot[cur^1] is free
-#endif
-            issue_step(++step, slot[cur ^ 1]);
-            CVec<4> acc;
-            s8_bias(acc, net.b[l], half, lane);
-            if (l == net.skip_layer) s8_mma<4, 10, 256 + 39>(acc, S8Cat<8, 2>(act, gact), slot[cur], lane);
-            else s8_mma<4, 8, 256>(acc, S8Act<8>(act), slot[cur], lane);
-            s8_epilogue(nact, acc, half);
-            cur ^= 1;
-        }
-        act = nact;
-    }
-    // ---- sdf row -----------------------------------------------------------------------------------
-    __syncthreads();
-    CVec<1> o;
-    load_bias(o, net.b[L - 1], lane);
-    s8_mma<1, 8, 256>(o, S8Act<8>(act), slot[cur], lane);
-    if (valid && lane < 32) sdf[p] = o.v[0][0] / net.scale;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Variant 2 (default; NCW_SDF_INFER8=2): WEIGHTS STATIONARY IN REGISTERS, ACTIVATIONS THROUGH LDS.
@@ -992,402 +821,13 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// sdf_bwd in the weights-stationary structure (NCW_SDF_BWD8), W = 256 bf16: (1) backward of the adjoint pass
-// l = 0 .. L-2 (tbar = W qbar, abar = tbar phi', zbar2 = tbar 100 t (1 - phi')), (2) backward of the forward pass
-// l = L-1 .. 0 (ubar = W^T zbar, zbar = ubar phi' + zbar2) -- the arithmetic and the stash of sdf_bwd_kernel.
-// gbuf: units 0..2 of a tile = qbar_0 = J_gamma nbar, unit 3 = the d_sdf block.
-// ------------------------------------------------------------------------------------------------
-constexpr int SB_G4 = SB_TILES * 4 * 1024;
-
-__global__ __launch_bounds__(64 * SB_WAVES) void sdf_bwdB_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
-                                                                const float* __restrict__ d_sdf,
-                                                                const float* __restrict__ d_grad, NcwSdfStash st) {
-    typedef __bf16 SE;
-    __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_G4];
-    sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
-    sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
-    sb_lfrag* const gbuf = abuf0 + 2 * SB_ACT / 16;
-    const int lane = ncw_lane();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int L = net.n_layers;
-    const int64_t tile0 = (int64_t)blockIdx.x * SB_TILES;
-    typedef const __attribute__((address_space(1))) bf16x8* gfrag;
-    if (wave < SB_TILES) {
-        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
-        const bool valid = p < n;
-        if (!valid) p = n - 1;
-        float xs[3];
-        load_point(src, p, xs, ray);
-        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
-        const float vmask = valid ? 1.f : 0.f;  // padded lanes must contribute nothing to weight grads
-        const float nb[3] = {d_grad[p * 3 + 0] * vmask, d_grad[p * 3 + 1] * vmask, d_grad[p * 3 + 2] * vmask};
-        const float dsdf = d_sdf[p] * vmask / net.scale;
-        const int h = lane >> 5;
-        CVec<2> q0;  // qbar_0 = J_gamma nbar
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (32 * rb + ncw_feat_of(r, 0) >= 39) {
-                    q0.v[rb][r] = 0.f;
-                    continue;
-                }
-                int comp;
-                const float dv = freq_feature_deriv<3, 6, true>(xs, 32 * rb + ncw_feat_of(r, 0) + 4 * h, comp);
-                q0.v[rb][r] = dv * (comp == 0 ? nb[0] : (comp == 1 ? nb[1] : nb[2]));
-            }
-        stash_store<2>((SE*)st.qbar[0], (size_t)(tile0 + wave), q0, lane);
-        Act<PrecBF16, 2> q0a;
-        to_act(q0a, q0);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) gbuf[(wave * 4 + q) * 64 + lane] = q0a.f[q];
-        CVec<1> zs, one;
-        cvec_zero(zs);
-        cvec_zero(one);
-        zs.v[0][0] = (lane < 32) ? dsdf : 0.f;
-        one.v[0][0] = (lane < 32) ? vmask : 0.f;
-        stash_store<1>((SE*)st.zsdf, (size_t)(tile0 + wave), zs, lane);
-        stash_store<1>((SE*)st.one, (size_t)(tile0 + wave), one, lane);
-        Act<PrecBF16, 1> zsa;
-        to_act(zsa, zs);
-        gbuf[(wave * 4 + 3) * 64 + lane] = zsa.f[0];
-    }
-    bf16x8 wa[16], wb[16], wg[3];
-    f32x16 zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-    // one output block of a tile pair: (tbar) -> zbar2_l (temporarily in zbar[l]), abar_l = qbar_{l+1} (stash + LDS)
-    auto adj_epilogue = [&](const f32x16& tbar, int l, int t, sb_lfrag* out) {
-        f32x16 sv, tv, z2, ab;
-        load_sprime_block_bf16(sv, (const SE*)st.h[l + 1], (size_t)(tile0 + t), 8, wave, lane);
-        stash_load_block(tv, (const SE*)st.t[l], (size_t)(tile0 + t), 8, wave, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            z2[r] = tbar[r] * 100.f * tv[r] * (1.f - sv[r]);  // a_l phi''(z_l) = 100 t_l (1 - s_l)
-            ab[r] = tbar[r] * sv[r];
-        }
-        stash_store_block((SE*)st.zbar[l], (size_t)(tile0 + t), 8, wave, z2, lane);
-        stash_store_block((SE*)st.qbar[l + 1], (size_t)(tile0 + t), 8, wave, ab, lane);
-        sb_store_units(out, t, wave, ab, lane);
-    };
-    // ---- (1) layer 0: tbar = W_0 qbar_0 (3 units) ----------------------------------------------------------
-    {
-        bf16x8 w0[3];
-        sb_load_slice<3>(w0, net.w[0], 8, wave, 0, lane);
-        if (1 <= L - 2) sb_load_slice<16>(wa, net.w[1], 8, wave, 0, lane);
-        else sb_load_slice<16>(wa, net.wt_feat, 8, wave, 0, lane);
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < SB_TILES; ++t) {
-            f32x16 acc = zero16;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[q], gbuf[(t * 4 + q) * 64 + lane], acc, 0, 0, 0);
-            adj_epilogue(acc, 0, t, abuf0);
-        }
-    }
-    int cur = 0;
-    for (int l = 1; l <= L - 2; ++l) {  // wa = slice of w[l]
-        const bool skip = (l == net.skip_layer);
-        if (skip) sb_load_slice<3>(wg, net.w[l], 8, wave, 16, lane);
-        sb_load_slice<16>(wb, l + 1 <= L - 2 ? net.w[l + 1] : net.wt_feat, 8, wave, 0, lane);
-        __syncthreads();
-        const sb_lfrag* in = cur ? abuf1 : abuf0;
-        sb_lfrag* out = cur ? abuf0 : abuf1;
-#pragma unroll
-        for (int tp = 0; tp < SB_TILES; tp += 2) {
-            f32x16 acc0 = zero16, acc1 = zero16;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
-            }
-            if (skip) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[(tp * 4 + q) * 64 + lane], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[((tp + 1) * 4 + q) * 64 + lane], acc1, 0, 0, 0);
-                }
-            }
-            adj_epilogue(acc0, l, tp, out);
-            adj_epilogue(acc1, l, tp + 1, out);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
-        cur ^= 1;
-    }
-    // ---- (2) u = wt_feat dfeat + wt[L-1] d_sdf  (wa = slice of wt_feat) ---------------------------------------------
-    // zbar_l = u phi'(z_l) + zbar2_l  -> stash zbar[l] (+ LDS when a further layer consumes it)
-    auto fwd_epilogue = [&](const f32x16& u, int l, int t, sb_lfrag* out) {
-        f32x16 sv, z2;
-        load_sprime_block_bf16(sv, (const SE*)st.h[l + 1], (size_t)(tile0 + t), 8, wave, lane);
-        stash_load_block(z2, (const SE*)st.zbar[l], (size_t)(tile0 + t), 8, wave, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z2[r] = u[r] * sv[r] + z2[r];
-        stash_store_block((SE*)st.zbar[l], (size_t)(tile0 + t), 8, wave, z2, lane);
-        if (l > 0) sb_store_units(out, t, wave, z2, lane);
-    };
-    {
-        // dfeat block `wave` of the 4 tiles: stash -> B fragments, INTO abuf[cur]: that buffer holds qbar_{L-1}, which
-        // nobody reads (it only goes to the stash) and of which this wave owns exactly the units it overwrites; the
-        // other buffer may still be being read by slower waves (it was the input of the last layer of pass 1)
-        sb_lfrag* dbuf = cur ? abuf1 : abuf0;
-#pragma unroll
-        for (int t = 0; t < SB_TILES; ++t) {
-            f32x16 df;
-            stash_load_block(df, (const SE*)st.dfeat, (size_t)(tile0 + t), 8, wave, lane);
-            sb_store_units(dbuf, t, wave, df, lane);
-        }
-        const bf16x8 wl = ((gfrag)net.wt[L - 1])[(size_t)wave * 64 + lane];  // wt[L-1]: 8 out-blocks, unit 0 (K = 1)
-        if (L - 2 > 0) sb_load_slice<16>(wb, net.wt[L - 2], (L - 2 == net.skip_layer) ? 10 : 8, wave, 0, lane);
-        __syncthreads();  // dfeat complete in dbuf; every wave is done with the other buffer
-        sb_lfrag* out = cur ? abuf0 : abuf1;
-#pragma unroll
-        for (int tp = 0; tp < SB_TILES; tp += 2) {
-            f32x16 u0 = zero16, u1 = zero16;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], dbuf[(tp * 16 + q) * 64 + lane], u0, 0, 0, 0);
-                u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], dbuf[((tp + 1) * 16 + q) * 64 + lane], u1, 0, 0, 0);
-            }
-            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, gbuf[(tp * 4 + 3) * 64 + lane], u0, 0, 0, 0);
-            u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, gbuf[((tp + 1) * 4 + 3) * 64 + lane], u1, 0, 0, 0);
-            fwd_epilogue(u0, L - 2, tp, out);
-            fwd_epilogue(u1, L - 2, tp + 1, out);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
-        cur ^= 1;  // zbar_{L-2} lives in abuf[cur]
-    }
-    for (int l = L - 2; l >= 1; --l) {  // u = wt[l] zbar_l (wa), zbar_{l-1} = u phi'(z_{l-1}) + zbar2_{l-1}
-        if (l - 1 > 0) sb_load_slice<16>(wb, net.wt[l - 1], (l - 1 == net.skip_layer) ? 10 : 8, wave, 0, lane);
-        __syncthreads();
-        const sb_lfrag* in = cur ? abuf1 : abuf0;
-        sb_lfrag* out = cur ? abuf0 : abuf1;
-#pragma unroll
-        for (int tp = 0; tp < SB_TILES; tp += 2) {
-            f32x16 u0 = zero16, u1 = zero16;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], u0, 0, 0, 0);
-                u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], u1, 0, 0, 0);
-            }
-            fwd_epilogue(u0, l - 1, tp, out);
-            fwd_epilogue(u1, l - 1, tp + 1, out);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
-        cur ^= 1;
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// color_fwd (RenderingNetwork, models/neuconw.py:59-170) in the weights-stationary structure (NCW_COLOR_FWD8),
-// d_feature = 256, head 128, trunk 256, bf16: f = xyz_encoding_final(feat), the appearance head on [f | AUX1],
-// the trunk on [e | AUX2], sigmoid rgb -- the arithmetic and stash of color_fwd_kernel (ncw_color.hip).
-// cbuf ([4 tiles][7 units]): units 0..5 = AUX1 = [gamma(dir) | appearance code], unit 6 = AUX2 = [point | normal].
-// ------------------------------------------------------------------------------------------------
-constexpr int SB_C7 = SB_TILES * 7 * 1024;
-
-NCW_DEV void sb_build_aux2(CVec<1>& aux, const float (&x)[3], const float (&nrm)[3], int lane) {  // neuconw.py:147-148
-    const int h = lane >> 5;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float v = 0.f;
-        if (ncw_feat_of(r, 0) < 6) {
-            const int f = ncw_feat_of(r, 0) + 4 * h;
-            v = f == 0 ? x[0] : f == 1 ? x[1] : f == 2 ? x[2] : f == 3 ? nrm[0] : f == 4 ? nrm[1] : f == 5 ? nrm[2] : 0.f;
-        }
-        aux.v[0][r] = v;
-    }
-}
-
-__global__ __launch_bounds__(64 * SB_WAVES) void color_fwdB_kernel(NcwColorNet net, NcwPoints src, int64_t n,
-                                                                  const float* __restrict__ normals,
-                                                                  const float* __restrict__ a,
-                                                                  const void* __restrict__ feat_stash, float* __restrict__ rgb,
-                                                                  NcwColorStash st) {
-    typedef __bf16 SE;
-    __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_C7];
-    sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
-    sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
-    sb_lfrag* const cbuf = abuf0 + 2 * SB_ACT / 16;
-    const int lane = ncw_lane();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t tile0 = (int64_t)blockIdx.x * SB_TILES;
-    const int hb = wave & 3, hp = wave >> 2, ta = 2 * hp, tb = 2 * hp + 1;
-    int64_t pp = 0;
-    bool pvalid = false;
-    if (wave < SB_TILES) {
-        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
-        pvalid = p < n;
-        if (!pvalid) p = n - 1;
-        pp = p;
-        float xs[3];
-        load_point(src, p, xs, ray);
-        const float dir[3] = {src.rays_d[ray * 3 + 0], src.rays_d[ray * 3 + 1], src.rays_d[ray * 3 + 2]};
-        const float nrm[3] = {normals[p * 3 + 0], normals[p * 3 + 1], normals[p * 3 + 2]};
-        CVec<3> aux1;
-        build_aux1<true>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
-        stash_store<3>((SE*)st.aux1, (size_t)(tile0 + wave), aux1, lane);
-        Act<PrecBF16, 3> a1;
-        to_act(a1, aux1);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) cbuf[(wave * 7 + q) * 64 + lane] = a1.f[q];
-        CVec<1> aux2;
-        sb_build_aux2(aux2, xs, nrm, lane);
-        stash_store<1>((SE*)st.aux2, (size_t)(tile0 + wave), aux2, lane);
-        Act<PrecBF16, 1> a2;
-        to_act(a2, aux2);
-        cbuf[(wave * 7 + 6) * 64 + lane] = a2.f[0];
-    }
-    // the SDF net's feature vector: block `wave` of the 4 tiles, stash -> B fragments
-#pragma unroll
-    for (int t = 0; t < SB_TILES; ++t) {
-        f32x16 v;
-        stash_load_block(v, (const SE*)feat_stash, (size_t)(tile0 + t), 8, wave, lane);
-        sb_store_units(abuf0, t, wave, v, lane);
-    }
-    bf16x8 wa[16], wb[16], wx[6];
-    auto bias_of = [&](const float* bp, int ob) {
-        CVec<1> b1;
-        load_bias(b1, bp + ob * 32, lane);
-        return b1.v[0];
-    };
-    auto relu16 = [](const f32x16& v) {
-        f32x16 y;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = fmaxf(v[r], 0.f);
-        return y;
-    };
-    int cur = 0;
-    // ---- f = xyz_encoding_final(feat): no activation (neuconw.py:128,136) ----------------------------------------
-    {
-        sb_load_slice<16>(wa, net.w_f, 8, wave, 0, lane);
-        sb_load_slice<16>(wb, net.w_e[0], 4, hb, 0, lane);   // head layer 0: f columns
-        sb_load_slice<6>(wx, net.w_e[0], 4, hb, 16, lane);   //               AUX1 columns (units 16..21)
-        const f32x16 bias = bias_of(net.b_f, wave);
-        __syncthreads();  // feat, AUX1, AUX2 visible
-#pragma unroll
-        for (int tp = 0; tp < SB_TILES; tp += 2) {
-            f32x16 acc0 = bias, acc1 = bias;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], abuf0[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], abuf0[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
-            }
-            stash_store_block((SE*)st.f, (size_t)(tile0 + tp), 8, wave, acc0, lane);
-            stash_store_block((SE*)st.f, (size_t)(tile0 + tp + 1), 8, wave, acc1, lane);
-            sb_store_units(abuf1, tp, wave, acc0, lane);
-            sb_store_units(abuf1, tp + 1, wave, acc1, lane);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
-        cur = 1;
-    }
-    // ---- appearance head (neuconw.py:111-127,137-140): wave = (block hb, tiles ta, tb) ----------------------------
-    for (int i = 0; i < net.n_head; ++i) {
-        if (i + 1 < net.n_head) sb_load_slice<8>(wb, net.w_e[i + 1], 4, hb, 0, lane);
-        else sb_load_slice<9>(wb, net.w_l[0], 8, wave, 0, lane);  // trunk layer 0: 8 units of e + the AUX2 unit
-        const f32x16 bias = bias_of(net.b_e[i], hb);
-        __syncthreads();
-        const sb_lfrag* in = cur ? abuf1 : abuf0;
-        sb_lfrag* out = cur ? abuf0 : abuf1;
-        f32x16 acc0 = bias, acc1 = bias;
-        if (i == 0) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(ta * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tb * 16 + q) * 64 + lane], acc1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], cbuf[(ta * 7 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], cbuf[(tb * 7 + q) * 64 + lane], acc1, 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(ta * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tb * 16 + q) * 64 + lane], acc1, 0, 0, 0);
-            }
-        }
-        const f32x16 y0 = relu16(acc0), y1 = relu16(acc1);
-        stash_store_block((SE*)st.e[i], (size_t)(tile0 + ta), 4, hb, y0, lane);
-        stash_store_block((SE*)st.e[i], (size_t)(tile0 + tb), 4, hb, y1, lane);
-        sb_store_units(out, ta, hb, y0, lane);
-        sb_store_units(out, tb, hb, y1, lane);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) wa[q] = wb[q];
-        cur ^= 1;
-    }
-    // ---- trunk (neuconw.py:158-166): layer 0 on [e | AUX2] (wa = 9 units of w_l[0]), then 256 -> 256 ---------------------
-    const int last = net.n_lin - 1;
-    for (int l = 0; l < last; ++l) {
-        if (l + 1 < last) sb_load_slice<16>(wb, net.w_l[l + 1], 8, wave, 0, lane);
-        const f32x16 bias = bias_of(net.b_l[l], wave);
-        __syncthreads();
-        const sb_lfrag* in = cur ? abuf1 : abuf0;
-        sb_lfrag* out = cur ? abuf0 : abuf1;
-#pragma unroll
-        for (int tp = 0; tp < SB_TILES; tp += 2) {
-            f32x16 acc0 = bias, acc1 = bias;
-            if (l == 0) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
-                }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[8], cbuf[(tp * 7 + 6) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[8], cbuf[((tp + 1) * 7 + 6) * 64 + lane], acc1, 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
-                }
-            }
-            const f32x16 y0 = relu16(acc0), y1 = relu16(acc1);
-            stash_store_block((SE*)st.x[l], (size_t)(tile0 + tp), 8, wave, y0, lane);
-            stash_store_block((SE*)st.x[l], (size_t)(tile0 + tp + 1), 8, wave, y1, lane);
-            sb_store_units(out, tp, wave, y0, lane);
-            sb_store_units(out, tp + 1, wave, y1, lane);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
-        cur ^= 1;
-    }
-    // ---- rgb = sigmoid(lin_last(x)) (neuconw.py:168-169), waves 0..3 --------------------------------------------
-    __syncthreads();
-    if (wave < SB_TILES) {
-        const sb_lfrag* in = cur ? abuf1 : abuf0;
-        bf16x8 w1[16];
-        sb_load_slice<16>(w1, net.w_l[last], 1, 0, 0, lane);
-        CVec<1> o;
-        load_bias(o, net.b_l[last], lane);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
-        if (pvalid && lane < 32) {
-            rgb[pp * 3 + 0] = sigmoidf_<true>(o.v[0][0]);
-            rgb[pp * 3 + 1] = sigmoidf_<true>(o.v[0][1]);
-            rgb[pp * 3 + 2] = sigmoidf_<true>(o.v[0][2]);
-        }
-    }
-}
-
 }  // namespace
 
 int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant) {
     const int64_t tiles = (n + 31) / 32;
-    if (variant == 2) {
-        hipLaunchKernelGGL(sdf_inferB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st,
-                           *net, src, n, sdf);
-        NCW_CHECK_LAUNCH();
-        return 0;
-    }
-    hipLaunchKernelGGL(sdf_infer8_kernel, dim3((unsigned)((tiles + S8_WAVES - 1) / S8_WAVES)), dim3(64 * S8_WAVES), 0, st, *net,
-                       src, n, sdf);
+    (void)variant;
+    hipLaunchKernelGGL(sdf_inferB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st,
+                       *net, src, n, sdf);
     NCW_CHECK_LAUNCH();
     return 0;
 }
@@ -1415,24 +855,6 @@ int ncw_nerf_bwd8_launch(const NcwNerfNet* net, const NcwPoints& src, int64_t n,
     const int64_t tiles = (n + 31) / 32;
     hipLaunchKernelGGL(nerf_bwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src, n,
                        d_density, d_rgb, d_a, stash);
-    NCW_CHECK_LAUNCH();
-    return 0;
-}
-
-int ncw_sdf_bwd8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, const float* d_sdf, const float* d_grad,
-                        const NcwSdfStash& stash, hipStream_t st) {
-    const int64_t tiles = (n + 31) / 32;
-    hipLaunchKernelGGL(sdf_bwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src, n,
-                       d_sdf, d_grad, stash);
-    NCW_CHECK_LAUNCH();
-    return 0;
-}
-
-int ncw_color_fwd8_launch(const NcwColorNet* net, const NcwPoints& src, int64_t n, const float* normals, const float* a,
-                          const void* feat_stash, float* rgb, const NcwColorStash& stash, hipStream_t st) {
-    const int64_t tiles = (n + 31) / 32;
-    hipLaunchKernelGGL(color_fwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src,
-                       n, normals, a, feat_stash, rgb, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }

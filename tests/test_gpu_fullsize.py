@@ -20,8 +20,18 @@ def _jitter(neuconw):
                 p.mul_(1.0 + 0.1 * torch.randn_like(p))
 
 
-@pytest.mark.parametrize("W,ns,ni,prec_name", [(256, 16, 16, "f32"), (512, 8, 16, "f32"), (256, 16, 16, "bf16")])
-def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name):
+# tolerances: fp32 = the north-star bar (1e-4 on the outputs; gradients 2e-3 of the network's largest gradient, see the
+# note on the fp32 reference's own noise below); bf16 = at most 2x the error MEASURED on MI355X (printed by the test,
+# recorded in DESIGN.md 4): outputs 5.6e-3 / gradients 8.8e-2 of the network's largest gradient at 16+16 samples,
+# outputs 3.4e-3 / gradients 4.3e-2 at 64+64; loss 1.7e-4 / 6.6e-4.
+BF16_TOL = {(16, 16): (1e-2, 0.175), (64, 64): (7e-3, 0.09)}
+
+
+@pytest.mark.parametrize("W,ns,ni,prec_name,R", [(256, 16, 16, "f32", 40), (512, 8, 16, "f32", 40), (256, 16, 16, "bf16", 40),
+                                                 (256, 64, 64, "f32", 16), (256, 64, 64, "bf16", 16)])
+def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
+    """(256, 64, 64) is the HEADLINE sampling shape of BASELINE configs[1] (64 coarse + 64 fine samples, W = 256): the
+    composed render + loss + backward against the oracle, not only its unit kernels."""
     import neuralrecon_w_amd as nw
     from oracle import neuconw_oracle as O
 
@@ -29,7 +39,6 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name):
     emb, neuconw, nerf, rdr = build_system(W=W, n_a=48, n_vocab=100, nerf_w=256, color_hidden=256, head=128, seed=5,
                                            prec=prec, n_samples=ns, n_importance=ni)
     _jitter(neuconw)
-    R = 40
     rays, ts, label, rgbs = synth_rays(R, 77, 100)
     out = rdr.render(rays.cuda(), ts.cuda(), label.cuda(), perturb_overwrite=0,
                      background_rgb=torch.zeros(1, 3).cuda(), cos_anneal_ratio=0.3)
@@ -48,12 +57,13 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name):
     gref = dict(zip(names, torch.autograd.grad(lref, [sd[k] for k in names], allow_unused=True)))
     if prec_name == "f32":
         tol_out, tol_grad = 2e-4, 2e-3
-    else:  # bf16 throughput mode: measured, reported in DESIGN.md
-        tol_out, tol_grad = 5e-2, 0.5
-    for k in ("color", "depth", "weights_sum", "gradient_error"):
-        e = rel_err(out[k].detach().cpu(), ref[k])
+    else:  # bf16 throughput mode
+        tol_out, tol_grad = BF16_TOL[(ns, ni)]
+    errs = {k: rel_err(out[k].detach().cpu(), ref[k]) for k in ("color", "depth", "weights_sum", "gradient_error")}
+    print("W=%d %d+%d %s outputs:" % (W, ns, ni, prec_name), {k: "%.2e" % v for k, v in errs.items()})
+    for k, e in errs.items():
         assert e < tol_out, (k, e)
-    assert abs(float(loss) - float(lref)) < (1e-4 if prec_name == "f32" else 2e-2)
+    assert abs(float(loss.detach()) - float(lref.detach())) < (1e-4 if prec_name == "f32" else 1.4e-3)
     params = named_params(emb, neuconw, nerf)
 
     def net_of(k):
@@ -127,15 +137,14 @@ def test_sync_free_depth_loss_is_the_same_loss():
 def test_weights_through_lds_kernels_at_the_bench_width_in_a_subprocess():
     """At W = 256 bf16 the forward kernels default to the weights-stationary structure (csrc/ncw_sdf8.hip); the
     weights-through-LDS kernels (the only ones for f32 / other widths) must stay correct at that shape: the bf16
-    train-step comparison of this file is re-run with NCW_SDF_FWD8=0 NCW_NERF_FWD8=0 NCW_NERF_BWD8=0 NCW_SDF_INFER8=0 --
-    and with the opt-in weights-stationary colour forward (NCW_COLOR_FWD8=1: correct, no faster, not the default)."""
+    train-step comparison of this file is re-run with NCW_SDF_FWD8=0 NCW_NERF_FWD8=0 NCW_NERF_BWD8=0 NCW_SDF_INFER8=0."""
     import os
     import subprocess
     import sys
 
     if os.environ.get("NCW_NERF_FWD8") is not None:
         pytest.skip("already inside a variant run")
-    env = dict(os.environ, NCW_SDF_FWD8="0", NCW_NERF_FWD8="0", NCW_NERF_BWD8="0", NCW_SDF_INFER8="0", NCW_COLOR_FWD8="1")
+    env = dict(os.environ, NCW_SDF_FWD8="0", NCW_NERF_FWD8="0", NCW_NERF_BWD8="0", NCW_SDF_INFER8="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "bf16"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

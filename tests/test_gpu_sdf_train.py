@@ -79,8 +79,7 @@ def test_weights_through_lds_forward_kernel_in_a_subprocess():
 
     if os.environ.get("NCW_SDF_FWD8") is not None:
         pytest.skip("already inside a variant run")
-    # ... and the opt-in weights-stationary backward (NCW_SDF_BWD8=1: correct, measured slower, not the default)
-    env = dict(os.environ, NCW_SDF_FWD8="0", NCW_SDF_BWD8="1")
+    env = dict(os.environ, NCW_SDF_FWD8="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "not subprocess"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
