@@ -10,8 +10,14 @@ configs[1]: 1024 rays/GPU x (64 coarse + 64 fine) samples, SDF 8x256, colour 4x2
 NeRF 8x256, 4 outside samples, bf16 MFMA with f32 accumulation.  Rays shard across ranks (weak
 scaling); value = total ray-samples of all ranks / max-over-ranks time.
 
-Prints ONE JSON line (rank 0) with the driver contract keys plus `roofline` (dominant kernel,
-algorithmic FLOPs / HIP-event duration) and `cpu_baseline` (the CPU oracle timed on this box).
+Prints ONE JSON line (rank 0) with the driver contract keys plus
+  `roofline`     dominant kernel by HIP-event time: `frac_mfma` (algorithmic FLOPs / duration / 2.5 PFLOP/s)
+                 AND `frac_hbm` (algorithmic stash bytes / duration / 8 TB/s) -- `frac` is the one for `bound`; `traffic`
+                 = HBM bytes per launch MEASURED WITH THIS RUN (two rocprofv3 --pmc passes of a short re-run of this
+                 script: FETCH_SIZE x 2 per MI355X_MICROARCH.md + WRITE_SIZE), `step_traffic_gb` = all kernels of a step;
+  `parity_mode`  the same step in the fp32 parity mode (the <= 1e-4 mode), a few steps timed in the same process;
+  `cpu_baseline` the CPU oracle on the first 256 rays of the SAME batch, timed on this box.
+Secondary rows (never the reported metric): --config shipped | voxel (BASELINE configs[2]) | grid512 (configs[4]).
 """
 import argparse
 import json
@@ -29,6 +35,7 @@ W_SDF = 256
 R_PER_GPU = 1024
 N_SAMPLES, N_IMPORTANCE, UP_STEPS, N_OUTSIDE, S_VAL_BASE = 64, 64, 2, 4, 3
 N_A, N_VOCAB = 48, 5000
+N_BOUNDARY = 0  # 10 in --config voxel (boundary samples of the fine-octree window)
 # algorithmic MACs per point (SURVEY.md 8d / BASELINE.md 4)
 M_SDF, M_SDF1, M_COL, M_BG = 524544, 459008, 355968, 659456
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
@@ -89,7 +96,7 @@ def loss_fn(out, rgbs):
 
 def kernel_flops(R):
     """Algorithmic FLOPs per launch of each C-ABI kernel at the bench shape (1 MAC = 2 FLOP)."""
-    S, O = N_SAMPLES + N_IMPORTANCE, N_OUTSIDE
+    S, O = N_SAMPLES + N_IMPORTANCE + N_BOUNDARY, N_OUTSIDE
     n_in, n_bg = R * S, R * (S + O)
     per_step_imp = N_IMPORTANCE // UP_STEPS
     # FLOPs per STEP of each entry point (summed over its launches in one step)
@@ -107,7 +114,7 @@ def kernel_flops(R):
     }
 
 
-def cpu_baseline(sample_rays=32, repeats=2, max_threads=32):
+def cpu_baseline(sample_rays=256, repeats=2, max_threads=32, seed=1000):
     """The CPU oracle (oracle/neuconw_oracle.py, pinned to the real reference by tests/golden) timed on
     this box's host cores on a bounded sample of the same workload (same nets, same sampler shape)."""
     from oracle import neuconw_oracle as O
@@ -124,7 +131,7 @@ def cpu_baseline(sample_rays=32, repeats=2, max_threads=32):
     cfg = dict(n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, n_outside=N_OUTSIDE, up_sample_steps=UP_STEPS,
                s_val_base=S_VAL_BASE, render_bg=True, trim_sphere=True, mesh_mask_list=["sky"], depth_loss=True,
                igr_weight=1e-4, mask_weight=0.1, depth_weight=0.1, skip_in=(4,), multires=6, multires_view=4)
-    rays, ts, label, rgbs = synth_batch(sample_rays, 123, "cpu")
+    rays, ts, label, rgbs = [t[:sample_rays] for t in synth_batch(R_PER_GPU, seed, "cpu")]  # rank 0's batch, first rays
     times = []
     for i in range(repeats + 1):
         t0 = time.perf_counter()
@@ -135,8 +142,132 @@ def cpu_baseline(sample_rays=32, repeats=2, max_threads=32):
     t = sorted(times[1:])[len(times[1:]) // 2]
     S = N_SAMPLES + N_IMPORTANCE
     return {"value": sample_rays * S / t, "unit": "ray-samples/s", "cores": cores, "kind": "port",
-            "sample": "%d rays x %d samples, same networks/sampler, fp32 torch-CPU oracle, render+loss+backward, "
-                      "median of %d after 1 warm-up (%.2f s/step)" % (sample_rays, S, repeats, t)}
+            "sample": "the first %d rays of the timed %d-ray batch x %d samples (BASELINE.md 3), same networks / sampler, "
+                      "fp32 torch-CPU oracle, render+loss+backward, median of %d after 1 warm-up (%.2f s/step)"
+                      % (sample_rays, R_PER_GPU, S, repeats, t)}
+
+
+# entry point -> substring of the kernel name the PMC passes report it under
+PMC_KERNEL = {"ncw_wgrad_tiled": "wgrad_dma_kernel", "ncw_wgrad": "wgrad_kernel", "ncw_sdf_bwd": "sdf_bwd_kernel",
+              "ncw_sdf_fwd": "sdf_fwd", "ncw_nerf_fwd": "nerf_fwd", "ncw_nerf_bwd": "nerf_bwd", "ncw_color_fwd": "color_fwd",
+              "ncw_color_bwd": "color_bwd", "ncw_sdf_infer_rays": "sdf_infer"}
+
+
+def pmc_kernel_name(raw):
+    """rocprofv3 kernel name -> short name that keeps anonymous-namespace kernels and template arguments apart."""
+    k = raw.replace("(anonymous namespace)::", "").replace("void ", "")
+    return k.split("(")[0] if "(" in k else k
+
+
+def pmc_traffic(argv_inner, steps_inner, timeout=240):
+    """HBM traffic measured WITH this run: two rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass:
+    MI355X_MICROARCH.md, PMC slots) of a short inner run of this script.  Returns ({kernel: bytes per launch},
+    bytes per step over all kernels) or (None, None).  FETCH_SIZE is doubled (the guide's gfx950 rule for wide
+    coalesced reads: 16 B/lane global_load and LDS-DMA alike -- every stash / weight read here); both counters are KB."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None, None
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(int)
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ncw_pmc_")
+        cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+               os.path.abspath(__file__)] + argv_inner
+        try:
+            subprocess.run(cmd, cwd=d, env=dict(os.environ, TMPDIR=d), capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if not files:
+                return None, None
+            n = collections.defaultdict(int)
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != ctr:
+                    continue
+                k = pmc_kernel_name(row["Kernel_Name"])
+                per_kernel[k][ctr] += float(row["Counter_Value"])
+                n[k] += 1
+            for k, v in n.items():
+                launches[k] = max(launches[k], v)
+        except Exception:
+            return None, None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out, total = {}, 0.0
+    for k, c in per_kernel.items():
+        b = (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0
+        total += b
+        out[k] = b / max(launches[k], 1)
+    return out, total / max(steps_inner, 1)
+
+
+def voxel_shell(level=7, r0=0.5, thick=0.05, device="cuda"):
+    """the voxels of a level-7 grid that intersect a sphere shell of radius 0.5 +- 0.05."""
+    G = 1 << level
+    c = (torch.arange(G, device=device).float() + 0.5) * (2.0 / G) - 1.0
+    x, y, z = torch.meshgrid(c, c, c, indexing="ij")
+    return ((x * x + y * y + z * z).sqrt() - r0).abs() < thick + (2.0 / G)
+
+
+def bench_grid512(args, nw, L, dev, world, rank):
+    """BASELINE configs[4]: the SDF sweep of tools/extract_mesh.py / utils/visualization.py:37-89 -- 512^3 grid points,
+    SDF MLP inference only (sdf column), coordinates generated on the chip, contiguous slices per rank."""
+    from neuralrecon_w_amd import grid
+
+    W = 512 if args.grid_width is None else args.grid_width
+    torch.manual_seed(0)
+    net = nw.SDFNetwork(d_in=3, d_out=W + 1, d_hidden=W, n_layers=8, skip_in=(4,), multires=6, bias=0.5, scale=1,
+                        geometric_init=True, weight_norm=True, inside_outside=False).to(dev)
+    dim = 512
+    total = dim ** 3
+    start, count, per = grid.local_range(total, rank, world)
+    prec = nw.PREC_BF16 if args.prec == "bf16" else nw.PREC_F32
+    out = torch.empty(per, device=dev, dtype=torch.float32)
+    lo, hi = (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)
+    chunk = 1 << 22
+
+    def sweep():
+        grid.sdf_grid_range(net, dim, lo, hi, start, count, prec=prec, chunk=chunk, out=out)
+
+    for _ in range(max(1, min(args.warmup, 2))):
+        sweep()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = max(1, min(args.steps, 3))
+    for _ in range(K):
+        sweep()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    macs = {256: 459008, 512: 1835520}[W]
+    pts_s = total * K / dt
+    peak = PEAK_BF16_TFLOPS if prec == nw.PREC_BF16 else 157.3
+    ach = 2.0 * macs * pts_s / 1e12
+    if rank == 0:
+        print(json.dumps({
+            "metric": "points/sec, 512^3 SDF grid sweep (tools/extract_mesh.py path) [secondary: BASELINE configs[4]]",
+            "value": pts_s, "unit": "points/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.prec, "data": "synthetic",
+            "config": {"workload": "512^3 = 134,217,728 grid points, SDF 8x%d sdf-only inference, coordinates from the linear "
+                                   "index on the chip, %d-point launches, contiguous 1/%d slice per rank" % (W, chunk, world),
+                       "points_per_rank": per, "sdf_precision_note": "the product default for this path is fp32 "
+                       "(NEUCONW_INFER_PREC); this row times --prec"},
+            "roofline": {"kernel": "ncw_sdf_infer_points", "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                         "algorithmic_mflop_per_point": round(2.0 * macs / 1e6, 3)},
+            "cpu_baseline": None}))
 
 
 def main():
@@ -147,9 +278,15 @@ def main():
     ap.add_argument("--prec", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--rays", type=int, default=R_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", default="headline", choices=["headline", "shipped"],
-                    help="headline = BASELINE.json configs[1] (the metric's shape); shipped = the reference's yaml shape "
-                         "(W=512 SDF, 8+16 samples): a secondary row, never the reported metric")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 parity-mode timing (`parity_mode`)")
+    ap.add_argument("--inner", action="store_true", help="(internal) the short run the PMC passes profile: timing loop only")
+    ap.add_argument("--grid-width", type=int, default=None, choices=[256, 512], help="--config grid512: SDF width (default 512)")
+    ap.add_argument("--config", default="headline", choices=["headline", "shipped", "voxel", "grid512"],
+                    help="headline = BASELINE.json configs[1] (the metric's shape).  Secondary rows, never the reported "
+                         "metric: shipped = the reference's yaml shape (W=512 SDF, 8+16 samples); voxel = configs[2] "
+                         "(headline + level-7 shell occupancy: voxel near/far, +-16-voxel window, 10 boundary samples); "
+                         "grid512 = configs[4] (512^3 SDF sweep, points/s)")
     ap.add_argument("--graph", action="store_true",
                     help="record the step into HIP graphs and replay it (trainer.TrainStep(capture=True)); measured "
                          "4.78 vs 4.80 ms eager on one MI355X -- the step is not host-launch-bound -- so eager is the default")
@@ -175,7 +312,6 @@ def main():
         globals().update(W_SDF=512, N_SAMPLES=8, N_IMPORTANCE=16, M_SDF=2097664, M_SDF1=1835520, M_COL=585344)
 
     import neuralrecon_w_amd as nw
-    from neuralrecon_w_amd import ddp
     from neuralrecon_w_amd import lib as L
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -212,21 +348,44 @@ def main():
         return
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if args.config == "grid512":
+        bench_grid512(args, nw, L, dev, world, rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     prec = nw.PREC_BF16 if args.prec == "bf16" else nw.PREC_F32
-    emb, neuconw, nerf, rdr = build_models(dev, prec)
-    # LR rule of train.py:21-25: 1e-4 * world*batch / 4096; Adam eps 1e-7 (utils/__init__.py:24-31); clip 0.99
-    # (train.py:61).  TrainStep = render + loss + backward + one flat all-reduce + clip + Adam (trainer.py).
     R = args.rays
-    # --graph: the step is recorded once into HIP graphs and replayed (trainer.py): same kernels, same arithmetic,
-    # one graph launch instead of ~130 launches; with N > 1 the RCCL all-reduce stays eager between two graphs.
-    train = nw.TrainStep(rdr, [emb, neuconw, nerf], loss_fn, lr=1e-4 * world * R / 4096.0, eps=1e-7, clip=0.99,
-                         world_size=world, capture=args.graph, capture_warmup=3)
-    rays, ts, label, rgbs = synth_batch(R, 1000 + rank, dev)
     bg = torch.zeros(1, 3, device=dev)
+    rays, ts, label, rgbs = synth_batch(R, 1000 + rank, dev)
+    n_boundary = 0
 
-    def step(i):
-        loss, _ = train(rays, ts, label, rgbs, background_rgb=bg, cos_anneal_ratio=min(1.0, i / 50000.0))
-        return loss
+    def make_step(prec_):
+        """models + TrainStep in precision prec_ -> step(i).  LR rule of train.py:21-25: 1e-4 * world*batch / 4096; Adam
+        eps 1e-7 (utils/__init__.py:24-31); clip 0.99 (train.py:61).  TrainStep = render + loss + backward + one flat
+        all-reduce + clip + Adam (trainer.py)."""
+        emb_, neuconw_, nerf_, rdr_ = build_models(dev, prec_)
+        if args.config == "voxel":  # configs[2]: coarse octree -> ray near/far; fine octree -> +-SAMPLE_RANGE window + boundary samples
+            from neuralrecon_w_amd import voxel
+
+            occ = voxel_shell(7, device=dev)
+            vs = 2.0 / 128
+            rdr_.nerf_far_override, rdr_.voxel_size = True, vs
+            rdr_.octree_data = voxel.occupancy_from_dense(occ, torch.zeros(3), 1.0, voxel_size=vs)
+            rdr_.fine_octree_data = voxel.occupancy_from_dense(occ, torch.zeros(3), 1.0, voxel_size=vs)
+            rdr_.sample_range, rdr_.boundary_samples = 16, 10
+        train_ = nw.TrainStep(rdr_, [emb_, neuconw_, nerf_], loss_fn, lr=1e-4 * world * R / 4096.0, eps=1e-7, clip=0.99,
+                              world_size=world, capture=args.graph, capture_warmup=3)
+
+        def step_(i):
+            loss_, _ = train_(rays, ts, label, rgbs, background_rgb=bg, cos_anneal_ratio=min(1.0, i / 50000.0))
+            return loss_
+
+        return step_, train_, (emb_, neuconw_, nerf_, rdr_)
+
+    if args.config == "voxel":
+        n_boundary = 10
+        globals().update(N_BOUNDARY=10)
+    step, train, (emb, neuconw, nerf, rdr) = make_step(prec)
 
     if args.graph:  # setup, not warm-up: 3 eager steps + the capture happen before the W warm-up steps
         for i in range(4):
@@ -248,8 +407,14 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    S = N_SAMPLES + N_IMPORTANCE
+    S = N_SAMPLES + N_IMPORTANCE + n_boundary
     value = world * R * S * args.steps / dt
+    if args.inner:  # the PMC passes only need the kernels to run
+        if rank == 0:
+            print(json.dumps({"inner": True, "ms_per_step": dt / args.steps * 1e3}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # ---- per-kernel HIP-event timing over a few more live steps (same stream) -> roofline ---------------
     roofline = None
@@ -275,31 +440,20 @@ def main():
         avg_ms = rows[dom][0] / rows[dom][1]
         ach = fl[dom] / (rows[dom][0] * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if prec == nw.PREC_BF16 else 157.3
-        # HBM traffic of the dominant entry point per launch: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, KB)
-        # of this same command, committed under profiles/ (bench.py cannot run rocprof on itself).
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_v3.json")))
-            keys = {"ncw_wgrad_tiled": "wgrad_dma_kernel", "ncw_sdf_bwd": "sdf_bwd_kernel", "ncw_sdf_fwd": "sdf_fwd_kernel"}
-            sel = [v for k, v in tj.items() if keys.get(dom, "\0") in k]
-            if sel and prec == nw.PREC_BF16 and R == R_PER_GPU:
-                # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts wide coalesced streaming reads (16 B/lane,
-                # global_load and LDS-DMA alike) at exactly 1/2 -> doubled; WRITE_SIZE is taken as reported.  KB.
-                kb = sum((2.0 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * v["launches"] for v in sel)
-                traffic = round(kb * 1024.0 / sum(v["launches"] for v in sel), 0)  # bytes per launch
-        except Exception:
-            traffic = None
+        frac_mfma = ach / peak
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
-                    "launches_per_step": rows[dom][1],
+                    "frac": round(frac_mfma, 4), "frac_mfma": round(frac_mfma, 4), "frac_hbm": None, "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": rows[dom][1],
                     "algorithmic_gflop_per_launch": round(fl[dom] / rows[dom][1] / 1e9, 2),
                     "kernel_tflops": {k: round(fl[k] / (rows[k][0] * 1e-3) / 1e12, 1) for k in rows if fl.get(k)},
+                    "kernel_frac_mfma": {k: round(fl[k] / (rows[k][0] * 1e-3) / 1e12 / peak, 4) for k in rows if fl.get(k)},
                     "per_step_kernel_ms": {k: round(v[0], 4) for k, v in sorted(rows.items(), key=lambda kv: -kv[1][0])},
                     "sum_kernel_ms_per_step": round(total_ms, 4)}
         if dom.startswith("ncw_wgrad"):
             # The weight-gradient GEMMs reduce over the POINTS: every product streams its two stash operands
             # once (algorithmic bytes = sum over products of (rbx + rby) x 32 features x elem x points); at
-            # ~180 FLOP/B they sit left of the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B): HBM-bound.
+            # ~100 FLOP/B they sit left of the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B): HBM-bound in THIS design.
+            # SURVEY 8(d) prices the MLP backward against MFMA: both fractions are reported, `frac` follows `bound`.
             esz = 2 if prec == nw.PREC_BF16 else 4
             alg_bytes = 0.0
             for ent in neuconw.sdf_net.__dict__.get("_stash_cache")._e.values():
@@ -308,13 +462,46 @@ def main():
                     alg_bytes += type(wb).algorithmic_bytes(wb.items, esz)
             gbs = alg_bytes / (rows[dom][0] * 1e-3) / 1e9
             roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                             "frac": round(gbs / 8000.0, 4), "algorithmic_gbytes_per_step": round(alg_bytes / 1e9, 3),
-                             "mfma_tflops": round(ach, 1)})
+                             "frac": round(gbs / 8000.0, 4), "frac_hbm": round(gbs / 8000.0, 4),
+                             "algorithmic_gbytes_per_step": round(alg_bytes / 1e9, 3), "mfma_tflops": round(ach, 1)})
         # step-level MFMA fraction: all algorithmic FLOPs of the step / wall time
         step_flops = 2.0 * R * ((N_SAMPLES + (UP_STEPS - 1) * N_IMPORTANCE // UP_STEPS) * M_SDF1
                                 + S * (6 * M_SDF + 3 * M_COL) + (S + N_OUTSIDE) * 3 * M_BG)
         roofline["step_algorithmic_tflop"] = round(step_flops / 1e12, 4)
         roofline["step_frac_of_mfma_peak"] = round(step_flops / (dt / args.steps) / 1e12 / peak, 4)
+        # ---- HBM traffic, measured with this run (single-GPU runs; N > 1 would profile N ranks) ----------------
+        if not args.no_pmc and world == 1:
+            inner_steps, inner_warm = 3, 2
+            inner = ["--inner", "--steps", str(inner_steps), "--warmup", str(inner_warm), "--prec", args.prec, "--rays", str(R),
+                     "--config", args.config, "--no-cpu-baseline", "--no-pmc", "--no-parity-mode"]
+            per_kernel, step_bytes = pmc_traffic(inner, inner_steps + inner_warm)
+            if per_kernel:
+                sel = [v for k, v in per_kernel.items() if PMC_KERNEL.get(dom, "\0") in k]
+                roofline["traffic"] = round(max(sel), 0) if sel else None
+                roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH x 2 + WRITE)"
+                roofline["step_traffic_gb"] = round(step_bytes / 1e9, 3)
+                top = sorted(((k, v) for k, v in per_kernel.items()), key=lambda kv: -kv[1])[:10]
+                roofline["kernel_traffic_mb_per_launch"] = {k[:48]: round(v / 1e6, 1) for k, v in top}
+
+    # ---- the fp32 parity mode (the <= 1e-4 mode, tests/test_gpu_render.py) timed in the same process ---------------
+    parity = None
+    if not args.no_parity_mode and world == 1 and args.prec == "bf16" and not args.graph:
+        del train, step
+        torch.cuda.empty_cache()
+        step32, train32, _ = make_step(nw.PREC_F32)
+        for i in range(2):
+            step32(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        k32 = 5
+        for i in range(k32):
+            step32(2 + i)
+        torch.cuda.synchronize()
+        d32 = (time.perf_counter() - t1) / k32
+        parity = {"dtype": "f32", "value": R * S / d32, "unit": "ray-samples/s", "ms_per_step": d32 * 1e3, "steps": k32,
+                  "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak): outputs within 1e-4 of the reference, "
+                          "bitwise run-to-run reproducible; step_frac_of_f32_mfma_peak = %.3f"
+                          % (roofline["step_algorithmic_tflop"] / d32 / 157.3 if roofline else float("nan"))}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -324,22 +511,24 @@ def main():
             cpu = {"value": None, "unit": "ray-samples/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
 
     if rank == 0:
+        names = {"headline": "BASELINE.json configs[1]", "shipped": "shipped yaml shape, secondary",
+                 "voxel": "BASELINE.json configs[2] (voxel-guided), secondary"}
         line = {
             "metric": ("ray-samples/sec (train step) at 1024 rays x 128 samples" if args.config == "headline" else
                        "ray-samples/sec (train step) at %d rays x %d samples [secondary shape]" % (R, S)), "value": value,
             "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.prec, "data": "synthetic",
-            "config": {"workload": "brandenburg_gate config (%s): %d rays/GPU x (%d coarse + %d fine) "
+            "config": {"workload": "brandenburg_gate config (%s): %d rays/GPU x (%d coarse + %d fine%s) "
                                    "samples, SDF 8x%d + colour 4x256 + bg NeRF 8x256, 4 outside samples, up_sample_steps 2, "
                                    "render+loss+backward+allreduce+clip+Adam"
-                                   % ("BASELINE.json configs[1]" if args.config == "headline" else "shipped yaml shape, secondary",
-                                      R, N_SAMPLES, N_IMPORTANCE, W_SDF),
+                                   % (names[args.config], R, N_SAMPLES, N_IMPORTANCE,
+                                      " + 10 boundary, level-7 shell occupancy" if args.config == "voxel" else "", W_SDF),
                        "rays_per_gpu": R, "samples_per_ray": S, "global_rays": world * R, "parallelism": "dp%d" % world,
                        "world_size": world, "ranks": ranks,
                        "submission": "hip-graph replay" if args.graph else "eager",
                        "final_loss": float(loss.detach())},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "parity_mode": parity, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:
