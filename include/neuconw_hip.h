@@ -250,6 +250,16 @@ int ncw_nerf_fwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, const fl
                  float* density, float* rgb, const NcwNerfStash* stash, void* stream);
 int ncw_nerf_bwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_density,
                  const float* d_rgb, float* d_a, float* d_a_rows, const NcwNerfStash* stash, void* stream);
+/* Batch assembly from the HBM-resident ray cache.  Replaces, per batch, PhototourismDataset.__getitem__
+ * for split "train" (datasets/phototourism.py:709-726: rays = row[0:8] ++ row[10:13] (with semantics) / row[9:12],
+ * ts = long(row[8]), semantics = row[9]), the DataLoader's collate + pinned H2D copy, and the black-list test of
+ * NeuconWSystem.training_step (lightning_modules/neuconw_system.py:345-349): keep[b] = 0 iff label[b] is one of
+ * mask_ids (<= 4 ids; the shipped RAY_MASK_LIST has 4).  all_rays [n_rows, ncols] (ncols 13 with semantics, 12 without),
+ * all_rgbs [n_rows,3], idx [B] int64 or NULL (= identity); outputs rays [B,11], ts [B] i64, label [B] i64 or NULL,
+ * rgbs [B,3] or NULL, keep [B] u8 or NULL.  mask_ids is a HOST array. */
+int ncw_batch_assemble(const float* all_rays, int ncols, const float* all_rgbs, const int64_t* idx, int64_t n_rows,
+                       int64_t B, int with_semantics, float* rays, int64_t* ts, int64_t* label, float* rgbs,
+                       const int* mask_ids, int n_ids, uint8_t* keep, void* stream);
 /* out[R,n_cols] (+)= per-ray sums of rows[R*per_ray, n_cols] in sample order (see d_a_rows above). */
 int ncw_ray_sum_rows(const float* rows, int64_t R, int per_ray, int n_cols, float* out, int accumulate, void* stream);
 

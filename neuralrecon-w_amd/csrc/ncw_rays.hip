@@ -716,6 +716,65 @@ extern "C" int ncw_ray_sum_rows(const float* rows, int64_t R, int per_ray, int n
 }
 
 // ------------------------------------------------------------------------------------------------
+// Batch assembly from the HBM-resident ray cache: PhototourismDataset.__getitem__ for split "train"
+// (datasets/phototourism.py:709-726) + the black-list test of NeuconWSystem.training_step
+// (lightning_modules/neuconw_system.py:345-349) for a whole batch in one launch -- a row gather by `idx`:
+//   with_semantics: cache row = [o(3) d(3) near far | ts | label | c10 c11 c12]  -> rays = [0:8] ++ [10:13]
+//   without:        cache row = [o(3) d(3) near far | ts | c9 c10 c11]            -> rays = [0:8] ++ [9:12]
+//   ts = long(row[8]); label = long(row[9]) (torch's float -> int64 truncation); keep = label not in mask_ids
+// One thread per output row; rows are 48 / 52 B so a wave reads 3 KiB of contiguous-ish HBM per instruction group.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void batch_assemble_kernel(const float* __restrict__ all_rays, int ncols,
+                                                             const float* __restrict__ all_rgbs,
+                                                             const int64_t* __restrict__ idx, int64_t n_rows, int64_t B,
+                                                             int with_semantics, float* __restrict__ rays,
+                                                             int64_t* __restrict__ ts, int64_t* __restrict__ label,
+                                                             float* __restrict__ rgbs, int4 ids, int n_ids,
+                                                             uint8_t* __restrict__ keep) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    int64_t r = idx ? idx[b] : b;
+    r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
+    const float* src = all_rays + r * ncols;
+    float* dst = rays + b * 11;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dst[c] = src[c];
+    const int tail = with_semantics ? 10 : 9;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[8 + c] = src[tail + c];
+    ts[b] = (int64_t)src[8];
+    const int64_t lab = with_semantics ? (int64_t)src[9] : 0;
+    if (label) label[b] = lab;
+    if (rgbs) {
+        rgbs[b * 3] = all_rgbs[r * 3]; rgbs[b * 3 + 1] = all_rgbs[r * 3 + 1]; rgbs[b * 3 + 2] = all_rgbs[r * 3 + 2];
+    }
+    if (keep) {
+        bool k = true;
+        if (with_semantics) {
+            if (n_ids > 0 && lab == ids.x) k = false;
+            if (n_ids > 1 && lab == ids.y) k = false;
+            if (n_ids > 2 && lab == ids.z) k = false;
+            if (n_ids > 3 && lab == ids.w) k = false;
+        }
+        keep[b] = k ? 1 : 0;
+    }
+}
+
+extern "C" int ncw_batch_assemble(const float* all_rays, int ncols, const float* all_rgbs, const int64_t* idx, int64_t n_rows,
+                                  int64_t B, int with_semantics, float* rays, int64_t* ts, int64_t* label, float* rgbs,
+                                  const int* mask_ids, int n_ids, uint8_t* keep, void* stream) {
+    if (B <= 0) return 0;
+    if (!all_rays || !rays || !ts || n_rows <= 0 || n_ids < 0 || n_ids > 4) return NCW_E_BADARG;
+    if (ncols != (with_semantics ? 13 : 12) || (rgbs && !all_rgbs)) return NCW_E_BADARG;
+    int4 ids = make_int4(n_ids > 0 ? mask_ids[0] : -1, n_ids > 1 ? mask_ids[1] : -1, n_ids > 2 ? mask_ids[2] : -1,
+                         n_ids > 3 ? mask_ids[3] : -1);
+    hipLaunchKernelGGL(batch_assemble_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, all_rays,
+                       ncols, all_rgbs, idx, n_rows, B, with_semantics, rays, ts, label, rgbs, ids, n_ids, keep);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-ray loss terms computed inside render() (renderer.py:763-765 gradient_error, :869-877 mask_error,
 // :892-897 sfm_depth_loss) and their backward: ~55 tiny torch launches per step become two.  One
 // workgroup (the work is R elements + three sums).

@@ -20,15 +20,9 @@ from . import rayops
 from .neuconw import default_infer_prec, default_prec, points_struct
 from .stash import LeaseGuard, StashCache, WgradBatch
 
-SKY_LABEL_ID = 2  # datasets/mask_utils.py: get_label_id_mapping()["sky"]
-LABEL_IDS = {"sky": 2}
+from .labels import LABEL_IDS, label_id as _label_id  # noqa: E402  (ADE20K ids: datasets/mask_utils.py)
 
-
-def _label_id(name):
-    if name in LABEL_IDS:
-        return LABEL_IDS[name]
-    raise NotImplementedError("label '%s': only the ADE20K ids used by the shipped configs are built in; "
-                              "extend neuralrecon_w_amd.renderer.LABEL_IDS" % name)
+SKY_LABEL_ID = LABEL_IDS["sky"]
 
 
 class _RenderFn(torch.autograd.Function):

@@ -131,7 +131,42 @@ class FlatAdam:
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,
                 "betas": self.betas, "eps": self.eps}
 
-    def load_state_dict(self, sd):
+    def torch_state_dict(self, param_order):
+        """The state in torch.optim.Adam's own `state_dict()` layout for the parameters in `param_order` (the order
+        the reference's `get_optimizer` hands them to Adam: utils/__init__.py:10-31 over [embedding_a, {neuconw, nerf}],
+        neuconw_system.py:70-136) -- what a PyTorch-Lightning checkpoint stores under `optimizer_states[0]`, so the
+        reference can resume from it.  Parameters that are not in the flat storage are skipped."""
+        state, ids = {}, []
+        for i, p in enumerate(param_order):
+            ids.append(i)
+            sl = self.fp.slices.get(id(p))
+            if sl is None:
+                continue
+            off, k = sl
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[off:off + k].view(p.shape).detach().cpu().clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + k].view(p.shape).detach().cpu().clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": ids}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd, param_order=None):
+        """Accepts this class' flat state or a torch.optim.Adam state_dict (with `param_order` as above)."""
+        if "param_groups" in sd:
+            if param_order is None:
+                raise ValueError("a torch.optim.Adam state_dict needs param_order")
+            step = 0
+            for i, p in enumerate(param_order):
+                st, sl = sd["state"].get(i), self.fp.slices.get(id(p))
+                if st is None or sl is None:
+                    continue
+                off, k = sl
+                self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                step = max(step, int(float(st["step"])))
+            self.step_count = step
+            return
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
@@ -259,9 +294,15 @@ class TrainStep:
 # Checkpoint I/O in the reference's format.  The reference saves PyTorch-Lightning checkpoints
 # whose `state_dict` holds `embedding_a.*`, `neuconw.*`, `nerf.*` (train.py:32-38, neuconw_system.py:376-400)
 # and reads them back by prefix (utils/__init__.py:64-98 `extract_model_state_dict` / `load_ckpt`, used by
-# tools/extract_mesh.py:130-134).  These two functions write / read exactly that layout, so checkpoints move
-# between the reference and this package in both directions.
+# tools/extract_mesh.py:130-134).  These two functions write / read exactly that layout; the optimiser state is
+# written in torch.optim.Adam's own state_dict layout in the reference's parameter order, so checkpoints -- weights AND
+# Adam moments -- move between the reference and this package in both directions (tests/test_checkpoint_io.py).
 # ---------------------------------------------------------------------------------------------------
+def reference_param_order(embedding_a, neuconw, nerf):
+    """`get_parameters([embedding_a, {"neuconw": neuconw, "nerf": nerf}])` of the reference (utils/__init__.py:10-21)."""
+    return list(embedding_a.parameters()) + list(neuconw.parameters()) + list(nerf.parameters())
+
+
 def save_checkpoint(path, embedding_a, neuconw, nerf, optimizer=None, global_step=0, extra=None):
     """Writes {'state_dict': {prefix.key: tensor}, 'global_step': ..., ['optimizer_states': [...]]}."""
     sd = {}
@@ -270,7 +311,11 @@ def save_checkpoint(path, embedding_a, neuconw, nerf, optimizer=None, global_ste
             sd[prefix + "." + k] = v.detach().cpu().clone()   # clone: parameters may be views of the flat buffer
     ckpt = {"state_dict": sd, "global_step": int(global_step)}
     if optimizer is not None:
-        ckpt["optimizer_states"] = [optimizer.state_dict()]
+        if hasattr(optimizer, "torch_state_dict"):  # FlatAdam -> torch.optim.Adam's layout in the reference's parameter
+            # order (utils/__init__.py:10-31 over [embedding_a, {neuconw, nerf}]), which PL's resume expects
+            ckpt["optimizer_states"] = [optimizer.torch_state_dict(reference_param_order(embedding_a, neuconw, nerf))]
+        else:
+            ckpt["optimizer_states"] = [optimizer.state_dict()]
     if extra:
         ckpt.update(extra)
     torch.save(ckpt, path)

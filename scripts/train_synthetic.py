@@ -49,7 +49,7 @@ def main():
         ck = trainer.load_checkpoint(args.resume, emb, neuconw, nerf, flat_params=step_fn.fp)
         start = int(ck.get("global_step", 0))
         if "optimizer_states" in ck:
-            step_fn.opt.load_state_dict(ck["optimizer_states"][0])
+            step_fn.opt.load_state_dict(ck["optimizer_states"][0], trainer.reference_param_order(emb, neuconw, nerf))
     bg = torch.zeros(1, 3, device=dev)
     t0 = time.perf_counter()
     for it in range(start, start + args.steps):

@@ -83,3 +83,36 @@ def test_reference_load_ckpt_reads_our_checkpoint(tmp_path):
     emb2, neuconw2, nerf2, *_ = _ours(seed=4)
     trainer.load_checkpoint(path, emb2, neuconw2, nerf2)
     assert torch.equal(neuconw2.sdf_net.lin8.weight_v, r_neuconw.sdf_net.lin8.weight_v)
+
+
+def test_optimizer_state_is_torch_adam_compatible(tmp_path):
+    """trainer.save_checkpoint writes FlatAdam's moments in torch.optim.Adam's own state_dict layout, in the reference's
+    parameter order (utils/__init__.py:10-31 over [embedding_a, {neuconw, nerf}]): a stock Adam -- what PyTorch-Lightning
+    restores `optimizer_states[0]` into -- loads it, and FlatAdam reads it back."""
+    from neuralrecon_w_amd import trainer
+
+    emb, neuconw, nerf, *_ = _ours(seed=3)
+    fp = trainer.FlatParams([emb, neuconw, nerf])
+    opt = trainer.FlatAdam(fp, lr=2e-4, eps=1e-7, clip=0.99)
+    g = torch.Generator().manual_seed(0)
+    opt.exp_avg.copy_(torch.randn(opt.exp_avg.shape, generator=g))
+    opt.exp_avg_sq.copy_(torch.rand(opt.exp_avg_sq.shape, generator=g))
+    opt.step_count = 7
+    path = os.path.join(tmp_path, "iter_7.ckpt")
+    ck = trainer.save_checkpoint(path, emb, neuconw, nerf, optimizer=opt, global_step=7)
+    order = trainer.reference_param_order(emb, neuconw, nerf)
+    sd = torch.load(path, map_location="cpu")["optimizer_states"][0]
+    assert sd["param_groups"][0]["params"] == list(range(len(order))) and sd["param_groups"][0]["eps"] == 1e-7
+    stock = torch.optim.Adam(order, lr=1.0, eps=1e-3)
+    stock.load_state_dict(sd)  # the stock optimiser accepts it ...
+    assert stock.param_groups[0]["lr"] == 2e-4 and stock.param_groups[0]["eps"] == 1e-7
+    p = neuconw.sdf_net.lin3.weight_v
+    off, k = fp.slices[id(p)]
+    st = stock.state[p]
+    assert float(st["step"]) == 7.0 and torch.equal(st["exp_avg"], opt.exp_avg[off:off + k].view_as(p))
+    assert torch.equal(st["exp_avg_sq"], opt.exp_avg_sq[off:off + k].view_as(p))
+    # ... and FlatAdam reads a stock Adam's state back (the reference -> us direction)
+    opt2 = trainer.FlatAdam(fp, lr=2e-4, eps=1e-7, clip=0.99)
+    opt2.load_state_dict(stock.state_dict(), order)
+    assert opt2.step_count == 7 and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    assert ck["global_step"] == 7

@@ -1,0 +1,91 @@
+"""GPU: the PL-free training driver (scripts/train.py) end to end on a small synthetic scene directory laid out like a
+Heritage-Recon scene: experiment yaml, scene config.yaml, COLMAP points3D.bin, npz ray-cache chunks with semantic
+labels.  Exercises N3 (cache -> HBM -> device batches, black-list prefilter), the recipe of train.py / NeuconWSystem,
+the coarse octree from SfM points + the periodic fine-octree refresh, and checkpoints in the reference's layout."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from tests._util import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_scene(root):
+    sys.path.insert(0, ROOT)
+    import bench
+
+    os.makedirs(os.path.join(root, "dense", "sparse"), exist_ok=True)
+    rng = np.random.RandomState(0)
+    d = rng.randn(400, 3)
+    pts = d / np.linalg.norm(d, axis=1, keepdims=True) * 0.5
+    with open(os.path.join(root, "dense", "sparse", "points3D.bin"), "wb") as f:
+        f.write(struct.pack("<Q", len(pts)))
+        for i, p in enumerate(pts):
+            f.write(struct.pack("<QdddBBBd", i + 1, *p, 1, 2, 3, 0.1))
+            f.write(struct.pack("<Q", 3))
+            f.write(struct.pack("<iiiiii", 1, i, 2, i, 3, i))
+    yaml.safe_dump({"origin": [0.0, 0.0, 0.0], "radius": 1.0, "sfm2gt": np.eye(4).tolist(),
+                    "eval_bbx": [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], "voxel_size": 0.125, "min_track_length": 2},
+                   open(os.path.join(root, "config.yaml"), "w"))
+    labels = np.array([0, 1, 2, 4, 12, 20], dtype=np.float32)
+    for i in range(2):
+        rays, ts, label, rgbs = bench.synth_batch(300, 50 + i, "cpu")  # [o d near far depth_gt depth_w], ts, sky-or-0, rgb
+        n = rays.shape[0]
+        row = np.zeros((n, 13), dtype=np.float32)
+        row[:, :8] = rays[:, :8].numpy()
+        row[:, 8] = (ts.numpy() % 64)
+        row[:, 9] = labels[rng.randint(0, len(labels), n)]
+        row[:, 10:12] = rays[:, 8:10].numpy()
+        sd = os.path.join(root, "cache", "splits", "split_%d" % i)
+        os.makedirs(sd, exist_ok=True)
+        np.savez_compressed(os.path.join(sd, "rays1.npz"), row)
+        np.savez_compressed(os.path.join(sd, "rgbs1.npz"), rgbs.numpy())
+    exp = {"NEUCONW": {"N_SAMPLES": 8, "N_IMPORTANCE": 8, "UP_SAMPLE_STEP": 2, "N_OUTSIDE": 4, "NEAR_FAR_OVERRIDE": True,
+                       "DEPTH_LOSS": True, "S_VAL_BASE": 3, "BOUNDARY_SAMPLES": 4, "SAMPLE_RANGE": 16, "SDF_THRESHOLD": 0.05,
+                       "TRAIN_VOXEL_SIZE": 0.06, "UPDATE_FREQ": 3, "N_VOCAB": 64, "N_A": 16, "ANNEAL_END": 100,
+                       "MESH_MASK_LIST": ["sky"], "RAY_MASK_LIST": ["person", "car"],
+                       "SDF_CONFIG": {"d_out": 65, "d_hidden": 64, "skip_in": "(4,)"},
+                       "COLOR_CONFIG": {"d_feature": 64, "d_hidden": 64, "head_channels": 32},
+                       "S_CONFIG": {"init_val": 0.3}, "LOSS": {"igr_weight": 0.0001}},
+           "DATASET": {"ROOT_DIR": root, "DATASET_NAME": "phototourism", "PHOTOTOURISM": {"CACHE_DIR": "cache"}},
+           "TRAINER": {"CANONICAL_BS": 4096, "CANONICAL_LR": "1e-4", "LR_SCHEDULER": "none", "SAVE_DIR": os.path.join(root, "ckpts"),
+                       "SAVE_FREQ": 4}}
+    cfg = os.path.join(root, "train_synth.yaml")
+    yaml.safe_dump(exp, open(cfg, "w"))
+    return cfg
+
+
+def test_train_driver_runs_refreshes_the_octree_and_resumes(tmp_path):
+    root = str(tmp_path / "scene")
+    cfg = _write_scene(root)
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "train.py"), "--cfg_path", cfg, "--batch_size", "64",
+           "--num_epochs", "3", "--max_steps", "7", "--exp_name", "t", "--prec", "f32", "--log_every", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("epoch")]
+    assert len(lines) == 7
+    losses = [float(l.split("loss")[1].split()[0]) for l in lines]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] * 1.5
+    assert "rays resident" in r.stdout
+    n_res = int(r.stdout.split("chunk(s), ")[1].split(" rays")[0])
+    assert 0 < n_res < 600  # the black-listed labels (person, car) were removed at load time
+    ck = torch.load(os.path.join(root, "ckpts", "t", "last.ckpt"), map_location="cpu")
+    assert ck["global_step"] == 7 and os.path.isfile(os.path.join(root, "ckpts", "t", "iter_4.ckpt"))
+    keys = list(ck["state_dict"])
+    assert "embedding_a.weight" in keys and "neuconw.sdf_net.lin0.weight_v" in keys and "nerf.rgb.0.weight" in keys
+    assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.is_floating_point())
+    st = ck["optimizer_states"][0]
+    assert st["param_groups"][0]["eps"] == 1e-7 and float(st["state"][0]["step"]) == 7.0
+    # resume: continues from global_step 7 with the Adam moments restored
+    r2 = subprocess.run(cmd[:-6] + ["--max_steps", "9", "--exp_name", "t2", "--prec", "f32", "--log_every", "1", "--ckpt_path",
+                                    os.path.join(root, "ckpts", "t", "last.ckpt")], capture_output=True, text=True, cwd=ROOT,
+                        timeout=600)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    assert "step 7 " in r2.stdout and "step 8 " in r2.stdout and "step 6 " not in r2.stdout

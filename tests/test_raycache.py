@@ -1,0 +1,113 @@
+"""Ray-cache reader + on-device batch assembly.
+
+  * the oracle restatement reproduces the golden vector produced by the reference's own __getitem__ / training_step
+    filter / _get_local_split (tests/golden/make_golden_raycache.py) exactly;
+  * the product's split assignment is the reference's for world sizes 1, 2, 4, 8 (CPU);
+  * GPU: RayCache.batch == the reference batch bit for bit (gather, column split, ts / label truncation, black-list
+    mask), prefilter gives full fixed-size batches drawn only from kept rays, ragged / empty / out-of-range inputs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import neuconw_oracle as O
+from tests._util import GOLDEN
+
+SCENE = os.path.join(GOLDEN, "raycache_scene")
+NAMES = ["split_0", "split_1", "split_2"]
+MASK = ["person", "car", "bicycle", "minibike"]
+
+
+def _golden():
+    z = np.load(os.path.join(GOLDEN, "raycache.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _cache_arrays():
+    rays = np.concatenate([np.load(os.path.join(SCENE, "cache", "splits", n, "rays1.npz"))["arr_0"] for n in NAMES])
+    rgbs = np.concatenate([np.load(os.path.join(SCENE, "cache", "splits", n, "rgbs1.npz"))["arr_0"] for n in NAMES])
+    return rays, rgbs
+
+
+def test_oracle_matches_reference_golden():
+    g = _golden()
+    rays, rgbs = _cache_arrays()
+    b = O.ray_cache_batch(rays, rgbs, g["idx"])
+    for k in ("rays", "ts", "semantics", "rgbs"):
+        assert np.array_equal(b[k], g[k]), k
+    assert np.array_equal(O.ray_mask_filter(b, g["mask_ids"]), g["ray_mask"])
+    assert 0 < g["ray_mask"].sum() < len(g["ray_mask"])
+    items = ["split_%d" % i for i in range(10)]
+    for world in (1, 2, 4, 8):
+        for rank in range(world):
+            assert O.local_split(items, world, rank) == list(g["split_w%d_r%d" % (world, rank)])
+
+
+def test_product_split_assignment_and_label_ids():
+    from neuralrecon_w_amd import raycache
+    from neuralrecon_w_amd.labels import LABEL_IDS
+
+    g = _golden()
+    items = ["split_%d" % i for i in range(10)]
+    for world in (1, 2, 4, 8):
+        got = [raycache.local_splits(items, world, r) for r in range(world)]
+        for r in range(world):
+            assert got[r] == list(g["split_w%d_r%d" % (world, r)])
+        assert len({len(x) for x in got}) == 1  # equal shares (padding by re-drawing, like the reference)
+    assert [LABEL_IDS[n] for n in MASK] == list(g["mask_ids"])
+    assert sorted(raycache.list_splits(SCENE, "cache")) == NAMES
+
+
+@pytest.mark.gpu
+def test_batch_assembly_matches_reference_batch():
+    from neuralrecon_w_amd import raycache
+
+    g = _golden()
+    rc = raycache.RayCache(SCENE, "cache", NAMES, "cuda", ray_mask_list=MASK)
+    assert len(rc) == 100
+    b = rc.batch(torch.from_numpy(g["idx"]).cuda())
+    assert np.array_equal(b["rays"].cpu().numpy(), g["rays"])
+    assert np.array_equal(b["ts"].cpu().numpy(), g["ts"]) and b["ts"].dtype == torch.int64
+    assert np.array_equal(b["semantics"].cpu().numpy(), g["semantics"].astype(np.int64))
+    assert np.array_equal(b["rgbs"].cpu().numpy(), g["rgbs"])
+    assert np.array_equal(b["keep"].cpu().numpy(), g["ray_mask"])
+    rays, ts, label, rgbs = rc.filtered(b)  # the reference's boolean index
+    assert rays.shape == (int(g["ray_mask"].sum()), 11) and np.array_equal(rays.cpu().numpy(), g["rays"][g["ray_mask"]])
+    # whole cache in order (idx = None), empty batch, out-of-range index clamped instead of reading past the cache
+    allb = rc.batch(None)
+    full, _ = _cache_arrays()
+    assert np.array_equal(allb["rays"].cpu().numpy(), np.concatenate([full[:, :8], full[:, 10:13]], -1))
+    assert rc.batch(torch.zeros(0, dtype=torch.int64, device="cuda"))["rays"].shape == (0, 11)
+    edge = rc.batch(torch.tensor([0, 99, 100, -1], device="cuda"))
+    assert np.array_equal(edge["rays"][2].cpu().numpy(), edge["rays"][1].cpu().numpy())
+    assert np.array_equal(edge["rays"][3].cpu().numpy(), edge["rays"][0].cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_prefiltered_cache_gives_full_fixed_batches():
+    from neuralrecon_w_amd import raycache
+
+    full, _ = _cache_arrays()
+    g = _golden()
+    kept = ~np.isin(full[:, 9], g["mask_ids"])
+    rc = raycache.RayCache(SCENE, "cache", NAMES, "cuda", ray_mask_list=MASK, prefilter=True)
+    assert rc.prefiltered and len(rc) == int(kept.sum()) < 100
+    seen = 0
+    for b in rc.epoch(16):
+        assert bool(b["keep"].all())  # nothing left to drop: fixed batch size, no device->host sync per step
+        assert not np.isin(b["semantics"].cpu().numpy(), g["mask_ids"]).any()
+        seen += b["rays"].shape[0]
+    assert seen == len(rc)
+    assert sum(b["rays"].shape[0] for b in rc.epoch(16, drop_last=True)) == (len(rc) // 16) * 16
+
+
+def test_h5_cache_is_refused(tmp_path):
+    from neuralrecon_w_amd import raycache
+
+    d = tmp_path / "cache" / "splits" / "split_0"
+    d.mkdir(parents=True)
+    (d / "rays1.h5").write_bytes(b"")
+    with pytest.raises(NotImplementedError):
+        raycache.RayCache(str(tmp_path), "cache", ["split_0"], "cpu")
