@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round profile set (run on the GPU box through gpurun): rocprofv3 kernel stats of the bench command, the
-# PMC passes (HBM traffic in separate passes, SQ counters) and the plain bench line.  Outputs: gpurun_out/r01/
+# PMC passes (HBM traffic in separate passes, SQ counters) and the plain bench line.  Outputs: gpurun_out/r02/
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$REPO/gpurun_out/r01; mkdir -p "$OUT"
-TAG=${1:-v3}
+OUT=$REPO/gpurun_out/r02; mkdir -p "$OUT"
+TAG=${1:-v1}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- \
-    python "$REPO/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_under_rocprof.json" 2> /tmp/prof_stats.err
+    python "$REPO/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --no-parity-mode > "$OUT/bench_${TAG}_under_rocprof.json" 2> /tmp/prof_stats.err
 f=$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/bench_${TAG}_kernel_stats.csv"
 f=$(find /tmp/prof_stats -name '*domain_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/bench_${TAG}_domain_stats.csv"
 python "$REPO/scripts/pmc_pass.py" "$OUT/pmc_traffic_${TAG}.json" "FETCH_SIZE" "WRITE_SIZE" > "$OUT/pmc_traffic_${TAG}.log" 2>&1

@@ -7,7 +7,7 @@ res = collections.defaultdict(dict)
 for gi, grp in enumerate(groups):
     d = "/tmp/pmc_pass_%d" % gi
     cmd = ["rocprofv3", "--pmc"] + grp.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--",
-           sys.executable, os.path.join(repo, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+           sys.executable, os.path.join(repo, "bench.py"), "--inner", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-pmc", "--no-parity-mode"]
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
@@ -16,8 +16,9 @@ for gi, grp in enumerate(groups):
         continue
     acc = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(files[0])):
-        k = row["Kernel_Name"].split("(")[0]
-        k = k.replace("void ", "")
+        # keep anonymous-namespace kernels and template arguments apart (round 1 collapsed them into one "" entry)
+        k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        k = k.split("(")[0] if "(" in k else k
         a = acc[(k, row["Counter_Name"])]
         a[0] += float(row["Counter_Value"]); a[1] += 1
     for (k, c), (s, n) in acc.items():

@@ -79,7 +79,7 @@ def test_train_driver_runs_refreshes_the_octree_and_resumes(tmp_path):
     ck = torch.load(os.path.join(root, "ckpts", "t", "last.ckpt"), map_location="cpu")
     assert ck["global_step"] == 7 and os.path.isfile(os.path.join(root, "ckpts", "t", "iter_4.ckpt"))
     keys = list(ck["state_dict"])
-    assert "embedding_a.weight" in keys and "neuconw.sdf_net.lin0.weight_v" in keys and "nerf.rgb.0.weight" in keys
+    assert "embedding_a.weight" in keys and "neuconw.sdf_net.lin0.weight_v" in keys and "nerf.rgb_linear.weight" in keys
     assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.is_floating_point())
     st = ck["optimizer_states"][0]
     assert st["param_groups"][0]["eps"] == 1e-7 and float(st["state"][0]["step"]) == 7.0
