@@ -260,6 +260,10 @@ int ncw_nerf_bwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t 
 int ncw_batch_assemble(const float* all_rays, int ncols, const float* all_rgbs, const int64_t* idx, int64_t n_rows,
                        int64_t B, int with_semantics, float* rays, int64_t* ts, int64_t* label, float* rgbs,
                        const int* mask_ids, int n_ids, uint8_t* keep, void* stream);
+/* out[idx[r], :] += rows[r, :] with f32 atomics (out [n_out, n_cols], zero-filled or accumulating; indices outside
+ * [0, n_out) are skipped): the backward of the appearance-embedding lookup `embeddings["a"](ts)` (renderer.py:808). */
+int ncw_scatter_add_rows(const float* rows, const int64_t* idx, int64_t R, int n_cols, int64_t n_out, float* out,
+                         void* stream);
 /* out[R,n_cols] (+)= per-ray sums of rows[R*per_ray, n_cols] in sample order (see d_a_rows above). */
 int ncw_ray_sum_rows(const float* rows, int64_t R, int per_ray, int n_cols, float* out, int accumulate, void* stream);
 

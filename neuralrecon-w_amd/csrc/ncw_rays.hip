@@ -705,6 +705,30 @@ __global__ __launch_bounds__(256) void ray_sum_rows_kernel(const float* __restri
     out[e] = accumulate ? out[e] + s : s;
 }
 
+// out[idx[r]][j] += rows[r][j]: the backward of the appearance-embedding lookup `embedding_a(ts)`
+// (lightning_modules/neuconw_system.py:70-75, renderer.py:808) -- torch's embedding_dense_backward takes 77 us for
+// 1024 rows (it serialises duplicate indices); f32 atomics into the zero-filled gradient take ~3 us.  The fp32 parity
+// mode keeps torch's deterministic kernel (atomics would make its result order-dependent for repeated images).
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ rows, const int64_t* __restrict__ idx,
+                                                               int64_t R, int n_cols, int64_t n_out, float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= R * n_cols) return;
+    const int64_t r = e / n_cols;
+    const int j = (int)(e - r * n_cols);
+    const int64_t t = idx[r];
+    if (t >= 0 && t < n_out) atomicAdd(out + t * n_cols + j, rows[e]);
+}
+
+extern "C" int ncw_scatter_add_rows(const float* rows, const int64_t* idx, int64_t R, int n_cols, int64_t n_out, float* out,
+                                    void* stream) {
+    if (R <= 0 || n_cols <= 0) return 0;
+    if (!rows || !idx || !out || n_out <= 0) return NCW_E_BADARG;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((R * n_cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rows, idx, R, n_cols, n_out, out);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int ncw_ray_sum_rows(const float* rows, int64_t R, int per_ray, int n_cols, float* out, int accumulate,
                                 void* stream) {
     if (R <= 0 || n_cols <= 0) return 0;

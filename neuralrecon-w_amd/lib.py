@@ -14,7 +14,7 @@ PREC_F32 = 0
 PREC_BF16 = 1
 MAX_LAYERS = 12
 MAX_SEGS = 4
-ABI_VERSION = 4  # 4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
+ABI_VERSION = 5  # 5: ncw_scatter_add_rows;  4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
 
 
 class NcwSeg(C.Structure):
@@ -145,6 +145,7 @@ _PROTOS = {
                                 C.c_void_p]),
     "ncw_batch_assemble": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ncw_scatter_add_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "ncw_ray_sum_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "ncw_nerf_fwd": (C.c_int, [C.POINTER(NcwNerfNet), C.c_int, C.POINTER(NcwPoints), C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NcwNerfStash), C.c_void_p]),

@@ -35,6 +35,7 @@ class _RenderFn(torch.autograd.Function):
         neuconw, nerf = rdr.neuconw, rdr.nerf
         R, S = z.shape
         dev = z.device
+        ctx.set_materialize_grads(False)  # outputs the loss does not use arrive as None, not as freshly filled zeros
         inv_s = torch.exp(variance.detach() * 10.0).clamp(1e-6, 1e6).reshape(1).float()
         a_det = a_embedded.detach().contiguous().float()
         use_bg = rdr.render_bg and rdr.n_outside > 0 and z_out is not None
@@ -150,6 +151,26 @@ class _RenderFn(torch.autograd.Function):
             pass
         ctx.guard.release()
         return (None, None, None, None, None, None, None, None, d_a, d_var) + tuple(out)
+
+
+class _EmbedFn(torch.autograd.Function):
+    """embeddings["a"](ts) (renderer.py:808) with the backward as one atomic scatter-add launch (`ncw_scatter_add_rows`,
+    ~3 us) instead of torch's embedding_dense_backward (77 us for 1024 rays: it serialises repeated indices)."""
+
+    @staticmethod
+    def forward(ctx, weight, ts):
+        ctx.save_for_backward(ts)
+        ctx.shape = weight.shape
+        return weight.detach().index_select(0, ts)
+
+    @staticmethod
+    def backward(ctx, d_a):
+        (ts,) = ctx.saved_tensors
+        d_a = d_a.contiguous().float()
+        dw = torch.zeros(ctx.shape, device=d_a.device, dtype=torch.float32)
+        L.check(L.get_lib().ncw_scatter_add_rows(L.ptr(d_a), L.ptr(ts), d_a.shape[0], d_a.shape[1], dw.shape[0], L.ptr(dw),
+                                                 L.stream_ptr(d_a.device)), "ncw_scatter_add_rows")
+        return dw, None
 
 
 class _RayTailFn(torch.autograd.Function):
@@ -370,7 +391,14 @@ class NeuconWRenderer:
         near = (near / self.radius).float()
         far = (far / self.radius).float()
         depth_gt = (depth_gt / self.radius).float()
-        a_embedded = self.embeddings["a"](ts)
+        emb_a = self.embeddings["a"]
+        ordered = self.reproducible if self.reproducible is not None else (self.prec == L.PREC_F32)
+        if (not ordered and isinstance(emb_a, torch.nn.Embedding) and emb_a.padding_idx is None and emb_a.max_norm is None
+                and not emb_a.sparse and emb_a.weight.dtype == torch.float32 and torch.is_grad_enabled()
+                and emb_a.weight.requires_grad and ts.dtype == torch.int64 and ts.dim() == 1):
+            a_embedded = _EmbedFn.apply(emb_a.weight, ts.contiguous())
+        else:  # fp32 / reproducible mode, or an unusual embedding: torch's own (deterministic) lookup + backward
+            a_embedded = emb_a(ts)
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
         n_samples, z_vals, z_vals_outside, sample_dist = self.sparse_sampler(rays_o, rays_d, near, far, perturb, _rand)
         bgc = None
@@ -406,7 +434,7 @@ class NeuconWRenderer:
             "cdf_fine": cdf, "gradients": gradients, "mask_error": mask_error, "weights": weights,
             "weights_sum": weights_sum, "weights_max": torch.max(weights, dim=-1, keepdim=True)[0],
             "gradient_error": gradient_error, "inside_sphere": inside,
-            "depth": depth, "floor_normal_error": torch.zeros_like(normals), "floor_y_error": torch.zeros_like(normals),
+            "depth": depth, "floor_normal_error": (zn := torch.zeros_like(normals)), "floor_y_error": zn,
             "sfm_depth_loss": sfm_depth_loss,
         }
 
