@@ -62,6 +62,10 @@ NCW_DEV void pp_load_slice(bf16x8* a, const void* w, int rb_stride, int ob, int 
 
 // LDS-only barrier: LDS stores of this phase are complete, vector-memory traffic stays in flight
 NCW_DEV void pp_barrier() {
+#ifdef PP_EXP_NOBAR  // timing experiment only: results are garbage
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return;
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -121,32 +125,64 @@ template <int NB> struct PPAcc { f32x16 v[NB][2]; };  // [block of the wave][til
 #ifndef PP_RING
 #define PP_RING 4
 #endif
+#ifdef PP_EXP_TRACE2  // timing experiment: cycle stamps INSIDE the segments of one workgroup (slots of 8 per segment)
+__device__ float* pp_trace_buf;
+__device__ unsigned long long pp_trace_t0;
+#define PP_STEP_STAMP(u) do { if ((u) % 4 == 0 && blockIdx.x == 0 && (threadIdx.x & 63) == 0) { \
+        const int w_ = threadIdx.x >> 6; int& c_ = pp_trace_cnt[0]; \
+        if (c_ < 62) pp_trace_buf[w_ * 512 + c_ * 8 + (u) / 4] = (float)(__builtin_readcyclecounter() - pp_trace_t0); } } while (0)
+#else
+#define PP_STEP_STAMP(u) do {} while (0)
+#endif
 template <bool PREFETCH, int NB, class EPI>
 NCW_DEV void pp_segment(PPAcc<NB>& m, const f32x16 (&c_init)[NB], bf16x8 (&w)[NB][16], const pp_lfrag* in,
-                        const void* wnext, int nstride, int ob0, int ob_step, int lane, EPI&& epi) {
+                        const void* wnext, int nstride, int ob0, int ob_step, int lane, EPI&& epi, int* pp_trace_cnt = nullptr) {
     constexpr int RD = PP_RING - 1;
+    (void)pp_trace_cnt;
     bf16x8 b[PP_RING][2];
+#ifndef PP_EXP_NOLDSR
 #pragma unroll
     for (int c = 0; c < RD; ++c) { b[c][0] = in[c * 64]; b[c][1] = in[(16 + c) * 64]; }
+#endif
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        if (u + RD < 16) { b[(u + RD) % PP_RING][0] = in[(u + RD) * 64]; b[(u + RD) % PP_RING][1] = in[(16 + u + RD) * 64]; }
+        PP_STEP_STAMP(u);
+#ifndef PP_EXP_NOLDSR
+        if (u + RD < 16)
+#else
+        if (false)
+#endif
+        { b[(u + RD) % PP_RING][0] = in[(u + RD) * 64]; b[(u + RD) % PP_RING][1] = in[(16 + u + RD) * 64]; }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-#if defined(PP_EXP_NOLDSR)
+#if defined(PP_EXP_NOMFMA) && defined(PP_EXP_NOLDSR)
+            if (u == 0) { m.v[nb][0] = c_init[nb]; m.v[nb][1] = c_init[nb]; }
+            m.v[nb][0][u] += (float)w[nb][u][0];
+            m.v[nb][1][u] += (float)w[nb][u][1];
+#elif defined(PP_EXP_NOMFMA)
+            if (u == 0) { m.v[nb][0] = c_init[nb]; m.v[nb][1] = c_init[nb]; }
+            m.v[nb][0][u] += (float)w[nb][u][0] * (float)b[u % PP_RING][0][0];
+            m.v[nb][1][u] += (float)w[nb][u][1] * (float)b[u % PP_RING][1][1];
+#elif defined(PP_EXP_NOLDSR)
             m.v[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][u], w[nb][(u + 1) & 15], u == 0 ? c_init[nb] : m.v[nb][0], 0, 0, 0);
             m.v[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][u], w[nb][(u + 2) & 15], u == 0 ? c_init[nb] : m.v[nb][1], 0, 0, 0);
 #else
             m.v[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][u], b[u % PP_RING][0], u == 0 ? c_init[nb] : m.v[nb][0], 0, 0, 0);
             m.v[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][u], b[u % PP_RING][1], u == 0 ? c_init[nb] : m.v[nb][1], 0, 0, 0);
 #endif
+#ifndef PP_EXP_NOW
             if (PREFETCH) w[nb][u] = pp_load_unit(wnext, u * nstride + ob0 + nb * ob_step, lane);
+#endif
         }
         epi(u);
 #ifndef PP_NO_SCHEDBAR
         __builtin_amdgcn_sched_barrier(0);
 #endif
     }
+    PP_STEP_STAMP(16);
+#ifdef PP_EXP_TRACE2
+    if (pp_trace_cnt) ++pp_trace_cnt[0];
+#endif
 }
 
 // extra k-units (gamma) from the x buffer: xin = xbuf + (first tile of the group) * XU * 64 + lane
@@ -225,6 +261,12 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
     // the group finished one segment earlier -- goes through the epilogue: no register copies
     PPAcc<NB> x, y;
     bf16x8 frag[NB];
+    int tcnt[1] = {0};
+    (void)tcnt;
+#ifdef PP_EXP_TRACE2
+    if (blockIdx.x == 0 && threadIdx.x == 0) { pp_trace_buf = sdf; pp_trace_t0 = __builtin_readcyclecounter(); }
+    __syncthreads();
+#endif
     f32x16 bias[NB];
     auto read_bias = [&](int l) {
 #pragma unroll
@@ -239,6 +281,9 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
     int stamp = 0;
     (void)stamp;
 #define PP_SEG_END() do { PP_STAMP(64 + stamp); pp_barrier(); ++stamp; PP_STAMP(stamp); } while (0)
+#ifdef PP_STATIC_PRIO  // experiment: the second-dispatched half loses every arbitration (MI355X_MICROARCH.md): boost it once
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(PP_STATIC_PRIO);
+#endif
     pp_barrier();
     PP_STAMP(0);
     auto softplus_f = [](float z, int, int, int) { return pp_softplus(z); };
@@ -267,7 +312,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
             const pp_lfrag* in = abuf + (0 * 2 + ((l - 1) & 1)) * (PP_GRP / 16) + lane;
             pp_lfrag* out = abuf + (1 * 2 + ((l - 1) & 1)) * (PP_GRP / 16);  // E(l-1, g1)
             auto epi = [&](int u) { pp_epi_step<NB>(u, y, frag, out, ob, NW, lane, softplus_f); };
-            pp_segment<false, NB>(x, bias, wa, in, nullptr, 8, ob, NW, lane, epi);
+            pp_segment<false, NB>(x, bias, wa, in, nullptr, 8, ob, NW, lane, epi, tcnt);
 #ifndef PP_EXP_NOSKIP
             if (l == net.skip_layer) pp_mma_x<3, NB>(x, wx, gbuf + lane);
 #endif
@@ -278,8 +323,8 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
             const pp_lfrag* in = abuf + (1 * 2 + ((l - 1) & 1)) * (PP_GRP / 16) + lane;
             pp_lfrag* out = abuf + (0 * 2 + (l & 1)) * (PP_GRP / 16);        // E(l, g0)
             auto epi = [&](int u) { pp_epi_step<NB>(u, x, frag, out, ob, NW, lane, softplus_f); };
-            if (more) pp_segment<true, NB>(y, bias, wa, in, net.w[l + 1], 8, ob, NW, lane, epi);
-            else pp_segment<false, NB>(y, bias, wa, in, nullptr, 8, ob, NW, lane, epi);
+            if (more) pp_segment<true, NB>(y, bias, wa, in, net.w[l + 1], 8, ob, NW, lane, epi, tcnt);
+            else pp_segment<false, NB>(y, bias, wa, in, nullptr, 8, ob, NW, lane, epi, tcnt);
 #ifndef PP_EXP_NOSKIP
             if (l == net.skip_layer) pp_mma_x<3, NB>(y, wx, gbuf + 2 * 3 * 64 + lane);
             // the skip layer's gamma columns (units 16..18) for the NEXT layer (W_0's units are no longer needed)
@@ -309,7 +354,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
 #pragma unroll
         for (int u = 0; u < 16; ++u) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[u], in[u * 64], o.v[0], 0, 0, 0);
         const int64_t p = (tile0 + t) * 32 + (lane & 31);
-#if !defined(PP_EXP_TRACE) && !defined(PP_EXP_TIMELINE)
+#if !defined(PP_EXP_TRACE) && !defined(PP_EXP_TIMELINE) && !defined(PP_EXP_TRACE2)
         if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
 #else
         if (o.v[0][0] == 123.456f) sdf[p] = 0.f;
