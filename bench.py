@@ -84,14 +84,28 @@ def build_models(device, prec, seed=0):
     return emb, neuconw, nerf, rdr
 
 
-def loss_fn(out, rgbs):
-    """NeuconWLoss, losses.py:21-43 with the brandenburg_gate weights (igr 1e-4, mask 0.1, depth 0.1)."""
+def loss_fn_torch(out, rgbs):
+    """NeuconWLoss, losses.py:21-43 with the brandenburg_gate weights (igr 1e-4, mask 0.1, depth 0.1), plain torch --
+    the arithmetic `loss_fn` below runs as one launch each way (tests/test_gpu_glue.py compares them)."""
     R = rgbs.shape[0]
     loss = (out["color"] - rgbs).abs().sum() / (R + 1e-5)
     loss = loss + 1e-4 * out["gradient_error"].mean()
     loss = loss + 0.1 * out["mask_error"].mean()
     loss = loss + 0.1 * out["sfm_depth_loss"].mean()
     return loss
+
+
+def loss_fn(out, rgbs):
+    """The same loss through neuralrecon_w_amd.NeuconWLoss (`ncw_loss_fwd` / `ncw_loss_bwd`)."""
+    global _LOSS
+    if _LOSS is None:
+        import neuralrecon_w_amd as nw
+
+        _LOSS = nw.NeuconWLoss(coef=1.0, igr_weight=1e-4, mask_weight=0.1, depth_weight=0.1, use_mask=True, use_depth=True)
+    return _LOSS(out, rgbs)
+
+
+_LOSS = None
 
 
 def kernel_flops(R):

@@ -260,6 +260,29 @@ int ncw_nerf_bwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t 
 int ncw_batch_assemble(const float* all_rays, int ncols, const float* all_rgbs, const int64_t* idx, int64_t n_rows,
                        int64_t B, int with_semantics, float* rays, int64_t* ts, int64_t* label, float* rgbs,
                        const int* mask_ids, int n_ids, uint8_t* keep, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Per-step glue of render() / the loss as single launches (each replaces 6-25 tiny torch kernels; the step is
+ * GPU-bound, so every 3-5 us launch counts).
+ * ---------------------------------------------------------------------------------------- */
+/* renderer.py:793-806: rays [R,ncols >= 8] -> rays_o = (rays[:,0:3] - origin) / radius, rays_d = rays[:,3:6],
+ * near = rays[:,6] / radius, far = rays[:,7] / radius, depth_gt = rays[:,8] / radius, depth_weight = rays[:,9]
+ * (zeros when ncols < 10).  origin: HOST float[3]. */
+int ncw_ray_prologue(const float* rays, int ncols, int64_t R, const float* origin_host, float radius, float* rays_o,
+                     float* rays_d, float* near, float* far, float* depth_gt, float* depth_weight, void* stream);
+/* SingleVarianceNetwork (models/neuconw.py:173-179) as used by render_core (renderer.py:624-632):
+ * inv_s = clamp(exp(10 variance), 1e-6, 1e6), s_val = 1 / inv_s; backward: d_variance = 10 inv_s [1e-6 < inv_s < 1e6]
+ * sum_r d_inv_s[r] (the per-ray terms of ncw_composite_bwd, summed in a fixed order). */
+int ncw_inv_s_fwd(const float* variance, float* inv_s, float* s_val, void* stream);
+int ncw_inv_s_bwd(const float* d_inv_s_rays, int64_t R, const float* inv_s, float* d_variance, void* stream);
+/* NeuconWLoss (losses.py:21-43): loss = coef * ( sum|color - rgbs| / (R + 1e-5) + igr_w * gradient_error
+ *   + mask_w * mean(mask_error[n_mask]) + depth_w * mean(sfm[n_sfm]) ); NULL / 0 switches a term off.
+ * bwd: d_color [R,3], d_gradient_error [1], d_mask_error [n_mask], d_sfm [n_sfm] for an upstream d_loss [1]. */
+int ncw_loss_fwd(const float* color, const float* rgbs, int64_t R, const float* gradient_error, const float* mask_error,
+                 int64_t n_mask, const float* sfm, int64_t n_sfm, float coef, float igr_w, float mask_w, float depth_w,
+                 float* loss, void* stream);
+int ncw_loss_bwd(const float* d_loss, const float* color, const float* rgbs, int64_t R, int64_t n_mask, int64_t n_sfm,
+                 float coef, float igr_w, float mask_w, float depth_w, float* d_color, float* d_gradient_error,
+                 float* d_mask_error, float* d_sfm, void* stream);
 /* out[idx[r], :] += rows[r, :] with f32 atomics (out [n_out, n_cols], zero-filled or accumulating; indices outside
  * [0, n_out) are skipped): the backward of the appearance-embedding lookup `embeddings["a"](ts)` (renderer.py:808). */
 int ncw_scatter_add_rows(const float* rows, const int64_t* idx, int64_t R, int n_cols, int64_t n_out, float* out,
@@ -389,6 +412,7 @@ typedef struct NcwCompositeOut {
     float* mid_z;        /* [R,S] */
     float* dists;        /* [R,S] */
     float* bg_alpha;     /* [R,S+O] or NULL when !has_bg */
+    float* weights_max;  /* [R] max of weights over the ray (render()'s "weights_max", renderer.py:905) or NULL */
 } NcwCompositeOut;
 
 typedef struct NcwCompositeGrad {

@@ -10,4 +10,5 @@ from .lib import PREC_BF16, PREC_F32, NeuconwHipError  # noqa: F401
 from .nerf import NeRF  # noqa: F401
 from .neuconw import NeuconW, RenderingNetwork, SDFNetwork, SingleVarianceNetwork  # noqa: F401
 from .renderer import NeuconWRenderer  # noqa: F401
+from .losses import NeuconWLoss  # noqa: F401
 from .trainer import FlatAdam, FlatParams, TrainStep  # noqa: F401

@@ -110,19 +110,10 @@ def surface_level(voxel_size, bbx):
 
 
 def neuconw_loss(cfg):
-    """losses.py:21-43 (NeuconWLoss) with the experiment's weights and switches -> loss_fn(outputs, rgbs): colour L1 over
-    the batch, eikonal term, mask term iff MESH_MASK_LIST, SfM-depth term iff DEPTH_LOSS, every term times `coef`."""
-    w, n = cfg["NEUCONW"]["LOSS"], cfg["NEUCONW"]
-    use_mask, use_depth = n["MESH_MASK_LIST"] is not None, bool(n["DEPTH_LOSS"])
+    """losses.py:21-43 (NeuconWLoss) with the experiment's weights and switches -> loss_fn(outputs, rgbs) (one launch each
+    way: neuralrecon_w_amd.losses.NeuconWLoss)."""
+    from .losses import NeuconWLoss
 
-    def loss_fn(out, rgbs):
-        R = rgbs.shape[0]
-        loss = w["coef"] * ((out["color"] - rgbs).abs().sum() / (R + 1e-5))
-        loss = loss + w["coef"] * (w["igr_weight"] * out["gradient_error"].mean())
-        if use_mask:
-            loss = loss + w["coef"] * (w["mask_weight"] * out["mask_error"].mean())
-        if use_depth:
-            loss = loss + w["coef"] * (w["depth_weight"] * out["sfm_depth_loss"].mean())
-        return loss
-
-    return loss_fn
+    w = cfg["NEUCONW"]["LOSS"]
+    return NeuconWLoss(coef=w["coef"], igr_weight=w["igr_weight"], mask_weight=w["mask_weight"], depth_weight=w["depth_weight"],
+                       floor_weight=w["floor_weight"], config=cfg)

@@ -245,7 +245,7 @@ struct CompArgs {
 };
 struct CompOut {
     float *color, *color_sphere, *color_bg, *weights, *weights_sum, *cdf, *inside, *depth, *normals, *eik;
-    float *mid_z, *dists, *bg_alpha;
+    float *mid_z, *dists, *bg_alpha, *weights_max;
 };
 
 NCW_DEV float iter_cos_of(float tc, float c) {
@@ -327,10 +327,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs A, CompOut 
     for (int j = lane; j < M; j += 64) tA[j] = 1.0f - alm[j] + 1e-7f;
     __builtin_amdgcn_wave_barrier();
     wave_excl_scan<true>(tA, tA, M, lane);  // tA = T merged
-    float cr = 0.f, cg = 0.f, cb = 0.f, wsum = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    float cr = 0.f, cg = 0.f, cb = 0.f, wsum = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, wmax = -3.4e38f;
     for (int j = lane; j < M; j += 64) {
         const float w = alm[j] * tA[j];
         Q.weights[(size_t)r * M + j] = w;
+        wmax = fmaxf(wmax, w);
         float rr, gg, bb;
         bool ins = false;
         if (j < S) ins = Q.inside[(size_t)r * S + j] > 0.f;
@@ -349,6 +350,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs A, CompOut 
         }
     }
     cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); wsum = wave_sum(wsum);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
     nx = wave_sum(nx); ny = wave_sum(ny); nz = wave_sum(nz);
     if (A.background_rgb) {
         cr += A.background_rgb[0] * (1.0f - wsum);
@@ -394,6 +397,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs A, CompOut 
         Q.color_sphere[r * 3] = sr; Q.color_sphere[r * 3 + 1] = sg; Q.color_sphere[r * 3 + 2] = sb;
         Q.color_bg[r * 3] = br; Q.color_bg[r * 3 + 1] = bgc; Q.color_bg[r * 3 + 2] = bb2;
         Q.weights_sum[r] = wsum;
+        if (Q.weights_max) Q.weights_max[r] = wmax;
         Q.depth[r] = depth;
         Q.normals[r * 3] = nx; Q.normals[r * 3 + 1] = ny; Q.normals[r * 3 + 2] = nz;
         Q.eik[r * 2] = eik_num; Q.eik[r * 2 + 1] = eik_den;
@@ -665,7 +669,7 @@ extern "C" int ncw_composite_fwd(const NcwCompositeIn* in, const NcwCompositeOut
     CompOut Q;
     Q.color = out->color; Q.color_sphere = out->color_sphere; Q.color_bg = out->color_bg; Q.weights = out->weights;
     Q.weights_sum = out->weights_sum; Q.cdf = out->cdf; Q.inside = out->inside; Q.depth = out->depth;
-    Q.normals = out->normals; Q.eik = out->eik; Q.mid_z = out->mid_z; Q.dists = out->dists; Q.bg_alpha = out->bg_alpha;
+    Q.normals = out->normals; Q.eik = out->eik; Q.mid_z = out->mid_z; Q.dists = out->dists; Q.bg_alpha = out->bg_alpha; Q.weights_max = out->weights_max;
     hipLaunchKernelGGL(composite_fwd_kernel, dim3((in->R + 3) / 4), dim3(256), 0, (hipStream_t)stream, A, Q);
     NCW_CHECK_LAUNCH();
     return 0;

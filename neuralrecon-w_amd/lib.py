@@ -14,7 +14,7 @@ PREC_F32 = 0
 PREC_BF16 = 1
 MAX_LAYERS = 12
 MAX_SEGS = 4
-ABI_VERSION = 5  # 5: ncw_scatter_add_rows;  4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
+ABI_VERSION = 6  # 6: ray prologue / inv_s / loss launches, NcwCompositeOut.weights_max;  5: ncw_scatter_add_rows;  4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
 
 
 class NcwSeg(C.Structure):
@@ -112,7 +112,7 @@ NcwCompositeIn = _ptr_struct(
 NcwCompositeOut = _ptr_struct(
     "NcwCompositeOut",
     ["color", "color_sphere", "color_bg", "weights", "weights_sum", "cdf", "inside", "depth", "normals", "eik",
-     "mid_z", "dists", "bg_alpha"],
+     "mid_z", "dists", "bg_alpha", "weights_max"],
 )
 NcwCompositeGrad = _ptr_struct(
     "NcwCompositeGrad",
@@ -145,6 +145,13 @@ _PROTOS = {
                                 C.c_void_p]),
     "ncw_batch_assemble": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ncw_ray_prologue": (C.c_int, [_VP, C.c_int, C.c_int64, C.POINTER(C.c_float), C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "ncw_inv_s_fwd": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "ncw_inv_s_bwd": (C.c_int, [_VP, C.c_int64, _VP, _VP, _VP]),
+    "ncw_loss_fwd": (C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, C.c_int64, _VP, C.c_int64, C.c_float, C.c_float, C.c_float,
+                               C.c_float, _VP, _VP]),
+    "ncw_loss_bwd": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                               _VP, _VP, _VP, _VP, _VP]),
     "ncw_scatter_add_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "ncw_ray_sum_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "ncw_nerf_fwd": (C.c_int, [C.POINTER(NcwNerfNet), C.c_int, C.POINTER(NcwPoints), C.c_void_p, C.c_int64,

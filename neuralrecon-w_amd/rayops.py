@@ -102,7 +102,8 @@ class CompositeCtx:
                  inside=torch.empty(R, S, device=dev), depth=torch.empty(R, device=dev),
                  normals=torch.empty(R, 3, device=dev), eik=torch.empty(R, 2, device=dev),
                  mid_z=torch.empty(R, S, device=dev), dists=torch.empty(R, S, device=dev),
-                 bg_alpha=torch.empty(R, M, device=dev) if self.has_bg else None)
+                 bg_alpha=torch.empty(R, M, device=dev) if self.has_bg else None,
+                 weights_max=torch.empty(R, device=dev))
         s = L.NcwCompositeOut()
         for k, v in o.items():
             setattr(s, k, v.data_ptr() if v is not None else 0)
@@ -126,5 +127,4 @@ class CompositeCtx:
         lib = L.get_lib()
         L.check(lib.ncw_composite_bwd(self.cin, s, L.stream_ptr(dev)), "ncw_composite_bwd")
         self._keep = ups
-        g["d_inv_s"] = g["d_inv_s"].sum().reshape(1)  # per-ray terms -> scalar (torch's reduction order is fixed)
-        return g
+        return g  # d_inv_s: per-ray terms [R]; the caller reduces them in a fixed order (ncw_inv_s_bwd / .sum())

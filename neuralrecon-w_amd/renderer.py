@@ -36,7 +36,10 @@ class _RenderFn(torch.autograd.Function):
         R, S = z.shape
         dev = z.device
         ctx.set_materialize_grads(False)  # outputs the loss does not use arrive as None, not as freshly filled zeros
-        inv_s = torch.exp(variance.detach() * 10.0).clamp(1e-6, 1e6).reshape(1).float()
+        inv_s = torch.empty(1, device=dev, dtype=torch.float32)   # clamp(exp(10 variance), 1e-6, 1e6): one launch
+        s_val = torch.empty(1, device=dev, dtype=torch.float32)
+        L.check(L.get_lib().ncw_inv_s_fwd(L.ptr(variance.detach().reshape(1).float().contiguous()), L.ptr(inv_s), L.ptr(s_val),
+                                          L.stream_ptr(dev)), "ncw_inv_s_fwd")
         a_det = a_embedded.detach().contiguous().float()
         use_bg = rdr.render_bg and rdr.n_outside > 0 and z_out is not None
         z_feed = density = bg_rgb = nctx = None
@@ -60,7 +63,8 @@ class _RenderFn(torch.autograd.Function):
         ctx.variance = variance
         ctx.params = params
         extras = (o["color_sphere"], o["color_bg"], o["weights"], o["cdf"], o["inside"], o["normals"],
-                  sdf.view(R, S), grad.view(R, S, 3), o["mid_z"], o["dists"], o["eik"][:, 1].contiguous(), inv_s)
+                  sdf.view(R, S), grad.view(R, S, 3), o["mid_z"], o["dists"], o["eik"][:, 1].contiguous(), inv_s, s_val,
+                  o["weights_max"])
         ctx.mark_non_differentiable(*extras)
         # the leases live exactly as long as this autograd node: returned by backward(), or when the node is dropped
         ctx.guard = LeaseGuard([c["lease"] for c in (sctx, cctx, nctx) if c is not None])
@@ -144,11 +148,9 @@ class _RenderFn(torch.autograd.Function):
                 off += p.numel()
             keep = [pl.unpack_grads(tviews) for pl in plans]
         ctx._keep = (keep, batch)
-        inv_s = ctx.inv_s
-        live = ((inv_s > 1e-6) & (inv_s < 1e6)).float()
-        d_var = (g["d_inv_s"] * 10.0 * inv_s * live).reshape(ctx.variance.shape)
-        if not ctx.use_bg:  # background parameters were passed but unused
-            pass
+        d_var = torch.empty(1, device=dev, dtype=torch.float32)  # 10 inv_s [clamp inactive] sum_r d_inv_s[r], fixed order
+        L.check(lib.ncw_inv_s_bwd(L.ptr(g["d_inv_s"]), R, L.ptr(ctx.inv_s), L.ptr(d_var), L.stream_ptr(dev)), "ncw_inv_s_bwd")
+        d_var = d_var.reshape(ctx.variance.shape)
         ctx.guard.release()
         return (None, None, None, None, None, None, None, None, d_a, d_var) + tuple(out)
 
@@ -158,19 +160,21 @@ class _EmbedFn(torch.autograd.Function):
     ~3 us) instead of torch's embedding_dense_backward (77 us for 1024 rays: it serialises repeated indices)."""
 
     @staticmethod
-    def forward(ctx, weight, ts):
+    def forward(ctx, weight, ts, direct_grad):
         ctx.save_for_backward(ts)
-        ctx.shape = weight.shape
+        ctx.shape, ctx.direct_grad = weight.shape, direct_grad
         return weight.detach().index_select(0, ts)
 
     @staticmethod
     def backward(ctx, d_a):
         (ts,) = ctx.saved_tensors
         d_a = d_a.contiguous().float()
-        dw = torch.zeros(ctx.shape, device=d_a.device, dtype=torch.float32)
+        # direct_grad: the weight's .grad inside a trainer's flat gradient buffer (already zeroed by FlatParams.zero_grad):
+        # accumulate straight into it -- no 960 KB zero fill + add_ through AccumulateGrad
+        dw = ctx.direct_grad if ctx.direct_grad is not None else torch.zeros(ctx.shape, device=d_a.device, dtype=torch.float32)
         L.check(L.get_lib().ncw_scatter_add_rows(L.ptr(d_a), L.ptr(ts), d_a.shape[0], d_a.shape[1], dw.shape[0], L.ptr(dw),
                                                  L.stream_ptr(d_a.device)), "ncw_scatter_add_rows")
-        return dw, None
+        return (None if ctx.direct_grad is not None else dw), None, None
 
 
 class _RayTailFn(torch.autograd.Function):
@@ -380,23 +384,26 @@ class NeuconWRenderer:
         if self.origin.device != device:
             self.origin = self.origin.to(device).float()
             self.sfm_to_gt = self.sfm_to_gt.to(device).float()
-        rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
-        near, far = rays[:, 6:7], rays[:, 7:8]
-        if rays.size(1) >= 10:
-            depth_gt, depth_weight = rays[:, 8], rays[:, 9]
-        else:
-            depth_gt = depth_weight = torch.zeros_like(near).squeeze(-1)
-        rays_o = ((rays_o - self.origin).float() / self.radius).float().contiguous()
-        rays_d = rays_d.float().contiguous()
-        near = (near / self.radius).float()
-        far = (far / self.radius).float()
-        depth_gt = (depth_gt / self.radius).float()
+        # renderer.py:793-806 (ray normalisation into unit-sphere units) as one launch
+        R = rays.shape[0]
+        rays_c = rays.contiguous().float()
+        rays_o, rays_d = torch.empty(R, 3, device=device), torch.empty(R, 3, device=device)
+        near, far = torch.empty(R, 1, device=device), torch.empty(R, 1, device=device)
+        depth_gt, depth_weight = torch.empty(R, device=device), torch.empty(R, device=device)
+        if self.__dict__.get("_origin_host") is None or self._origin_host[1] is not self.origin:
+            self._origin_host = ((C.c_float * 3)(*[float(v) for v in self.origin.reshape(-1).tolist()]), self.origin)
+        L.check(L.get_lib().ncw_ray_prologue(L.ptr(rays_c), rays_c.shape[1], R, self._origin_host[0], float(self.radius),
+                                             L.ptr(rays_o), L.ptr(rays_d), L.ptr(near), L.ptr(far), L.ptr(depth_gt),
+                                             L.ptr(depth_weight), L.stream_ptr(device)), "ncw_ray_prologue")
         emb_a = self.embeddings["a"]
         ordered = self.reproducible if self.reproducible is not None else (self.prec == L.PREC_F32)
         if (not ordered and isinstance(emb_a, torch.nn.Embedding) and emb_a.padding_idx is None and emb_a.max_norm is None
                 and not emb_a.sparse and emb_a.weight.dtype == torch.float32 and torch.is_grad_enabled()
                 and emb_a.weight.requires_grad and ts.dtype == torch.int64 and ts.dim() == 1):
-            a_embedded = _EmbedFn.apply(emb_a.weight, ts.contiguous())
+            g = emb_a.weight.grad
+            direct = g if (self.__dict__.get("_gv_adopted", False) and g is not None and g.is_contiguous()
+                           and g.dtype == torch.float32) else None
+            a_embedded = _EmbedFn.apply(emb_a.weight, ts.contiguous(), direct)
         else:  # fp32 / reproducible mode, or an unusual embedding: torch's own (deterministic) lookup + backward
             a_embedded = emb_a(ts)
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
@@ -411,7 +418,7 @@ class NeuconWRenderer:
                                cos_anneal_ratio if torch.is_tensor(cos_anneal_ratio) else float(cos_anneal_ratio), bgc,
                                a_embedded, self.neuconw.deviation_network.variance, *self._params())
         (color, wsum, depth, eik_num, color_sphere, color_bg, weights, cdf, inside, normals, sdf, gradients, mid_z,
-         dists, eik_den, inv_s) = outs
+         dists, eik_den, inv_s, s_val, weights_max) = outs
         weights_sum = wsum.unsqueeze(-1)
         has_mask = self.mesh_mask_list is not None
         dense_depth = bool(self.depth_loss and self.sync_free)
@@ -430,9 +437,9 @@ class NeuconWRenderer:
         else:
             sfm_depth_loss = torch.zeros_like(depth)
         return {
-            "color": color, "color_sphere": color_sphere, "color_bg": color_bg, "s_val": (1.0 / inv_s).reshape(1, 1),
+            "color": color, "color_sphere": color_sphere, "color_bg": color_bg, "s_val": s_val.reshape(1, 1),
             "cdf_fine": cdf, "gradients": gradients, "mask_error": mask_error, "weights": weights,
-            "weights_sum": weights_sum, "weights_max": torch.max(weights, dim=-1, keepdim=True)[0],
+            "weights_sum": weights_sum, "weights_max": weights_max.unsqueeze(-1),
             "gradient_error": gradient_error, "inside_sphere": inside,
             "depth": depth, "floor_normal_error": (zn := torch.zeros_like(normals)), "floor_y_error": zn,
             "sfm_depth_loss": sfm_depth_loss,

@@ -80,7 +80,7 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
         e = float((params[k].grad.cpu().double() - g.double()).abs().max()) / scale[net_of(k)]
         worst = max(worst, e)
         assert e < tol_grad, (k, e)
-    print("W=%d %s: loss %.6f vs %.6f, worst param-grad err / network max-grad %.2e" % (W, prec_name, float(loss),
+    print("W=%d %s: loss %.6f vs %.6f, worst param-grad err / network max-grad %.2e" % (W, prec_name, float(loss.detach()),
                                                                                        float(lref), worst))
 
 

@@ -142,6 +142,7 @@ def test_composite_fwd_bwd_vs_oracle(S, O_, with_bg, brgb):
     got = ctx.backward(*_cu(dc, dw, dd, de))
     m = {"sdf": "d_sdf", "grad": "d_grad", "rgb": "d_rgb", "inv_s": "d_inv_s", "density": "d_density",
          "bg_rgb": "d_bg_rgb"}
+    got["d_inv_s"] = got["d_inv_s"].sum().reshape(1)  # per-ray terms: the caller reduces them (ncw_inv_s_bwd in the renderer)
     for k in names:
         e = rel_err(got[m[k]].cpu().reshape(gref[k].shape), gref[k])
         assert e < 1e-4, (k, e)
