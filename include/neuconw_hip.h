@@ -408,7 +408,7 @@ typedef struct NcwCompositeOut {
     float* inside;       /* [R,S] */
     float* depth;        /* [R]   */
     float* normals;      /* [R,3] */
-    float* eik;          /* [R,2] per-ray (sum relax*(|g|-1)^2, sum relax): eikonal partials */
+    float* eik;          /* [2,R] per-ray eikonal partials: row 0 = sum relax*(|g|-1)^2, row 1 = sum relax */
     float* mid_z;        /* [R,S] */
     float* dists;        /* [R,S] */
     float* bg_alpha;     /* [R,S+O] or NULL when !has_bg */

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs A, CompOut 
         if (Q.weights_max) Q.weights_max[r] = wmax;
         Q.depth[r] = depth;
         Q.normals[r * 3] = nx; Q.normals[r * 3 + 1] = ny; Q.normals[r * 3 + 2] = nz;
-        Q.eik[r * 2] = eik_num; Q.eik[r * 2 + 1] = eik_den;
+        Q.eik[r] = eik_num; Q.eik[A.R + r] = eik_den;  // [2,R]: two contiguous per-ray arrays
     }
 }
 

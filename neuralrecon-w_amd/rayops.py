@@ -100,7 +100,7 @@ class CompositeCtx:
                  color_bg=torch.empty(R, 3, device=dev), weights=torch.empty(R, M, device=dev),
                  weights_sum=torch.empty(R, device=dev), cdf=torch.empty(R, S, device=dev),
                  inside=torch.empty(R, S, device=dev), depth=torch.empty(R, device=dev),
-                 normals=torch.empty(R, 3, device=dev), eik=torch.empty(R, 2, device=dev),
+                 normals=torch.empty(R, 3, device=dev), eik=torch.empty(2, R, device=dev),
                  mid_z=torch.empty(R, S, device=dev), dists=torch.empty(R, S, device=dev),
                  bg_alpha=torch.empty(R, M, device=dev) if self.has_bg else None,
                  weights_max=torch.empty(R, device=dev))

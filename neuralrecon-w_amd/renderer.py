@@ -63,14 +63,14 @@ class _RenderFn(torch.autograd.Function):
         ctx.variance = variance
         ctx.params = params
         extras = (o["color_sphere"], o["color_bg"], o["weights"], o["cdf"], o["inside"], o["normals"],
-                  sdf.view(R, S), grad.view(R, S, 3), o["mid_z"], o["dists"], o["eik"][:, 1].contiguous(), inv_s, s_val,
+                  sdf.view(R, S), grad.view(R, S, 3), o["mid_z"], o["dists"], o["eik"][1], inv_s, s_val,
                   o["weights_max"])
         ctx.mark_non_differentiable(*extras)
         # the leases live exactly as long as this autograd node: returned by backward(), or when the node is dropped
         ctx.guard = LeaseGuard([c["lease"] for c in (sctx, cctx, nctx) if c is not None])
         if not any(ctx.needs_input_grad):  # inference: nobody will come back for the stashes
             ctx.guard.release()
-        return (o["color"], o["weights_sum"], o["depth"], o["eik"][:, 0].contiguous()) + extras
+        return (o["color"], o["weights_sum"], o["depth"], o["eik"][0]) + extras
 
     @staticmethod
     def backward(ctx, d_color, d_wsum, d_depth, d_eik, *unused):
@@ -122,8 +122,7 @@ class _RenderFn(torch.autograd.Function):
                 nerf.add_wgrads(nctx, b_bg)
                 batch.extend(b_bg)
             sctx["lease"]["wgrad_batch"] = batch
-        for p in plans:
-            p.g_arena.zero_()
+        torch._foreach_zero_([p.g_arena for p in plans])  # one multi-tensor launch for the three dense gradient arenas
         batch.run()
         # Parameter gradients.  Default: returned THROUGH autograd (AccumulateGrad runs, so DistributedDataParallel /
         # Lightning reducer hooks, torch.autograd.grad and post-accumulate hooks all see them -- the reference trains

@@ -129,8 +129,8 @@ def test_composite_fwd_bwd_vs_oracle(S, O_, with_bg, brgb):
     for k, kr in pairs:
         e = rel_err(out[k].cpu().reshape(ref[kr].shape), ref[kr])
         assert e < 2e-5, (k, e)
-    assert rel_err(out["eik"][:, 0].cpu(), ref["eik_num"]) < 2e-5
-    assert rel_err(out["eik"][:, 1].cpu(), ref["eik_den"]) < 1e-6
+    assert rel_err(out["eik"][0].cpu(), ref["eik_num"]) < 2e-5
+    assert rel_err(out["eik"][1].cpu(), ref["eik_den"]) < 1e-6
     # ---- backward ------------------------------------------------------------------------------
     g = torch.Generator().manual_seed(1)
     dc, dw, dd, de = (torch.randn(R, 3, generator=g), torch.randn(R, generator=g), torch.randn(R, generator=g),
