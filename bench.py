@@ -239,7 +239,7 @@ def bench_grid512(args, nw, L, dev, world, rank):
     dim = 512
     total = dim ** 3
     start, count, per = grid.local_range(total, rank, world)
-    prec = nw.PREC_BF16 if args.prec == "bf16" else nw.PREC_F32
+    prec = {"bf16": nw.PREC_BF16, "f16": nw.PREC_F16, "f32": nw.PREC_F32}[args.prec]
     out = torch.empty(per, device=dev, dtype=torch.float32)
     lo, hi = (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)
     chunk = 1 << 22
@@ -266,7 +266,7 @@ def bench_grid512(args, nw, L, dev, world, rank):
         dt = float(t.item())
     macs = {256: 459008, 512: 1835520}[W]
     pts_s = total * K / dt
-    peak = PEAK_BF16_TFLOPS if prec == nw.PREC_BF16 else 157.3
+    peak = PEAK_BF16_TFLOPS if prec != nw.PREC_F32 else 157.3  # fp16 MFMA peak = bf16 peak
     ach = 2.0 * macs * pts_s / 1e12
     if rank == 0:
         print(json.dumps({
@@ -289,7 +289,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--prec", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--rays", type=int, default=R_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
@@ -367,7 +367,7 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    prec = nw.PREC_BF16 if args.prec == "bf16" else nw.PREC_F32
+    prec = {"bf16": nw.PREC_BF16, "f16": nw.PREC_F16, "f32": nw.PREC_F32}[args.prec]
     R = args.rays
     bg = torch.zeros(1, 3, device=dev)
     rays, ts, label, rgbs = synth_batch(R, 1000 + rank, dev)
@@ -453,7 +453,7 @@ def main():
         dom = max((k for k in rows if fl.get(k) is not None), key=lambda k: rows[k][0])
         avg_ms = rows[dom][0] / rows[dom][1]
         ach = fl[dom] / (rows[dom][0] * 1e-3) / 1e12
-        peak = PEAK_BF16_TFLOPS if prec == nw.PREC_BF16 else 157.3
+        peak = PEAK_BF16_TFLOPS if prec != nw.PREC_F32 else 157.3  # fp16 MFMA peak = bf16 peak
         frac_mfma = ach / peak
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(frac_mfma, 4), "frac_mfma": round(frac_mfma, 4), "frac_hbm": None, "traffic": None,
@@ -468,7 +468,7 @@ def main():
             # once (algorithmic bytes = sum over products of (rbx + rby) x 32 features x elem x points); at
             # ~100 FLOP/B they sit left of the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B): HBM-bound in THIS design.
             # SURVEY 8(d) prices the MLP backward against MFMA: both fractions are reported, `frac` follows `bound`.
-            esz = 2 if prec == nw.PREC_BF16 else 4
+            esz = 2 if prec != nw.PREC_F32 else 4
             alg_bytes = 0.0
             for ent in neuconw.sdf_net.__dict__.get("_stash_cache")._e.values():
                 wb = ent.get("wgrad_batch")

@@ -15,7 +15,10 @@
  * struct; `stream` is a hipStream_t passed as void*; every function is asynchronous on `stream`
  * and returns 0 on success or a hipError_t / negative NCW_E_* code.  No torch types appear here.
  * prec: 0 = exact-fp32 MFMA (v_mfma_f32_32x32x2_f32; parity mode), 1 = bf16 MFMA with f32
- * accumulation (v_mfma_f32_32x32x16_bf16; throughput mode).
+ * accumulation (v_mfma_f32_32x32x16_bf16; throughput mode), 2 = fp16 MFMA with f32 accumulation
+ * (v_mfma_f32_32x32x16_f16: the same kernels compiled a second time with the 16-bit type switched -- 8x the mantissa
+ * of bf16 at the same speed; the library also exports every MLP entry point as <name>_f16, which is what prec 2
+ * dispatches to).  Packed weights and stashes of a network must be built with the prec they are used with.
  */
 #ifndef NEUCONW_HIP_H
 #define NEUCONW_HIP_H
@@ -27,6 +30,7 @@ extern "C" {
 
 #define NCW_PREC_F32 0
 #define NCW_PREC_BF16 1
+#define NCW_PREC_F16 2   /* fp16 operands (10 mantissa bits), f32 accumulate; the caller loss-scales the backward */
 #define NCW_MAX_LAYERS 12
 #define NCW_MAX_SEGS 4
 
@@ -86,6 +90,7 @@ typedef struct NcwUnpackDesc {
     int32_t ld, ldw;
     int32_t row0, nrows, drow0;
     float scale;
+    float grad_mul;      /* multiplies every gradient written (0 = 1): 1 / loss scale in the fp16 mode */
     int32_t accumulate;  /* 1: add into d_* (torch .grad accumulation), 0: overwrite     */
     int32_t nseg;
     NcwSeg seg[NCW_MAX_SEGS];
@@ -321,6 +326,9 @@ int ncw_wgrad_ordered(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n
  * networks and sizes share ONE launch with a work-proportional split. */
 int ncw_wgrad_tiled(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
                     int tile, int64_t n_points, void* stream);
+/* the same for fp16 stashes (prec NCW_PREC_F16; ncw_wgrad / ncw_wgrad_ordered take it through `prec`) */
+int ncw_wgrad_tiled_f16(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
+                        int tile, int64_t n_points, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser step over flat fp32 buffers (16-byte aligned): global-norm clip + Adam in one launch.
@@ -330,7 +338,8 @@ int ncw_wgrad_tiled(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_d
  *   m += (1-beta1)(g - m);  v = beta2 v + (1-beta2) g g;
  *   p -= step_size * m / (sqrt(v) / bias_correction2_sqrt + eps)
  * with step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t) computed by the caller.
- * total_norm: DEVICE scalar (the 2-norm of grad) or NULL for no clipping.
+ * total_norm: DEVICE scalar (the 2-norm of grad) or NULL for no clipping.  A non-finite total_norm skips the step
+ * (nothing is written): one overflowed fp16 step must not poison the parameters and the moments.
  * ---------------------------------------------------------------------------------------- */
 int ncw_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float step_size,
                   float beta1, float beta2, float eps, float bias_correction2_sqrt, const float* total_norm,
@@ -426,6 +435,9 @@ typedef struct NcwCompositeGrad {
     float* d_density;  /* [R,S+O]   */
     float* d_bg_rgb;   /* [R,S+O,3] */
     float* d_inv_s;    /* [R]: every ray's term of d loss / d inv_s; the caller sums them (order-fixed) */
+    float grad_scale;  /* multiplies every upstream cotangent on load (0 = 1): the fp16 mode's loss scale, so that the
+                        * per-point adjoints the MLP backward kernels round to fp16 stay in its normal range; the caller
+                        * divides it back out of the parameter gradients (NcwUnpackDesc.scale), d_a and d_inv_s */
 } NcwCompositeGrad;
 
 int ncw_composite_fwd(const NcwCompositeIn* in, const NcwCompositeOut* out, void* stream);

@@ -6,7 +6,7 @@ libneuconw_hip.so (hand-written HIP, C ABI in include/neuconw_hip.h).
 """
 from . import lib  # noqa: F401
 from . import mesh  # noqa: F401
-from .lib import PREC_BF16, PREC_F32, NeuconwHipError  # noqa: F401
+from .lib import PREC_BF16, PREC_F16, PREC_F32, NeuconwHipError  # noqa: F401
 from .nerf import NeRF  # noqa: F401
 from .neuconw import NeuconW, RenderingNetwork, SDFNetwork, SingleVarianceNetwork  # noqa: F401
 from .renderer import NeuconWRenderer  # noqa: F401

@@ -28,8 +28,15 @@ if "NCW_MLP_FLAGS" in os.environ:  # A/B builds (scripts/): e.g. NCW_MLP_FLAGS="
     MLP_FLAGS = os.environ["NCW_MLP_FLAGS"].split()
 
 
+# The fp16 mode (NCW_PREC_F16) is the SAME source compiled a second time with the 16-bit type switched (ncw_common.h:
+# ncw_h16 = _Float16, the f16 MFMA, entry points suffixed _f16, kernels in their own namespace); the bf16 objects'
+# entry points forward prec == NCW_PREC_F16 to them.
+F16_FILES = ["ncw_sdf.hip", "ncw_sdf8.hip", "ncw_pp.hip", "ncw_color.hip", "ncw_nerf.hip", "ncw_wgrad.hip"]
+
+
 def _sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return [(f, False) for f in srcs] + [(f, True) for f in F16_FILES]
 
 
 def _deps_mtime():
@@ -38,15 +45,17 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, src[:-4] + ".o")
+def _compile(job):
+    src, f16 = job
+    obj = os.path.join(OBJ, src[:-4] + ("_f16.o" if f16 else ".o"))
     srcp = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), _deps_mtime()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + (MLP_FLAGS if src in MLP_FILES else []) + ["-c", srcp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + (MLP_FLAGS if src in MLP_FILES else []) + (["-DNCW_HALF_F16"] if f16 else [])
+    cmd += ["-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        raise RuntimeError("hipcc failed for %s%s:\n%s\n%s" % (src, " (f16)" if f16 else "", r.stdout, r.stderr))
     return obj, True
 
 
@@ -56,7 +65,7 @@ def build(verbose=True, force=False):
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
     srcs = _sources()
-    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 8, len(srcs))) as ex:
         res = list(ex.map(_compile, srcs))
     objs = [o for o, _ in res]
     rebuilt = any(c for _, c in res)

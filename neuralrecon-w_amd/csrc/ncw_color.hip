@@ -5,6 +5,8 @@
 #include "ncw_mlp.h"
 
 
+namespace NCW_NS {
+
 // AUX2 (1 block): [points (3) | normals (3) | 0...]   (neuconw.py:147-148)
 NCW_DEV void build_aux2(CVec<1>& aux, const float (&x)[3], const float (&nrm)[3], int lane) {
     const int h = lane >> 5;
@@ -223,6 +225,9 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
     }
 }
 
+}  // namespace NCW_NS
+using namespace NCW_NS;
+
 static bool color_ok(const NcwColorNet* net) {
     return net && net->n_head >= 1 && net->n_head <= 4 && net->n_lin >= 2 && net->n_lin <= 8 && net->n_a >= 0 &&
            net->n_a <= 69;
@@ -246,9 +251,17 @@ static bool color_ok(const NcwColorNet* net) {
         }                                                                                                        \
     } while (0)
 
-extern "C" int ncw_color_fwd(const NcwColorNet* net, int prec, const NcwPoints* pts, int64_t n, const float* normals,
-                             const float* a, const void* feat_stash, float* rgb, const NcwColorStash* stash,
-                             void* stream) {
+#ifndef NCW_HALF_F16
+extern "C" int ncw_color_fwd_f16(const NcwColorNet*, int, const NcwPoints*, int64_t, const float*, const float*, const void*, float*,
+                                 const NcwColorStash*, void*);
+extern "C" int ncw_color_bwd_f16(const NcwColorNet*, int, const NcwPoints*, int64_t, const float*, const float*, float*, float*, float*,
+                                 void*, const NcwColorStash*, void*);
+#endif
+
+extern "C" int NCW_FN(ncw_color_fwd)(const NcwColorNet* net, int prec, const NcwPoints* pts, int64_t n, const float* normals,
+                                     const float* a, const void* feat_stash, float* rgb, const NcwColorStash* stash,
+                                     void* stream) {
+    NCW_FORWARD_F16(prec, ncw_color_fwd_f16(net, NCW_PREC_BF16, pts, n, normals, a, feat_stash, rgb, stash, stream));
     if (!color_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -256,9 +269,10 @@ extern "C" int ncw_color_fwd(const NcwColorNet* net, int prec, const NcwPoints* 
     return 0;
 }
 
-extern "C" int ncw_color_bwd(const NcwColorNet* net, int prec, const NcwPoints* pts, int64_t n, const float* rgb,
-                             const float* d_rgb, float* d_grad, float* d_a, float* d_a_rows, void* dfeat_stash,
-                             const NcwColorStash* stash, void* stream) {
+extern "C" int NCW_FN(ncw_color_bwd)(const NcwColorNet* net, int prec, const NcwPoints* pts, int64_t n, const float* rgb,
+                                     const float* d_rgb, float* d_grad, float* d_a, float* d_a_rows, void* dfeat_stash,
+                                     const NcwColorStash* stash, void* stream) {
+    NCW_FORWARD_F16(prec, ncw_color_bwd_f16(net, NCW_PREC_BF16, pts, n, rgb, d_rgb, d_grad, d_a, d_a_rows, dfeat_stash, stash, stream));
     if (!color_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;

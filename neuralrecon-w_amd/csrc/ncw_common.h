@@ -25,13 +25,37 @@
 #include <stdint.h>
 #include <type_traits>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// The 16-bit element type.  Every fused-MLP / weight-gradient source file is compiled TWICE (build.py): once with
+// ncw_h16 = __bf16 (prec NCW_PREC_BF16) and once with -DNCW_HALF_F16, ncw_h16 = _Float16 (prec NCW_PREC_F16: 10 mantissa
+// bits instead of 7 at the same MFMA rate; the backward's cotangents are loss-scaled by the host, see renderer.py).
+// In the second compilation every entry point and cross-file helper carries the suffix _f16 (NCW_FN) and the kernels live
+// in their own namespace (NCW_NS); the bf16 build's entry points forward prec == NCW_PREC_F16 calls to them.
+// (`bf16x8` / `bf16x4` / PrecBF16 keep their names: "the 16-bit fragment / precision".)
+#ifdef NCW_HALF_F16
+typedef _Float16 ncw_h16;
+#define NCW_MFMA_H __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define NCW_FN(name) name##_f16
+#define NCW_NS ncw_h_f16
+#else
+typedef __bf16 ncw_h16;
+#define NCW_MFMA_H __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define NCW_FN(name) name
+#define NCW_NS ncw_h_bf16
+#endif
+typedef ncw_h16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef ncw_h16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define NCW_PREC_F32 0
 #define NCW_PREC_BF16 1
+#define NCW_PREC_F16 2   // forwarded to the _f16 build of the same entry point (which sees it as its 16-bit precision)
+// bf16 build only: hand a prec == NCW_PREC_F16 call to the fp16 build of this entry point
+#ifdef NCW_HALF_F16
+#define NCW_FORWARD_F16(prec, call) do {} while (0)
+#else
+#define NCW_FORWARD_F16(prec, call) do { if ((prec) == NCW_PREC_F16) return call; } while (0)
+#endif
 
 #define NCW_DEV __device__ __forceinline__
 #define NCW_HD __host__ __device__ __forceinline__
@@ -53,8 +77,8 @@ struct PrecF32 {
 };
 struct PrecBF16 {
     static constexpr int id = NCW_PREC_BF16;
-    typedef __bf16 welem;
-    typedef __bf16 selem;
+    typedef ncw_h16 welem;
+    typedef ncw_h16 selem;
     // 2 k-steps * 64 lanes * 8
     static constexpr int W_PER_INBLOCK = 2 * 64 * 8;
 };
@@ -99,7 +123,7 @@ NCW_DEV void to_act(Act<PrecBF16, RB>& a, const CVec<RB>& c) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a.f[2 * i + t][e] = (__bf16)c.v[i][8 * t + e];
+            for (int e = 0; e < 8; ++e) a.f[2 * i + t][e] = (ncw_h16)c.v[i][8 * t + e];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -126,7 +150,7 @@ NCW_DEV void mma(CVec<RB_OUT>& acc, const Act<PrecF32, RB_IN>& in, const float* 
     }
 }
 template <int RB_IN, int RB_OUT, int K_REAL, int RB_STRIDE = RB_OUT>
-NCW_DEV void mma(CVec<RB_OUT>& acc, const Act<PrecBF16, RB_IN>& in, const __bf16* __restrict__ wp, int lane) {
+NCW_DEV void mma(CVec<RB_OUT>& acc, const Act<PrecBF16, RB_IN>& in, const ncw_h16* __restrict__ wp, int lane) {
 #pragma unroll
     for (int s = 0; s < 2 * RB_IN; ++s) {
         if (16 * s >= K_REAL) continue;
@@ -134,7 +158,7 @@ NCW_DEV void mma(CVec<RB_OUT>& acc, const Act<PrecBF16, RB_IN>& in, const __bf16
 #pragma unroll
         for (int ro = 0; ro < RB_OUT; ++ro) {
             bf16x8 a = w[ro * 64];
-            acc.v[ro] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, in.f[s], acc.v[ro], 0, 0, 0);
+            acc.v[ro] = NCW_MFMA_H(a, in.f[s], acc.v[ro], 0, 0, 0);
         }
     }
 }
@@ -216,7 +240,7 @@ NCW_DEV bf16x8 unit_b(const Act<PrecBF16, RB_IN>& in, int rb, int sub) { return 
 
 NCW_DEV f32x16 unit_mfma(float a, float b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 NCW_DEV f32x16 unit_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    return NCW_MFMA_H(a, b, c, 0, 0, 0);
 }
 
 // first feature touched by unit (rb, sub) on half 0 (the h=1 half is larger): skip test vs K_REAL
@@ -386,14 +410,16 @@ NCW_DEV void softplus100(float z, float& y, float& s) {
     return;
 #endif
     if (FAST) {
-        // bf16 kernels: y = max(z, 0) + c(|z|) with the correction c(a) = log1p(exp(-100 a)) / 100 evaluated as a
-        // degree-4 polynomial on [0, 0.06] and held constant beyond (there c < 2.5e-5): max abs error 8.4e-6 inside,
-        // <= 3.3e-5 everywhere = 1/12 of a bf16 ulp at 0.1, far below the bf16 rounding the value gets next.
-        // 7 plain VALU instead of 4 plain + 2 transcendentals: at W = 256 every MFMA produces one accumulator register
-        // per lane and these kernels are bound by VALU issue next to the MFMAs (scripts/probes/issue_probe.hip), so
-        // the epilogue's instruction count IS the kernel time.  s = 1 - exp(-100 y) (== sigmoid(100 z)) as before; it is
-        // dead code wherever Softplus' is recomputed from the stashed h.  The fp32 kernels keep the exact form below.
-#ifdef NCW_EXACT_SOFTPLUS  // A/B switch: the exact 2-transcendental form
+        // 16-bit kernels: y = max(z, 0) + log2(1 + 2^-|t|) ln2 / 100, t = 100 z log2(e), on the hardware exp2 / log2
+        // (4 plain VALU + 2 transcendentals); s = 1 - exp(-100 y) (== sigmoid(100 z)), dead code wherever Softplus' is
+        // recomputed from the stashed h.
+        // -DNCW_POLY_SOFTPLUS replaces the correction term by a degree-4 polynomial on [0, 0.06], constant beyond (7 plain
+        // VALU, max abs error 3.3e-5).  It was the default for a while: sdf_infer 7 % faster, the whole step 0.5 %.  But its
+        // constant tail (2.5e-5 instead of -> 0) puts a FLOOR of 2.5e-3 under the recomputed sigmoid of every switched-off
+        // unit, which is what bounded the accuracy of the 16-bit modes: with the exact form the fp16 mode's rendered
+        // outputs moved from 3e-3 to 1-2.4e-4 of the fp64 oracle and its parameter gradients from 6.9e-2 to 1.8e-2
+        // (tests/test_gpu_fullsize.py), bf16's outputs from 4.9e-3 to 2.3e-3.
+#ifndef NCW_POLY_SOFTPLUS
         const float t = z * 144.26950408889634f;  // 100 z log2(e)
         const float w = __builtin_amdgcn_exp2f(-__builtin_fabsf(t));
         const float l = __builtin_amdgcn_logf(1.f + w);  // log2(1 + w)
@@ -518,7 +544,7 @@ NCW_DEV void stash_store(float* __restrict__ base, size_t tile, const CVec<RB>& 
         }
 }
 template <int RB>
-NCW_DEV void stash_store(__bf16* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
+NCW_DEV void stash_store(ncw_h16* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
 #ifdef NCW_EXP_NOSTASH  // timing experiment only
     return;
 #endif
@@ -529,7 +555,7 @@ NCW_DEV void stash_store(__bf16* __restrict__ base, size_t tile, const CVec<RB>&
         for (int g = 0; g < 4; ++g) {
             bf16x4 t;
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) t[c4] = (__bf16)c.v[rb][4 * g + c4];
+            for (int c4 = 0; c4 < 4; ++c4) t[c4] = (ncw_h16)c.v[rb][4 * g + c4];
             p[(rb * 4 + g) * 64] = t;
         }
 }
@@ -546,7 +572,7 @@ NCW_DEV void stash_load(CVec<RB>& c, const float* __restrict__ base, size_t tile
         }
 }
 template <int RB>
-NCW_DEV void stash_load(CVec<RB>& c, const __bf16* __restrict__ base, size_t tile, int lane) {
+NCW_DEV void stash_load(CVec<RB>& c, const ncw_h16* __restrict__ base, size_t tile, int lane) {
     const bf16x4* p = reinterpret_cast<const bf16x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)

@@ -86,7 +86,7 @@ NCW_DEV void to_act_block(Act<PrecBF16, RB>& a, int rb, const f32x16& v) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a.f[2 * rb + t][e] = (__bf16)v[8 * t + e];
+        for (int e = 0; e < 8; ++e) a.f[2 * rb + t][e] = (ncw_h16)v[8 * t + e];
 }
 
 // act = Softplus100(acc); optionally stash y (next layer's input) and s = Softplus'

@@ -4,12 +4,14 @@
 
 #include "ncw_mlp.h"
 
-int ncw_nerf_fwd8_launch(const NcwNerfNet* net, const NcwPoints& src, const float* x4, int64_t n, const float* a, float* density,
+int NCW_FN(ncw_nerf_fwd8_launch)(const NcwNerfNet* net, const NcwPoints& src, const float* x4, int64_t n, const float* a, float* density,
                          float* rgb, const NcwNerfStash& stash, hipStream_t st);  // ncw_sdf8.hip
-int ncw_nerf_bwd8_launch(const NcwNerfNet* net, const NcwPoints& src, int64_t n, const float* d_density, const float* d_rgb,
+int NCW_FN(ncw_nerf_bwd8_launch)(const NcwNerfNet* net, const NcwPoints& src, int64_t n, const float* d_density, const float* d_rgb,
                          float* d_a, const NcwNerfStash& stash, hipStream_t st);
 
 // 4-D inverted-sphere point (renderer.py:181-186): r = clip(|p|, 1, 1e10); p4 = [p / r, 1 / r]
+namespace NCW_NS {
+
 NCW_DEV void inverted_sphere(const float (&x)[3], float (&p4)[4]) {
     float r = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
     r = fminf(fmaxf(r, 1.0f), 1e10f);
@@ -229,6 +231,9 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void nerf_bwd_kernel(NcwNerfN
     }
 }
 
+}  // namespace NCW_NS
+using namespace NCW_NS;
+
 static bool nerf_ok(const NcwNerfNet* net) {
     return net && net->D >= 2 && net->D <= 8 && net->n_head >= 1 && net->n_head <= 4 && net->n_a >= 0 &&
            net->n_a <= 69 && net->skip >= 0 && net->skip < net->D - 1;
@@ -245,8 +250,16 @@ static bool nerf_ok(const NcwNerfNet* net) {
         } else return NCW_E_UNSUPPORTED;                                                             \
     } while (0)
 
-extern "C" int ncw_nerf_fwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, const float* x4, int64_t n,
-                            const float* a, float* density, float* rgb, const NcwNerfStash* stash, void* stream) {
+#ifndef NCW_HALF_F16
+extern "C" int ncw_nerf_fwd_f16(const NcwNerfNet*, int, const NcwPoints*, const float*, int64_t, const float*, float*, float*,
+                                const NcwNerfStash*, void*);
+extern "C" int ncw_nerf_bwd_f16(const NcwNerfNet*, int, const NcwPoints*, int64_t, const float*, const float*, float*, float*,
+                                const NcwNerfStash*, void*);
+#endif
+
+extern "C" int NCW_FN(ncw_nerf_fwd)(const NcwNerfNet* net, int prec, const NcwPoints* pts, const float* x4, int64_t n,
+                                    const float* a, float* density, float* rgb, const NcwNerfStash* stash, void* stream) {
+    NCW_FORWARD_F16(prec, ncw_nerf_fwd_f16(net, NCW_PREC_BF16, pts, x4, n, a, density, rgb, stash, stream));
     if (!nerf_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -254,13 +267,14 @@ extern "C" int ncw_nerf_fwd(const NcwNerfNet* net, int prec, const NcwPoints* pt
     // NCW_NERF_FWD8=0 selects the weights-through-LDS kernel below
     static const int fwd8 = getenv("NCW_NERF_FWD8") ? atoi(getenv("NCW_NERF_FWD8")) : 1;
     if (fwd8 > 0 && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 && net->n_head <= 4)
-        return ncw_nerf_fwd8_launch(net, *pts, x4, n, a, density, rgb, *stash, st);
+        return NCW_FN(ncw_nerf_fwd8_launch)(net, *pts, x4, n, a, density, rgb, *stash, st);
     NCW_NERF_DISPATCH(nerf_fwd_kernel, *net, *pts, x4, n, a, density, rgb, *stash);
     return 0;
 }
 
-extern "C" int ncw_nerf_bwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_density,
-                            const float* d_rgb, float* d_a, float* d_a_rows, const NcwNerfStash* stash, void* stream) {
+extern "C" int NCW_FN(ncw_nerf_bwd)(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_density,
+                                    const float* d_rgb, float* d_a, float* d_a_rows, const NcwNerfStash* stash, void* stream) {
+    NCW_FORWARD_F16(prec, ncw_nerf_bwd_f16(net, NCW_PREC_BF16, pts, n, d_density, d_rgb, d_a, d_a_rows, stash, stream));
     if (!nerf_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -269,7 +283,7 @@ extern "C" int ncw_nerf_bwd(const NcwNerfNet* net, int prec, const NcwPoints* pt
     static const int bwd8 = getenv("NCW_NERF_BWD8") ? atoi(getenv("NCW_NERF_BWD8")) : 1;
     if (bwd8 > 0 && d_a_rows == nullptr && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 &&
         net->n_head <= 4)
-        return ncw_nerf_bwd8_launch(net, *pts, n, d_density, d_rgb, d_a, *stash, st);
+        return NCW_FN(ncw_nerf_bwd8_launch)(net, *pts, n, d_density, d_rgb, d_a, *stash, st);
     NCW_NERF_DISPATCH(nerf_bwd_kernel, *net, *pts, n, d_density, d_rgb, d_a, d_a_rows, *stash);
     return 0;
 }

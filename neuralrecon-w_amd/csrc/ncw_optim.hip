@@ -11,7 +11,13 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, f
                                                         float beta2, float eps, float bc2_sqrt,
                                                         const float* __restrict__ total_norm, float max_norm) {
     float coef = 1.f;
-    if (total_norm != nullptr) coef = fminf(max_norm / (total_norm[0] + 1e-6f), 1.f);  // clip_grad_norm_
+    if (total_norm != nullptr) {
+        const float tn = total_norm[0];
+        // a non-finite gradient norm (an fp16 overflow, a NaN batch) would turn every parameter and both moments into
+        // NaN through coef: the step is skipped instead -- nothing is written (the reference would not recover either)
+        if (!(tn < __builtin_inff())) return;
+        coef = fminf(max_norm / (tn + 1e-6f), 1.f);  // clip_grad_norm_
+    }
     const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
     const float w1 = 1.f - beta1, w2 = 1.f - beta2;

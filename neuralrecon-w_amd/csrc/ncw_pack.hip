@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const NcwPackDesc* __restrict
             const int k = transpose ? o_log : k_log;
             const size_t idx = packed_index(o, k, rb_out, prec);
             if (prec == NCW_PREC_F32) reinterpret_cast<float*>(dst_w)[idx] = v;
+            else if (prec == NCW_PREC_F16) reinterpret_cast<_Float16*>(dst_w)[idx] = (_Float16)v;
             else reinterpret_cast<__bf16*>(dst_w)[idx] = (__bf16)v;
         }
     }
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(256) void unpack_kernel(const NcwUnpackDesc* __rest
     const float* drow = D.dw + (size_t)(D.drow0 + i) * D.ldw;
     const float* vrow = D.src + (size_t)row * D.ld;
     float* out = D.d_src + (size_t)row * D.ld;
-    const float scale = D.scale;
+    const float gm = D.grad_mul != 0.f ? D.grad_mul : 1.0f;
+    const float scale = D.scale * gm;
     const int accumulate = D.accumulate;
     if (D.g == nullptr) {
         for (int s = 0; s < D.nseg; ++s) {
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(const NcwUnpackDesc* __rest
         if (lane == 0 && D.d_g != nullptr) D.d_g[row] = accumulate ? D.d_g[row] + gbar : gbar;
     }
     if (lane == 0 && D.d_bias != nullptr && D.db != nullptr) {
-        const float b = D.db[D.drow0 + i];
+        const float b = D.db[D.drow0 + i] * gm;
         D.d_bias[row] = accumulate ? D.d_bias[row] + b : b;
     }
 }
@@ -179,6 +181,9 @@ extern "C" int ncw_stash_from_rows(int prec, const float* rows, int64_t n, int F
     if (prec == NCW_PREC_F32)
         hipLaunchKernelGGL((stash_rows_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, (float*)stash,
                            const_cast<float*>(rows), n, F, rb);
+    else if (prec == NCW_PREC_F16)
+        hipLaunchKernelGGL((stash_rows_kernel<_Float16, false>), grid, dim3(256), 0, (hipStream_t)stream, (_Float16*)stash,
+                           const_cast<float*>(rows), n, F, rb);
     else
         hipLaunchKernelGGL((stash_rows_kernel<__bf16, false>), grid, dim3(256), 0, (hipStream_t)stream, (__bf16*)stash,
                            const_cast<float*>(rows), n, F, rb);
@@ -194,6 +199,9 @@ extern "C" int ncw_stash_to_rows(int prec, const void* stash, int64_t n, int F, 
     if (prec == NCW_PREC_F32)
         hipLaunchKernelGGL((stash_rows_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream,
                            (float*)const_cast<void*>(stash), rows, n, F, rb);
+    else if (prec == NCW_PREC_F16)
+        hipLaunchKernelGGL((stash_rows_kernel<_Float16, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                           (_Float16*)const_cast<void*>(stash), rows, n, F, rb);
     else
         hipLaunchKernelGGL((stash_rows_kernel<__bf16, true>), grid, dim3(256), 0, (hipStream_t)stream,
                            (__bf16*)const_cast<void*>(stash), rows, n, F, rb);
@@ -201,7 +209,7 @@ extern "C" int ncw_stash_to_rows(int prec, const void* stash, int64_t n, int F, 
     return 0;
 }
 
-extern "C" int ncw_abi_version(void) { return 6; }
+extern "C" int ncw_abi_version(void) { return 7; }
 
 extern "C" int ncw_device_info(char* buf, int buflen) {
     int cnt = 0;

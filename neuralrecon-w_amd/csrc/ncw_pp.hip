@@ -105,7 +105,7 @@ NCW_DEV float pp_softplus(float z) {
     return __builtin_fmaxf(z, 0.f);
 #else
     float y, s;
-    softplus100<true>(z, y, s);  // the degree-4 polynomial form of ncw_common.h
+    softplus100<true>(z, y, s);  // hardware exp2 / log2 form of ncw_common.h
     return y;
 #endif
 }
@@ -164,11 +164,11 @@ NCW_DEV void pp_segment(PPAcc<NB>& m, const f32x16 (&c_init)[NB], bf16x8 (&w)[NB
             m.v[nb][0][u] += (float)w[nb][u][0] * (float)b[u % PP_RING][0][0];
             m.v[nb][1][u] += (float)w[nb][u][1] * (float)b[u % PP_RING][1][1];
 #elif defined(PP_EXP_NOLDSR)
-            m.v[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][u], w[nb][(u + 1) & 15], u == 0 ? c_init[nb] : m.v[nb][0], 0, 0, 0);
-            m.v[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][u], w[nb][(u + 2) & 15], u == 0 ? c_init[nb] : m.v[nb][1], 0, 0, 0);
+            m.v[nb][0] = NCW_MFMA_H(w[nb][u], w[nb][(u + 1) & 15], u == 0 ? c_init[nb] : m.v[nb][0], 0, 0, 0);
+            m.v[nb][1] = NCW_MFMA_H(w[nb][u], w[nb][(u + 2) & 15], u == 0 ? c_init[nb] : m.v[nb][1], 0, 0, 0);
 #else
-            m.v[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][u], b[u % PP_RING][0], u == 0 ? c_init[nb] : m.v[nb][0], 0, 0, 0);
-            m.v[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb][u], b[u % PP_RING][1], u == 0 ? c_init[nb] : m.v[nb][1], 0, 0, 0);
+            m.v[nb][0] = NCW_MFMA_H(w[nb][u], b[u % PP_RING][0], u == 0 ? c_init[nb] : m.v[nb][0], 0, 0, 0);
+            m.v[nb][1] = NCW_MFMA_H(w[nb][u], b[u % PP_RING][1], u == 0 ? c_init[nb] : m.v[nb][1], 0, 0, 0);
 #endif
 #ifndef PP_EXP_NOW
             if (PREFETCH) w[nb][u] = pp_load_unit(wnext, u * nstride + ob0 + nb * ob_step, lane);
@@ -192,8 +192,8 @@ NCW_DEV void pp_mma_x(PPAcc<NB>& a, const bf16x8 (&wx)[NB][XU], const pp_lfrag* 
     for (int u = 0; u < XU; ++u)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            a.v[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[nb][u], xin[u * 64], a.v[nb][0], 0, 0, 0);
-            a.v[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[nb][u], xin[(XU + u) * 64], a.v[nb][1], 0, 0, 0);
+            a.v[nb][0] = NCW_MFMA_H(wx[nb][u], xin[u * 64], a.v[nb][0], 0, 0, 0);
+            a.v[nb][1] = NCW_MFMA_H(wx[nb][u], xin[(XU + u) * 64], a.v[nb][1], 0, 0, 0);
         }
 }
 
@@ -206,8 +206,8 @@ NCW_DEV void pp_epi_step(int u, const PPAcc<NB>& e, bf16x8 (&frag)[NB], pp_lfrag
     const int j = u >> 3, r = 2 * (u & 7);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        frag[nb][r & 7] = (__bf16)f(e.v[nb][j][r], nb, j, r);
-        frag[nb][(r & 7) + 1] = (__bf16)f(e.v[nb][j][r + 1], nb, j, r + 1);
+        frag[nb][r & 7] = (ncw_h16)f(e.v[nb][j][r], nb, j, r);
+        frag[nb][(r & 7) + 1] = (ncw_h16)f(e.v[nb][j][r + 1], nb, j, r + 1);
         if ((u & 3) == 3) out[(j * 16 + 2 * (ob0 + nb * ob_step) + ((u & 7) >> 2)) * 64 + lane] = frag[nb];
     }
 }
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
         load_bias(o, net.b[L - 1], lane);
         const pp_lfrag* in = abuf + ((t >> 1) * 2 + ((NL - 1) & 1)) * (PP_GRP / 16) + (t & 1) * 16 * 64 + lane;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[u], in[u * 64], o.v[0], 0, 0, 0);
+        for (int u = 0; u < 16; ++u) o.v[0] = NCW_MFMA_H(w1[u], in[u * 64], o.v[0], 0, 0, 0);
         const int64_t p = (tile0 + t) * 32 + (lane & 31);
 #if !defined(PP_EXP_TRACE) && !defined(PP_EXP_TIMELINE) && !defined(PP_EXP_TRACE2)
         if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
 
 }  // namespace
 
-int ncw_sdf_inferC_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
+int NCW_FN(ncw_sdf_inferC_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
     // NCW_PP_NB: output blocks per wave.  1 (default) = eight waves, two per SIMD; 2 = four 512-register waves: every LDS
     // fragment feeds two MFMAs and nobody competes for the issue port, but half of a 512-register wave's file is

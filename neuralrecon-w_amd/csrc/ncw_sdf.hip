@@ -19,6 +19,8 @@ NCW_DEV NcwPoints points_from_x(const float* x) {
 }
 
 // Shapes of the packed SDF matrices as seen by the weight ring (first-chunk sizes for prefetch).
+namespace NCW_NS {
+
 template <class P, int RB, int OCC = 1>
 struct SdfShapes {
     static constexpr int SLOT = RingSlot<RB, OCC>::bytes;
@@ -378,6 +380,9 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RB >= 16 ? 1 : 2)) void sdf_bwd
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+}  // namespace NCW_NS
+using namespace NCW_NS;
+
 static bool sdf_net_ok(const NcwSdfNet* net) {
     return net && net->multires == 6 && net->n_layers >= 2 && net->n_layers <= NCW_MAX_LAYERS;
 }
@@ -396,12 +401,12 @@ static bool sdf_net_ok(const NcwSdfNet* net) {
         } else return NCW_E_UNSUPPORTED;                                                                \
     } while (0)
 
-int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant);  // ncw_sdf8.hip
+int NCW_FN(ncw_sdf_infer8_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant);  // ncw_sdf8.hip
 
-int ncw_sdf_fwd8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
+int NCW_FN(ncw_sdf_fwd8_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
                         hipStream_t st);  // ncw_sdf8.hip
 
-int ncw_sdf_inferC_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);  // ncw_pp.hip
+int NCW_FN(ncw_sdf_inferC_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);  // ncw_pp.hip
 
 static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, int64_t n, float* sdf, void* stream) {
     if (!sdf_net_ok(net) || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
@@ -412,28 +417,39 @@ static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, i
     // 0 = the weights-through-LDS kernel below (0.26 ms).
     static const int variant8 = getenv("NCW_SDF_INFER8") ? atoi(getenv("NCW_SDF_INFER8")) : 3;
     if (variant8 == 3 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3 && net->n_layers <= 12)
-        return ncw_sdf_inferC_launch(net, src, n, sdf, st);
+        return NCW_FN(ncw_sdf_inferC_launch)(net, src, n, sdf, st);
     if (variant8 > 0 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
-        return ncw_sdf_infer8_launch(net, src, n, sdf, st, variant8 == 3 ? 2 : variant8);
+        return NCW_FN(ncw_sdf_infer8_launch)(net, src, n, sdf, st, variant8 == 3 ? 2 : variant8);
     NCW_SDF_DISPATCH(sdf_infer_kernel, *net, src, n, sdf);
     return 0;
 }
 
-extern "C" int ncw_sdf_infer(const NcwSdfNet* net, int prec, const float* x, int64_t n, float* sdf, void* stream) {
+#ifndef NCW_HALF_F16
+extern "C" int ncw_sdf_infer_f16(const NcwSdfNet*, int, const float*, int64_t, float*, void*);
+extern "C" int ncw_sdf_infer_points_f16(const NcwSdfNet*, int, const NcwPoints*, int64_t, float*, void*);
+extern "C" int ncw_sdf_infer_rays_f16(const NcwSdfNet*, int, const float*, const float*, const float*, int, int, float*, void*);
+extern "C" int ncw_sdf_fwd_f16(const NcwSdfNet*, int, const NcwPoints*, int64_t, float*, float*, const NcwSdfStash*, void*);
+extern "C" int ncw_sdf_bwd_f16(const NcwSdfNet*, int, const NcwPoints*, int64_t, const float*, const float*, const NcwSdfStash*, void*);
+#endif
+
+extern "C" int NCW_FN(ncw_sdf_infer)(const NcwSdfNet* net, int prec, const float* x, int64_t n, float* sdf, void* stream) {
+    NCW_FORWARD_F16(prec, ncw_sdf_infer_f16(net, NCW_PREC_BF16, x, n, sdf, stream));
     NcwPoints src = {};
     src.x = x; src.rays_o = nullptr; src.rays_d = nullptr; src.z = nullptr; src.sample_dist = nullptr;
     src.per_ray = 1; src.mode = 0;
     return sdf_infer_any(net, prec, src, n, sdf, stream);
 }
 
-extern "C" int ncw_sdf_infer_points(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t count, float* sdf,
-                                    void* stream) {
+extern "C" int NCW_FN(ncw_sdf_infer_points)(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t count, float* sdf,
+                                            void* stream) {
+    NCW_FORWARD_F16(prec, ncw_sdf_infer_points_f16(net, NCW_PREC_BF16, pts, count, sdf, stream));
     if (!pts) return NCW_E_BADARG;
     return sdf_infer_any(net, prec, *pts, count, sdf, stream);
 }
 
-extern "C" int ncw_sdf_infer_rays(const NcwSdfNet* net, int prec, const float* rays_o, const float* rays_d,
-                                  const float* z, int R, int n, float* sdf, void* stream) {
+extern "C" int NCW_FN(ncw_sdf_infer_rays)(const NcwSdfNet* net, int prec, const float* rays_o, const float* rays_d,
+                                          const float* z, int R, int n, float* sdf, void* stream) {
+    NCW_FORWARD_F16(prec, ncw_sdf_infer_rays_f16(net, NCW_PREC_BF16, rays_o, rays_d, z, R, n, sdf, stream));
     if (R < 0 || n <= 0) return NCW_E_BADARG;
     NcwPoints src = {};
     src.x = nullptr; src.rays_o = rays_o; src.rays_d = rays_d; src.z = z; src.sample_dist = nullptr;
@@ -441,8 +457,9 @@ extern "C" int ncw_sdf_infer_rays(const NcwSdfNet* net, int prec, const float* r
     return sdf_infer_any(net, prec, src, (int64_t)R * n, sdf, stream);
 }
 
-extern "C" int ncw_sdf_fwd(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t n, float* sdf, float* grad,
-                           const NcwSdfStash* stash, void* stream) {
+extern "C" int NCW_FN(ncw_sdf_fwd)(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t n, float* sdf, float* grad,
+                                   const NcwSdfStash* stash, void* stream) {
+    NCW_FORWARD_F16(prec, ncw_sdf_fwd_f16(net, NCW_PREC_BF16, pts, n, sdf, grad, stash, stream));
     if (!sdf_net_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -450,13 +467,14 @@ extern "C" int ncw_sdf_fwd(const NcwSdfNet* net, int prec, const NcwPoints* pts,
     // NCW_SDF_FWD8=0 selects the weights-through-LDS kernel below
     static const int fwd8 = getenv("NCW_SDF_FWD8") ? atoi(getenv("NCW_SDF_FWD8")) : 1;
     if (fwd8 > 0 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
-        return ncw_sdf_fwd8_launch(net, *pts, n, sdf, grad, *stash, st);
+        return NCW_FN(ncw_sdf_fwd8_launch)(net, *pts, n, sdf, grad, *stash, st);
     NCW_SDF_DISPATCH(sdf_fwd_kernel, *net, *pts, n, sdf, grad, *stash);
     return 0;
 }
 
-extern "C" int ncw_sdf_bwd(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_sdf,
-                           const float* d_grad, const NcwSdfStash* stash, void* stream) {
+extern "C" int NCW_FN(ncw_sdf_bwd)(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_sdf,
+                                   const float* d_grad, const NcwSdfStash* stash, void* stream) {
+    NCW_FORWARD_F16(prec, ncw_sdf_bwd_f16(net, NCW_PREC_BF16, pts, n, d_sdf, d_grad, stash, stream));
     if (!sdf_net_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;

@@ -20,7 +20,7 @@ namespace {
 constexpr int SB_WAVES = 8, SB_TILES = 4;
 
 // phi'(z) = 1 - exp(-100 h) from the stashed post-activation h (ncw_sdf.hip load_sprime_block)
-NCW_DEV void load_sprime_block_bf16(f32x16& sv, const __bf16* __restrict__ st_h, size_t tile, int RB, int rb, int lane) {
+NCW_DEV void load_sprime_block_bf16(f32x16& sv, const ncw_h16* __restrict__ st_h, size_t tile, int RB, int rb, int lane) {
     stash_load_block(sv, st_h, tile, RB, rb, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) sv[r] = 1.f - __builtin_amdgcn_exp2f(sv[r] * -144.26950408889634f);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_inferB_kernel(NcwSdfNet net
         for (int t = 0; t < SB_TILES; ++t) {
             f32x16 acc = bias;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[q], gbuf[(t * 3 + q) * 64 + lane], acc, 0, 0, 0);
+            for (int q = 0; q < 3; ++q) acc = NCW_MFMA_H(w0[q], gbuf[(t * 3 + q) * 64 + lane], acc, 0, 0, 0);
             Act<PrecBF16, 1> o;
             f32x16 yv;
 #pragma unroll
@@ -109,14 +109,14 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_inferB_kernel(NcwSdfNet net
             f32x16 acc0 = bias, acc1 = bias;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+                acc0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
             }
             if (skip) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[(tp * 3 + q) * 64 + lane], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[((tp + 1) * 3 + q) * 64 + lane], acc1, 0, 0, 0);
+                    acc0 = NCW_MFMA_H(wg[q], gbuf[(tp * 3 + q) * 64 + lane], acc0, 0, 0, 0);
+                    acc1 = NCW_MFMA_H(wg[q], gbuf[((tp + 1) * 3 + q) * 64 + lane], acc1, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_inferB_kernel(NcwSdfNet net
         load_bias(o, net.b[L - 1], lane);
         const sb_lfrag* in = cur ? abuf1 : abuf0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
+        for (int q = 0; q < 16; ++q) o.v[0] = NCW_MFMA_H(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
         const int64_t p = (tile0 + wave) * 32 + (lane & 31);
         if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
     }
@@ -168,7 +168,7 @@ NCW_DEV void sb_store_units(sb_lfrag* buf, int t, int ob, const f32x16& v, int l
 __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
                                                                 float* __restrict__ sdf, float* __restrict__ grad,
                                                                 NcwSdfStash st) {
-    typedef __bf16 SE;
+    typedef ncw_h16 SE;
     __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_GAM];
     sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
     sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
         for (int t = 0; t < SB_TILES; ++t) {
             f32x16 acc = bias;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[q], gbuf[(t * 3 + q) * 64 + lane], acc, 0, 0, 0);
+            for (int q = 0; q < 3; ++q) acc = NCW_MFMA_H(w0[q], gbuf[(t * 3 + q) * 64 + lane], acc, 0, 0, 0);
             f32x16 yv;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[r], y, s); yv[r] = y; }
@@ -232,14 +232,14 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
             f32x16 acc0 = bias, acc1 = bias;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+                acc0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
             }
             if (skip) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[(tp * 3 + q) * 64 + lane], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[q], gbuf[((tp + 1) * 3 + q) * 64 + lane], acc1, 0, 0, 0);
+                    acc0 = NCW_MFMA_H(wg[q], gbuf[(tp * 3 + q) * 64 + lane], acc0, 0, 0, 0);
+                    acc1 = NCW_MFMA_H(wg[q], gbuf[((tp + 1) * 3 + q) * 64 + lane], acc1, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
             f32x16 acc0 = bias, acc1 = bias;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+                acc0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
             }
             stash_store_block((SE*)st.feat, (size_t)(tile0 + tp), 8, wave, acc0, lane);
             stash_store_block((SE*)st.feat, (size_t)(tile0 + tp + 1), 8, wave, acc1, lane);
@@ -280,19 +280,19 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
             CVec<1> o;
             load_bias(o, net.b[L - 1], lane);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
+            for (int q = 0; q < 16; ++q) o.v[0] = NCW_MFMA_H(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
             const int64_t p = (tile0 + wave) * 32 + (lane & 31);
             if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
         }
         // ---- adjoint start: a_{L-2} = W_{L-1}^T e_0 (the same for every point); t_{L-2} = a * phi'(z_{L-2}) ----
         bf16x8 e0f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) e0f[e] = (__bf16)0.f;
-        e0f[0] = (__bf16)(lane < 32 ? 1.f : 0.f);
+        for (int e = 0; e < 8; ++e) e0f[e] = (ncw_h16)0.f;
+        e0f[0] = (ncw_h16)(lane < 32 ? 1.f : 0.f);
         f32x16 a0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a0[r] = 0.f;
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt1, e0f, a0, 0, 0, 0);
+        a0 = NCW_MFMA_H(wt1, e0f, a0, 0, 0, 0);
         sb_lfrag* out = cur ? abuf0 : abuf1;  // free: its readers finished before the barrier above
 #pragma unroll
         for (int t = 0; t < SB_TILES; ++t) {
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+                acc0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
         if (skip) {  // the gamma columns of the transposed skip layer: out-blocks 8, 9 (one (block, tile) job per wave)
             sb_load_slice<16>(wb, net.wt[l], 10, 8 + jb, 0, lane);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) gg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[q], in[(jt * 16 + q) * 64 + lane], gg, 0, 0, 0);
+            for (int q = 0; q < 16; ++q) gg = NCW_MFMA_H(wb[q], in[(jt * 16 + q) * 64 + lane], gg, 0, 0, 0);
             if (l - 1 >= 1) sb_load_slice<16>(wb, net.wt[l - 1], (l - 1 == net.skip_layer) ? 10 : 8, wave, 0, lane);
         }
 #pragma unroll
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
     {
         const sb_lfrag* in = cur ? abuf1 : abuf0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) gg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[q], in[(jt * 16 + q) * 64 + lane], gg, 0, 0, 0);
+        for (int q = 0; q < 16; ++q) gg = NCW_MFMA_H(wb[q], in[(jt * 16 + q) * 64 + lane], gg, 0, 0, 0);
     }
     int64_t p = (tile0 + jt) * 32 + (lane & 31), ray;
     const bool valid = p < n;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
                                                                  int64_t n, const float* __restrict__ a,
                                                                  float* __restrict__ density, float* __restrict__ rgb,
                                                                  NcwNerfStash st) {
-    typedef __bf16 SE;
+    typedef ncw_h16 SE;
     __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_X];
     sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
     sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
         for (int t = 0; t < SB_TILES; ++t) {
             f32x16 acc = bias;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[q], xbuf[(t * 6 + q) * 64 + lane], acc, 0, 0, 0);
+            for (int q = 0; q < 6; ++q) acc = NCW_MFMA_H(w0[q], xbuf[(t * 6 + q) * 64 + lane], acc, 0, 0, 0);
             const f32x16 y = relu16(acc);
             stash_store_block((SE*)st.h[1], (size_t)(tile0 + t), 8, wave, y, lane);
             sb_store_units(abuf0, t, wave, y, lane);
@@ -493,14 +493,14 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
             f32x16 acc0 = bias, acc1 = bias;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+                acc0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
             }
             if (skip) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], xbuf[(tp * 6 + q) * 64 + lane], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], xbuf[((tp + 1) * 6 + q) * 64 + lane], acc1, 0, 0, 0);
+                    acc0 = NCW_MFMA_H(wx[q], xbuf[(tp * 6 + q) * 64 + lane], acc0, 0, 0, 0);
+                    acc1 = NCW_MFMA_H(wx[q], xbuf[((tp + 1) * 6 + q) * 64 + lane], acc1, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
             CVec<1> o;
             load_bias(o, net.b_alpha, lane);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
+            for (int q = 0; q < 16; ++q) o.v[0] = NCW_MFMA_H(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
             if (pvalid && lane < 32) density[pp] = o.v[0][0];
         }
 #pragma unroll
@@ -545,8 +545,8 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
             f32x16 acc0 = bias, acc1 = bias;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+                acc0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
             }
             stash_store_block((SE*)st.featn, (size_t)(tile0 + tp), 8, wave, acc0, lane);
             stash_store_block((SE*)st.featn, (size_t)(tile0 + tp + 1), 8, wave, acc1, lane);
@@ -570,19 +570,19 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
         if (i == 0) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(ta * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tb * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+                acc0 = NCW_MFMA_H(wa[q], in[(ta * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wa[q], in[(tb * 16 + q) * 64 + lane], acc1, 0, 0, 0);
             }
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], xbuf[(ta * 6 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[q], xbuf[(tb * 6 + q) * 64 + lane], acc1, 0, 0, 0);
+                acc0 = NCW_MFMA_H(wx[q], xbuf[(ta * 6 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wx[q], xbuf[(tb * 6 + q) * 64 + lane], acc1, 0, 0, 0);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(ta * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tb * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+                acc0 = NCW_MFMA_H(wa[q], in[(ta * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wa[q], in[(tb * 16 + q) * 64 + lane], acc1, 0, 0, 0);
             }
         }
         const f32x16 y0 = relu16(acc0), y1 = relu16(acc1);
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
         CVec<1> o;
         load_bias(o, net.b_rgb, lane);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
+        for (int q = 0; q < 8; ++q) o.v[0] = NCW_MFMA_H(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
         if (pvalid && lane < 32) {
             rgb[pp * 3 + 0] = o.v[0][0];
             rgb[pp * 3 + 1] = o.v[0][1];
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
 // nerf_bwd_kernel (ncw_nerf.hip) -- rgb head reversed, appearance head, feature / density, trunk -- emitting the
 // z-bar stashes the weight-gradient GEMMs read and the per-ray appearance-code gradient d_a.
 // ------------------------------------------------------------------------------------------------
-NCW_DEV f32x16 sb_relu_bwd(const f32x16& u, const __bf16* __restrict__ st_y, size_t tile, int RB, int rb, int lane) {
+NCW_DEV f32x16 sb_relu_bwd(const f32x16& u, const ncw_h16* __restrict__ st_y, size_t tile, int RB, int rb, int lane) {
     f32x16 y, z;
     stash_load_block(y, st_y, tile, RB, rb, lane);
 #pragma unroll
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
                                                                  const float* __restrict__ d_density,
                                                                  const float* __restrict__ d_rgb, float* __restrict__ d_a,
                                                                  NcwNerfStash st) {
-    typedef __bf16 SE;
+    typedef ncw_h16 SE;
     __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_X];
     sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
     sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
@@ -695,8 +695,8 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
         if (NH > 1) sb_load_slice<8>(wa, net.wt_a[NH - 1], 4, hb, 0, lane);
         else sb_load_slice<8>(wa, net.wt_a[0], 11, wave, 0, lane);
         __syncthreads();  // d_rgb / d_density units visible
-        ue0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr, xbuf[(ta * 6 + 0) * 64 + lane], zero16, 0, 0, 0);
-        ue1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr, xbuf[(tb * 6 + 0) * 64 + lane], zero16, 0, 0, 0);
+        ue0 = NCW_MFMA_H(wr, xbuf[(ta * 6 + 0) * 64 + lane], zero16, 0, 0, 0);
+        ue1 = NCW_MFMA_H(wr, xbuf[(tb * 6 + 0) * 64 + lane], zero16, 0, 0, 0);
     }
     for (int i = NH - 1; i >= 1; --i) {
         sb_lfrag* out = cur ? abuf1 : abuf0;
@@ -712,8 +712,8 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
         ue0 = zero16; ue1 = zero16;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            ue0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], out[(ta * 16 + q) * 64 + lane], ue0, 0, 0, 0);
-            ue1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], out[(tb * 16 + q) * 64 + lane], ue1, 0, 0, 0);
+            ue0 = NCW_MFMA_H(wa[q], out[(ta * 16 + q) * 64 + lane], ue0, 0, 0, 0);
+            ue1 = NCW_MFMA_H(wa[q], out[(tb * 16 + q) * 64 + lane], ue1, 0, 0, 0);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) wa[q] = wb[q];
@@ -737,8 +737,8 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
             f32x16 a0 = zero16, a1 = zero16;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], a1, 0, 0, 0);
+                a0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], a0, 0, 0, 0);
+                a1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], a1, 0, 0, 0);
             }
             stash_store_block((SE*)st.zfeat, (size_t)(tile0 + tp), 8, wave, a0, lane);
             stash_store_block((SE*)st.zfeat, (size_t)(tile0 + tp + 1), 8, wave, a1, lane);
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
             sb_load_slice<8>(wq, net.wt_a[0], 11, 8 + b, 0, lane);
             f32x16 qa = zero16;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) qa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[q], in[(t * 16 + q) * 64 + lane], qa, 0, 0, 0);
+            for (int q = 0; q < 8; ++q) qa = NCW_MFMA_H(wq[q], in[(t * 16 + q) * 64 + lane], qa, 0, 0, 0);
             int64_t p = (tile0 + t) * 32 + (lane & 31);
             const bool valid = p < n;
             if (!valid) p = n - 1;
@@ -775,11 +775,11 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
             f32x16 u0 = zero16, u1 = zero16;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], u0, 0, 0, 0);
-                u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], u1, 0, 0, 0);
+                u0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], u0, 0, 0, 0);
+                u1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], u1, 0, 0, 0);
             }
-            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wal, xbuf[(tp * 6 + 1) * 64 + lane], u0, 0, 0, 0);
-            u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wal, xbuf[((tp + 1) * 6 + 1) * 64 + lane], u1, 0, 0, 0);
+            u0 = NCW_MFMA_H(wal, xbuf[(tp * 6 + 1) * 64 + lane], u0, 0, 0, 0);
+            u1 = NCW_MFMA_H(wal, xbuf[((tp + 1) * 6 + 1) * 64 + lane], u1, 0, 0, 0);
             const f32x16 z0 = sb_relu_bwd(u0, (const SE*)st.h[D], (size_t)(tile0 + tp), 8, wave, lane);
             const f32x16 z1 = sb_relu_bwd(u1, (const SE*)st.h[D], (size_t)(tile0 + tp + 1), 8, wave, lane);
             stash_store_block((SE*)st.zp[D - 1], (size_t)(tile0 + tp), 8, wave, z0, lane);
@@ -802,8 +802,8 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
             f32x16 u0 = zero16, u1 = zero16;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[(tp * 16 + q) * 64 + lane], u0, 0, 0, 0);
-                u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], u1, 0, 0, 0);
+                u0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], u0, 0, 0, 0);
+                u1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], u1, 0, 0, 0);
             }
             const f32x16 z0 = sb_relu_bwd(u0, (const SE*)st.h[i], (size_t)(tile0 + tp), 8, wave, lane);
             const f32x16 z1 = sb_relu_bwd(u1, (const SE*)st.h[i], (size_t)(tile0 + tp + 1), 8, wave, lane);
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
 
 }  // namespace
 
-int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant) {
+int NCW_FN(ncw_sdf_infer8_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant) {
     const int64_t tiles = (n + 31) / 32;
     (void)variant;
     hipLaunchKernelGGL(sdf_inferB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st,
@@ -832,7 +832,7 @@ int ncw_sdf_infer8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n,
     return 0;
 }
 
-int ncw_sdf_fwd8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
+int NCW_FN(ncw_sdf_fwd8_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
                         hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
     hipLaunchKernelGGL(sdf_fwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src,
@@ -841,7 +841,7 @@ int ncw_sdf_fwd8_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, f
     return 0;
 }
 
-int ncw_nerf_fwd8_launch(const NcwNerfNet* net, const NcwPoints& src, const float* x4, int64_t n, const float* a, float* density,
+int NCW_FN(ncw_nerf_fwd8_launch)(const NcwNerfNet* net, const NcwPoints& src, const float* x4, int64_t n, const float* a, float* density,
                          float* rgb, const NcwNerfStash& stash, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
     hipLaunchKernelGGL(nerf_fwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src,
@@ -850,7 +850,7 @@ int ncw_nerf_fwd8_launch(const NcwNerfNet* net, const NcwPoints& src, const floa
     return 0;
 }
 
-int ncw_nerf_bwd8_launch(const NcwNerfNet* net, const NcwPoints& src, int64_t n, const float* d_density, const float* d_rgb,
+int NCW_FN(ncw_nerf_bwd8_launch)(const NcwNerfNet* net, const NcwPoints& src, int64_t n, const float* d_density, const float* d_rgb,
                          float* d_a, const NcwNerfStash& stash, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
     hipLaunchKernelGGL(nerf_bwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src, n,

@@ -13,6 +13,8 @@
 // t_l qbar_l^T of SURVEY 8a-2.
 #include "ncw_mlp.h"
 
+namespace NCW_NS {
+
 template <class P> struct WgT;
 template <> struct WgT<PrecBF16> {
     static constexpr int CH = 64;       // points per chunk
@@ -116,10 +118,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const NcwWgradDesc* __restri
                     bf16x8 a1 = a0, b1 = b0;
                     if (act_i1) a1 = *reinterpret_cast<const bf16x8*>(&XT[((2 * wi + 1) * 32 + fi) * LDT + ko]);
                     if (act_j1) b1 = *reinterpret_cast<const bf16x8*>(&YT[((2 * wj + 1) * 32 + fi) * LDT + ko]);
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                    if (act_j1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                    if (act_i1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                    if (act_i1 && act_j1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+                    acc[0][0] = NCW_MFMA_H(a0, b0, acc[0][0], 0, 0, 0);
+                    if (act_j1) acc[0][1] = NCW_MFMA_H(a0, b1, acc[0][1], 0, 0, 0);
+                    if (act_i1) acc[1][0] = NCW_MFMA_H(a1, b0, acc[1][0], 0, 0, 0);
+                    if (act_i1 && act_j1) acc[1][1] = NCW_MFMA_H(a1, b1, acc[1][1], 0, 0, 0);
                 }
             } else {
                 for (int kk = 0; kk < npts / 2; ++kk) {
@@ -329,16 +331,26 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const NcwWgradDesc* __re
             for (int b = 0; b < WJ; ++b) bfr[b] = frag(bufp + (XB + WJ * wj + b) * 2048, kk);
 #pragma unroll
             for (int a = 0; a < WI; ++a) {
+                float sacc = 0.f;
+#ifdef NCW_HALF_F16
+                typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+                const h16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const h16x2 pr = {af[a][2 * e], af[a][2 * e + 1]};
+                    sacc = __builtin_amdgcn_fdot2(pr, ones, sacc, false);
+                }
+#else
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 wv = __builtin_bit_cast(u32x4, af[a]);
-                float sacc = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     sacc += __builtin_bit_cast(float, wv[e] << 16) + __builtin_bit_cast(float, wv[e] & 0xffff0000u);
+#endif
                 bsum[a] += sacc;
 #pragma unroll
                 for (int b = 0; b < WJ; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = NCW_MFMA_H(af[a], bfr[b], acc[a][b], 0, 0, 0);
             }
         }
         bufi = bufi + 1 == NBUF ? 0 : bufi + 1;
@@ -368,9 +380,12 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const NcwWgradDesc* __re
     }
 }
 
+}  // namespace NCW_NS
+using namespace NCW_NS;
+
 // tile: 0 = 128 x 256 (X x Y features per workgroup), 1 = 256 x 256 (each stash element is read once per
 // product; for products with more than 4 X blocks).  bf16 only; the f32 kernel ignores it.
-extern "C" int ncw_wgrad_tiled(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
+extern "C" int NCW_FN(ncw_wgrad_tiled)(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
                                int tile, int64_t n_points, void* stream) {
     if (n_desc <= 0 || total_wgs <= 0 || n_points <= 0) return 0;
     if (ksplit < 1 || (tile != 0 && tile != 1)) return NCW_E_BADARG;
@@ -384,8 +399,14 @@ extern "C" int ncw_wgrad_tiled(const NcwWgradDesc* descs, const int32_t* wg_pref
     return 0;
 }
 
-extern "C" int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
-                         int prec, int64_t n_points, void* stream) {
+#ifndef NCW_HALF_F16
+extern "C" int ncw_wgrad_f16(const NcwWgradDesc*, const int32_t*, int, int, int, int, int64_t, void*);
+extern "C" int ncw_wgrad_ordered_f16(const NcwWgradDesc*, const int32_t*, int, int, int, int, int64_t, float*, void*);
+#endif
+
+extern "C" int NCW_FN(ncw_wgrad)(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
+                                 int prec, int64_t n_points, void* stream) {
+    NCW_FORWARD_F16(prec, ncw_wgrad_f16(descs, wg_prefix, n_desc, total_wgs, ksplit, NCW_PREC_BF16, n_points, stream));
     if (n_desc <= 0 || total_wgs <= 0 || n_points <= 0) return 0;
     if (ksplit < 1) return NCW_E_BADARG;
     const int64_t ntiles = (n_points + 31) / 32;
@@ -401,10 +422,13 @@ extern "C" int ncw_wgrad(const NcwWgradDesc* descs, const int32_t* wg_prefix, in
     return 0;
 }
 
+#ifndef NCW_HALF_F16
 extern "C" int64_t ncw_wgrad_ordered_scratch_floats(int total_wgs) { return (int64_t)total_wgs * WG_SLAB; }
+#endif
 
-extern "C" int ncw_wgrad_ordered(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
-                                 int prec, int64_t n_points, float* partials, void* stream) {
+extern "C" int NCW_FN(ncw_wgrad_ordered)(const NcwWgradDesc* descs, const int32_t* wg_prefix, int n_desc, int total_wgs, int ksplit,
+                                         int prec, int64_t n_points, float* partials, void* stream) {
+    NCW_FORWARD_F16(prec, ncw_wgrad_ordered_f16(descs, wg_prefix, n_desc, total_wgs, ksplit, NCW_PREC_BF16, n_points, partials, stream));
     if (n_desc <= 0 || total_wgs <= 0 || n_points <= 0) return 0;
     if (ksplit < 1 || partials == nullptr) return NCW_E_BADARG;
     const int64_t ntiles = (n_points + 31) / 32;

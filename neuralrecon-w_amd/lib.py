@@ -12,9 +12,10 @@ LIB_PATH = os.environ.get("NEUCONW_HIP_LIB") or os.path.join(HERE, "libneuconw_h
 
 PREC_F32 = 0
 PREC_BF16 = 1
+PREC_F16 = 2  # fp16 operands, f32 accumulate; backward needs the loss scale (renderer.grad_scale)
 MAX_LAYERS = 12
 MAX_SEGS = 4
-ABI_VERSION = 6  # 6: ray prologue / inv_s / loss launches, NcwCompositeOut.weights_max;  5: ncw_scatter_add_rows;  4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
+ABI_VERSION = 7  # 6: ray prologue / inv_s / loss launches, NcwCompositeOut.weights_max;  5: ncw_scatter_add_rows;  4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
 
 
 class NcwSeg(C.Structure):
@@ -35,7 +36,8 @@ class NcwUnpackDesc(C.Structure):
         ("dw", C.c_void_p), ("db", C.c_void_p), ("src", C.c_void_p), ("g", C.c_void_p),
         ("d_src", C.c_void_p), ("d_g", C.c_void_p), ("d_bias", C.c_void_p),
         ("ld", C.c_int32), ("ldw", C.c_int32), ("row0", C.c_int32), ("nrows", C.c_int32), ("drow0", C.c_int32),
-        ("scale", C.c_float), ("accumulate", C.c_int32), ("nseg", C.c_int32), ("seg", NcwSeg * MAX_SEGS),
+        ("scale", C.c_float), ("grad_mul", C.c_float), ("accumulate", C.c_int32), ("nseg", C.c_int32),
+        ("seg", NcwSeg * MAX_SEGS),
     ]
 
 
@@ -118,6 +120,7 @@ NcwCompositeGrad = _ptr_struct(
     "NcwCompositeGrad",
     ["d_color", "d_weights_sum", "d_depth", "d_eik_num", "d_sdf", "d_grad", "d_rgb", "d_density", "d_bg_rgb",
      "d_inv_s"],
+    [("grad_scale", C.c_float)],
 )
 
 _VP = C.c_void_p
@@ -133,6 +136,7 @@ _PROTOS = {
     "ncw_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
     "ncw_wgrad_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "ncw_wgrad_tiled_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "ncw_sdf_infer_points": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p,
                                        C.c_void_p]),
     "ncw_voxel_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -63,7 +63,10 @@ def _wvb(m):
 
 
 def _prec_of(v):
-    return L.PREC_F32 if v.lower() in ("f32", "fp32", "0") else L.PREC_BF16
+    v = v.lower()
+    if v in ("f32", "fp32", "0"):
+        return L.PREC_F32
+    return L.PREC_F16 if v in ("f16", "fp16", "half", "2") else L.PREC_BF16
 
 
 def default_prec():

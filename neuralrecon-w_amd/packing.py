@@ -152,11 +152,12 @@ class PackPlan:
         L.check(lib.ncw_pack_weights(L.ptr(self._pack_tab), L.ptr(self._pack_prefix), self._pack_n,
                                      self._pack_rows, L.stream_ptr(self.device)), "ncw_pack_weights")
 
-    def unpack_grads(self, accumulate_into, accumulate=False):
+    def unpack_grads(self, accumulate_into, accumulate=False, grad_mul=1.0):
         """accumulate_into: dict id(param) -> grad tensor (same shape, fp32, contiguous).  Writes (or,
         with accumulate=True, adds) the parameter gradients from the dense gradient arena.  The device
-        descriptor table is cached by content, so the steady state does no host->device copy."""
-        key = (bool(accumulate),) + tuple(accumulate_into[id(u["weight"])].data_ptr() for u in self._unpack) \
+        descriptor table is cached by content, so the steady state does no host->device copy.
+        grad_mul multiplies everything written (1 / loss scale in the fp16 mode)."""
+        key = (bool(accumulate), float(grad_mul)) + tuple(accumulate_into[id(u["weight"])].data_ptr() for u in self._unpack) \
             + tuple(u["weight"].data_ptr() for u in self._unpack)
         cache = self.__dict__.setdefault("_unpack_cache", {})
         hit = cache.get(key)
@@ -179,6 +180,7 @@ class PackPlan:
             d.ld, d.ldw = w.shape[1], self.dense_ld(u["dense"])
             d.row0, d.nrows, d.drow0 = u["row0"], u["nrows"], u["drow0"]
             d.scale = u["scale"]
+            d.grad_mul = float(grad_mul)
             d.accumulate = 1 if accumulate else 0
             d.nseg = len(u["segs"])
             for i, (c0, nc, dc0) in enumerate(u["segs"]):

@@ -111,7 +111,7 @@ class CompositeCtx:
         L.check(lib.ncw_composite_fwd(self.cin, s, L.stream_ptr(dev)), "ncw_composite_fwd")
         return o
 
-    def backward(self, d_color, d_weights_sum, d_depth, d_eik_num):
+    def backward(self, d_color, d_weights_sum, d_depth, d_eik_num, grad_scale=1.0):
         R, S, M, dev = self.R, self.S, self.S + self.O, self.dev
         z = lambda t, shape: _f(t).reshape(shape) if t is not None else torch.zeros(shape, device=dev)  # noqa: E731
         ups = dict(d_color=z(d_color, (R, 3)), d_weights_sum=z(d_weights_sum, (R,)), d_depth=z(d_depth, (R,)),
@@ -124,6 +124,7 @@ class CompositeCtx:
         s = L.NcwCompositeGrad()
         for k, v in list(ups.items()) + list(g.items()):
             setattr(s, k, v.data_ptr() if v is not None else 0)
+        s.grad_scale = float(grad_scale)  # every returned adjoint carries this factor (fp16 loss scaling)
         lib = L.get_lib()
         L.check(lib.ncw_composite_bwd(self.cin, s, L.stream_ptr(dev)), "ncw_composite_bwd")
         self._keep = ups

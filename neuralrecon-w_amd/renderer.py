@@ -79,7 +79,12 @@ class _RenderFn(torch.autograd.Function):
         prec = rdr.prec
         dev = ctx.inv_s.device
         ctx.guard.consume()
-        g = comp.backward(d_color, d_wsum, d_depth, d_eik)
+        # fp16 mode: the per-point adjoints are rounded to fp16 inside the MLP backward kernels (MFMA operands, delta
+        # stashes), whose normal range ends at 6e-5 -- the loss's 1/(3R) alone puts them below it.  The compositor
+        # backward multiplies its upstream by the (power-of-two) loss scale; it is divided back out of the parameter
+        # gradients (unpack), d_a and d_var below, all in f32.
+        gscale = float(rdr.grad_scale) if prec == L.PREC_F16 else 1.0
+        g = comp.backward(d_color, d_wsum, d_depth, d_eik, grad_scale=gscale)
         R, S = comp.R, comp.S
         d_grad = g["d_grad"].view(R * S, 3)
         dfeat_ptr = sctx["arena"].ptr(sctx["ids"]["dfeat"])
@@ -135,7 +140,7 @@ class _RenderFn(torch.autograd.Function):
             flat, views = rdr._grad_views(ctx.params)
             direct = all(p.grad is not None and p.grad.data_ptr() == views[id(p)].data_ptr() for p in ctx.params)
         if direct:
-            keep = [pl.unpack_grads(views, accumulate=True) for pl in plans]
+            keep = [pl.unpack_grads(views, accumulate=True, grad_mul=1.0 / gscale) for pl in plans]
         else:
             tmp = torch.zeros(sum(p.numel() for p in ctx.params), device=dev, dtype=torch.float32)
             tviews, off = {}, 0
@@ -145,11 +150,14 @@ class _RenderFn(torch.autograd.Function):
                 tviews[id(p)] = v
                 out.append(v)
                 off += p.numel()
-            keep = [pl.unpack_grads(tviews) for pl in plans]
+            keep = [pl.unpack_grads(tviews, grad_mul=1.0 / gscale) for pl in plans]
         ctx._keep = (keep, batch)
         d_var = torch.empty(1, device=dev, dtype=torch.float32)  # 10 inv_s [clamp inactive] sum_r d_inv_s[r], fixed order
         L.check(lib.ncw_inv_s_bwd(L.ptr(g["d_inv_s"]), R, L.ptr(ctx.inv_s), L.ptr(d_var), L.stream_ptr(dev)), "ncw_inv_s_bwd")
         d_var = d_var.reshape(ctx.variance.shape)
+        if gscale != 1.0:
+            d_a.mul_(1.0 / gscale)
+            d_var = d_var * (1.0 / gscale)
         ctx.guard.release()
         return (None, None, None, None, None, None, None, None, d_a, d_var) + tuple(out)
 
@@ -253,6 +261,8 @@ class NeuconWRenderer:
                              "ray's samples in LDS (RAY_MAXN 512).  Note config/defaults.py's N_SAMPLES = N_IMPORTANCE = "
                              "512 is overridden by every shipped scene yaml (8 + 16)."
                              % (self.n_samples + self.n_importance + (self.boundary_samples or 0) + self.n_outside))
+        # loss scale of the fp16 mode (prec = PREC_F16; unused otherwise): a power of two, see _RenderFn.backward
+        self.grad_scale = float(os.environ.get("NEUCONW_F16_LOSS_SCALE", "1024"))
         # sync_free=True keeps render() free of device->host synchronisations (see sfm_depth_loss below);
         # the default reproduces the reference's output shapes exactly.
         self.sync_free = False

@@ -109,7 +109,7 @@ class WgradBatch:
         items = [it for it in self.items if it[7] > 0]
         if not items:
             return []
-        if self.prec == L.PREC_BF16:
+        if self.prec != L.PREC_F32:
             # cost of one (product, 256x256 quad): stash blocks streamed x tiles
             def quads(it):
                 return ((it[1] + 7) // 8) * ((it[3] + 7) // 8)
@@ -146,8 +146,8 @@ class WgradBatch:
                 L.check(lib.ncw_wgrad_ordered(L.ptr(tab), L.ptr(pre), nd, wgs, ks, self.prec, n, L.ptr(scr),
                                               L.stream_ptr(self.device)), "ncw_wgrad_ordered")
             else:
-                L.check(lib.ncw_wgrad_tiled(L.ptr(tab), L.ptr(pre), nd, wgs, ks, tile, n,
-                                            L.stream_ptr(self.device)), "ncw_wgrad_tiled")
+                fn = lib.ncw_wgrad_tiled_f16 if self.prec == L.PREC_F16 else lib.ncw_wgrad_tiled
+                L.check(fn(L.ptr(tab), L.ptr(pre), nd, wgs, ks, tile, n, L.stream_ptr(self.device)), "ncw_wgrad_tiled")
 
 
 class StashCache:

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--num_epochs", type=int, default=20)
     ap.add_argument("--max_steps", type=int, default=0, help="stop after this many steps (0 = run the epochs out)")
     ap.add_argument("--exp_name", default="exp")
-    ap.add_argument("--prec", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--ckpt_path", default="", help="resume from this checkpoint")
     ap.add_argument("--log_every", type=int, default=100)
     args = ap.parse_args()
@@ -49,7 +49,7 @@ def main():
     cfg = C.load_config(args.cfg_path, {"DATASET": {"ROOT_DIR": args.root_dir}} if args.root_dir else None)
     lr = C.scale_lr(cfg, world, args.batch_size)
     torch.manual_seed(cfg["TRAINER"]["SEED"])  # pl.seed_everything (train.py:18): identical initial weights on every rank
-    prec = nw.PREC_BF16 if args.prec == "bf16" else nw.PREC_F32
+    prec = {"bf16": nw.PREC_BF16, "f16": nw.PREC_F16, "f32": nw.PREC_F32}[args.prec]
     emb, neuconw, nerf, rdr, scene = C.build_system(cfg, dev, prec)
     rdr.sync_free = True
     n, pt = cfg["NEUCONW"], cfg["DATASET"]["PHOTOTOURISM"]

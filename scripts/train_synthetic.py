@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--rays", type=int, default=1024)
-    ap.add_argument("--prec", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--update-freq", type=int, default=0, help="octree refresh period (NEUCONW.UPDATE_FREQ), 0 = off")
     ap.add_argument("--train-level", type=int, default=7)
     ap.add_argument("--ckpt", default="")
@@ -36,7 +36,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
-    prec = nw.PREC_BF16 if args.prec == "bf16" else nw.PREC_F32
+    prec = {"bf16": nw.PREC_BF16, "f16": nw.PREC_F16, "f32": nw.PREC_F32}[args.prec]
     emb, neuconw, nerf, rdr = bench.build_models(dev, prec)
     if args.update_freq:  # a coarse occupancy shell around the initial surface (stands in for the SfM octree)
         G = 32

@@ -17,7 +17,7 @@ def _run(W, n_layers, skip, prec_name, n=777):
     from oracle import neuconw_oracle as O
     from tests.test_gpu_sdf import _mk
 
-    prec = nw.PREC_F32 if prec_name == "f32" else nw.PREC_BF16
+    prec = {"f32": nw.PREC_F32, "bf16": nw.PREC_BF16, "f16": nw.PREC_F16}[prec_name]
     net = _mk(W, n_layers, skip, seed=3)
     g = torch.Generator().manual_seed(9)
     x = (torch.rand(n, 3, generator=g) * 2 - 1) * 0.9
@@ -67,6 +67,20 @@ def test_sdf_train_bf16(W, n_layers, skip):
     worst = max(rel_err(got[k], gref[k]) for k in gref)
     print("bf16 W=%d worst param-grad rel err %.3e" % (W, worst))
     assert worst < 0.25
+
+
+@pytest.mark.parametrize("W,n_layers,skip", [(64, 8, (4,)), (256, 8, (4,))])
+def test_sdf_train_f16(W, n_layers, skip):
+    """fp16 operands (the bf16 kernels compiled with the 16-bit type switched): 3 more mantissa bits than bf16.  Bounds =
+    about 2x the errors measured on MI355X (outputs <= 1.6e-3, parameter gradients 1.3e-2 at W = 64, 3.5e-3 at W = 256;
+    bf16: 0.11 / 0.031).  The cotangents here are O(1), no loss scale involved."""
+    outs, got, gref = _run(W, n_layers, skip, "f16")
+    for k, (a, b) in outs.items():
+        print("f16 W=%d %s rel err %.3e" % (W, k, rel_err(a, b)))
+        assert rel_err(a, b) < 4e-3, (k, rel_err(a, b))
+    worst = max(rel_err(got[k], gref[k]) for k in gref)
+    print("f16 W=%d worst param-grad rel err %.3e" % (W, worst))
+    assert worst < (0.03 if W == 64 else 8e-3)
 
 
 def test_weights_through_lds_forward_kernel_in_a_subprocess():
