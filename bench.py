@@ -7,8 +7,9 @@ A "step" = NeuconWRenderer.render (sampler + background NeRF + SDF/colour nets +
 + NeuconWLoss + backward (incl. the second-order SDF terms and every weight gradient) + the
 gradient all-reduce + grad-norm clip + Adam step, on a synthetic batch of BASELINE.json's
 configs[1]: 1024 rays/GPU x (64 coarse + 64 fine) samples, SDF 8x256, colour 4x256, background
-NeRF 8x256, 4 outside samples, bf16 MFMA with f32 accumulation.  Rays shard across ranks (weak
-scaling); value = total ray-samples of all ranks / max-over-ranks time.
+NeRF 8x256, 4 outside samples, fp16 MFMA operands with f32 accumulation and a 2^10 loss scale (--prec f16, the default:
+as fast as bf16 and 10-20x closer to the oracle, tests/test_gpu_fullsize.py; --prec bf16 | f32 select the others).  Rays
+shard across ranks (weak scaling); value = total ray-samples of all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with the driver contract keys plus
   `roofline`     dominant kernel by HIP-event time: `frac_mfma` (algorithmic FLOPs / duration / 2.5 PFLOP/s)
@@ -16,6 +17,7 @@ Prints ONE JSON line (rank 0) with the driver contract keys plus
                  = HBM bytes per launch MEASURED WITH THIS RUN (two rocprofv3 --pmc passes of a short re-run of this
                  script: FETCH_SIZE x 2 per MI355X_MICROARCH.md + WRITE_SIZE), `step_traffic_gb` = all kernels of a step;
   `parity_mode`  the same step in the fp32 parity mode (the <= 1e-4 mode), a few steps timed in the same process;
+  `alt_mode`     the same step in the other 16-bit type (bf16 when --prec f16), timed in the same process;
   `cpu_baseline` the CPU oracle on the first 256 rays of the SAME batch, timed on this box.
 Secondary rows (never the reported metric): --config shipped | voxel (BASELINE configs[2]) | grid512 (configs[4]).
 """
@@ -289,7 +291,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--prec", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--prec", default="f16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--rays", type=int, default=R_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
@@ -444,6 +446,7 @@ def main():
         dist.barrier()
     if rank == 0:
         prof, L.PROFILE = L.PROFILE, None
+        prof = {(k[:-4] if k.endswith("_f16") else k): v for k, v in prof.items()}  # the fp16 build of an entry point
         fl = kernel_flops(R)
         rows = {}
         for name, evs in prof.items():
@@ -499,8 +502,22 @@ def main():
 
     # ---- the fp32 parity mode (the <= 1e-4 mode, tests/test_gpu_render.py) timed in the same process ---------------
     parity = None
-    if not args.no_parity_mode and world == 1 and args.prec == "bf16" and not args.graph:
+    alt = None
+    if not args.no_parity_mode and world == 1 and args.prec in ("bf16", "f16") and not args.graph:
         del train, step
+        torch.cuda.empty_cache()
+        alt_name = "bf16" if args.prec == "f16" else "f16"
+        step_a, train_a, _ = make_step({"bf16": nw.PREC_BF16, "f16": nw.PREC_F16}[alt_name])
+        for i in range(5):
+            step_a(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step_a(5 + i)
+        torch.cuda.synchronize()
+        d_a = (time.perf_counter() - t1) / args.steps
+        alt = {"dtype": alt_name, "value": R * S / d_a, "unit": "ray-samples/s", "ms_per_step": d_a * 1e3, "steps": args.steps}
+        del train_a, step_a
         torch.cuda.empty_cache()
         step32, train32, _ = make_step(nw.PREC_F32)
         for i in range(2):
@@ -542,7 +559,7 @@ def main():
                        "world_size": world, "ranks": ranks,
                        "submission": "hip-graph replay" if args.graph else "eager",
                        "final_loss": float(loss.detach())},
-            "roofline": roofline, "parity_mode": parity, "cpu_baseline": cpu,
+            "roofline": roofline, "parity_mode": parity, "alt_mode": alt, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

@@ -70,10 +70,16 @@ def _prec_of(v):
 
 
 def default_prec():
-    """Precision of the TRAINING passes (the three MLPs forward/backward, the sampler's SDF queries)."""
+    """Precision of the TRAINING passes (the three MLPs forward/backward, the sampler's SDF queries): NEUCONW_PREC =
+    f16 (default) | bf16 | f32.  fp16 and bf16 run the same kernels at the same speed (csrc/ncw_common.h: one source,
+    compiled per 16-bit type); fp16's 10 mantissa bits put the rendered outputs within 1-4e-4 of the fp64 oracle where
+    bf16 is at 3-7e-3 (tests/test_gpu_fullsize.py), at the price of fp16's range: the backward runs under a 2^10 loss
+    scale (renderer.grad_scale) and the optimiser skips a step whose gradient norm is not finite.  Everything in the
+    path is bounded well inside +-65504 (points in the unit sphere, weight-normed layers, f32 outputs and accumulators);
+    bf16 stays available for scenes where that is in doubt, f32 is the <= 1e-4 parity mode."""
     import os
 
-    return _prec_of(os.environ.get("NEUCONW_PREC", "bf16"))
+    return _prec_of(os.environ.get("NEUCONW_PREC", "f16"))
 
 
 def default_infer_prec():

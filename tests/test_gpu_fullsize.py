@@ -26,14 +26,18 @@ def _jitter(neuconw):
 #   bf16: outputs 2.6e-3 / gradients 8.7e-2 of the network's largest gradient at 16+16 samples, outputs 6.7e-3 /
 #         gradients 4.3e-2 at 64+64; loss 3.5e-5 / 4.8e-4
 #   fp16: outputs 2.4e-4 / gradients 1.8e-2 at 16+16, outputs 4.2e-4 / gradients 1.3e-3 at 64+64; loss 8e-6 / 2e-6
-BF16_TOL = {(16, 16): (1e-2, 0.175), (64, 64): (1.4e-2, 0.09)}
-F16_TOL = {(16, 16): (6e-4, 0.04), (64, 64): (1e-3, 4e-3)}
+#   W = 512 at 8+16 samples (the shipped yaml's shape) is the ill-conditioned case -- 24 samples per ray, one moved
+#   sample shows: fp32 itself is at 1.5e-4 there; bf16 1.5e-2 / 4.7e-2, fp16 3.4e-3 (gradient_error 7.6e-3) / 1.3e-2,
+#   loss 2e-3 / 2e-4.  The kernels themselves are as accurate at W = 512 as at 256 (scripts/diag/sdf_fwd_prec.py:
+#   sdf_fwd's sdf / normals / features vs the fp32 mode, bf16 3.9e-3 / 1.1e-2 / 4.6e-3, fp16 3.7e-4 / 1.3e-3 / 7.0e-4).
+BF16_TOL = {(16, 16): (1e-2, 0.175), (64, 64): (1.4e-2, 0.09), (8, 16): (3e-2, 0.1)}
+F16_TOL = {(16, 16): (6e-4, 0.04), (64, 64): (1e-3, 4e-3), (8, 16): (1.5e-2, 0.03)}
 LOSS_TOL = {"f32": 1e-4, "bf16": 1.4e-3, "f16": 5e-5}
 
 
 @pytest.mark.parametrize("W,ns,ni,prec_name,R", [(256, 16, 16, "f32", 40), (512, 8, 16, "f32", 40), (256, 16, 16, "bf16", 40),
                                                  (256, 64, 64, "f32", 16), (256, 64, 64, "bf16", 16),
-                                                 (256, 16, 16, "f16", 40), (256, 64, 64, "f16", 16)])
+                                                 (256, 16, 16, "f16", 40), (256, 64, 64, "f16", 16), (512, 8, 16, "f16", 40), (512, 8, 16, "bf16", 40)])
 def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
     """(256, 64, 64) is the HEADLINE sampling shape of BASELINE configs[1] (64 coarse + 64 fine samples, W = 256): the
     composed render + loss + backward against the oracle, not only its unit kernels."""
@@ -70,7 +74,7 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
     print("W=%d %d+%d %s outputs:" % (W, ns, ni, prec_name), {k: "%.2e" % v for k, v in errs.items()})
     for k, e in errs.items():
         assert e < tol_out, (k, e)
-    assert abs(float(loss.detach()) - float(lref.detach())) < LOSS_TOL[prec_name]
+    assert abs(float(loss.detach()) - float(lref.detach())) < LOSS_TOL[prec_name] * (40 if W == 512 and prec_name != "f32" else 1)
     params = named_params(emb, neuconw, nerf)
 
     def net_of(k):
