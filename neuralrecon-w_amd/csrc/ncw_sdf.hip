@@ -408,6 +408,17 @@ int NCW_FN(ncw_sdf_fwd8_launch)(const NcwSdfNet* net, const NcwPoints& src, int6
 
 int NCW_FN(ncw_sdf_inferC_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);  // ncw_pp.hip
 
+// W = 512, 16-bit: weights streamed from L2, activations in LDS (ncw_sdf16.hip); NCW_SDF16=0 selects the generic kernels below
+int NCW_FN(ncw_sdf_infer16_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);
+int NCW_FN(ncw_sdf_fwd16_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
+                                 const NcwSdfStash& stash, hipStream_t st);
+int NCW_FN(ncw_sdf_bwd16_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, const float* d_sdf, const float* d_grad,
+                                 const NcwSdfStash& stash, hipStream_t st);
+static bool sdf16_on(const NcwSdfNet* net, int prec) {
+    static const int on = getenv("NCW_SDF16") ? atoi(getenv("NCW_SDF16")) : 1;
+    return on > 0 && net->rb == 16 && prec == NCW_PREC_BF16 && net->n_layers >= 3;
+}
+
 static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, int64_t n, float* sdf, void* stream) {
     if (!sdf_net_ok(net) || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
@@ -416,6 +427,7 @@ static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, i
     // 2 = the weights-stationary burst kernel of ncw_sdf8.hip (0.170 ms with the polynomial Softplus, 0.198 before it),
     // 0 = the weights-through-LDS kernel below (0.26 ms).
     static const int variant8 = getenv("NCW_SDF_INFER8") ? atoi(getenv("NCW_SDF_INFER8")) : 3;
+    if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_infer16_launch)(net, src, n, sdf, st);
     if (variant8 == 3 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3 && net->n_layers <= 12)
         return NCW_FN(ncw_sdf_inferC_launch)(net, src, n, sdf, st);
     if (variant8 > 0 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
@@ -468,6 +480,7 @@ extern "C" int NCW_FN(ncw_sdf_fwd)(const NcwSdfNet* net, int prec, const NcwPoin
     static const int fwd8 = getenv("NCW_SDF_FWD8") ? atoi(getenv("NCW_SDF_FWD8")) : 1;
     if (fwd8 > 0 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
         return NCW_FN(ncw_sdf_fwd8_launch)(net, *pts, n, sdf, grad, *stash, st);
+    if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_fwd16_launch)(net, *pts, n, sdf, grad, *stash, st);
     NCW_SDF_DISPATCH(sdf_fwd_kernel, *net, *pts, n, sdf, grad, *stash);
     return 0;
 }
@@ -478,6 +491,7 @@ extern "C" int NCW_FN(ncw_sdf_bwd)(const NcwSdfNet* net, int prec, const NcwPoin
     if (!sdf_net_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_bwd16_launch)(net, *pts, n, d_sdf, d_grad, *stash, st);
     NCW_SDF_DISPATCH(sdf_bwd_kernel, *net, *pts, n, d_sdf, d_grad, *stash);
     return 0;
 }

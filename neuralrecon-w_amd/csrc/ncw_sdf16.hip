@@ -1,0 +1,549 @@
+// SDF network at W = 512 (the width the reference ships, config/train_*.yaml), 16-bit operands: sdf_infer, sdf_fwd and
+// sdf_bwd with the WEIGHTS STREAMED FROM L2 and the activations in LDS -- the arithmetic and the stashes of the generic
+// kernels of ncw_sdf.hip (models/neuconw.py:263-296 forward, the analytic adjoint pass for the normals, the second-order
+// backward), which at RB = 16 need 256 accumulator registers per wave and spill 1.1-1.8 KB per lane.
+//
+// A layer is 512 KB of 16-bit weights = the whole register file of a CU, so the weights-stationary structure of
+// ncw_sdf8.hip does not carry over.  Here a workgroup of 8 waves owns T tiles of 32 points (T = 4: 128 points; T = 2 for
+// launches that would not fill the chip otherwise); wave w owns OUTPUT BLOCKS w and w + 8 of every layer.  Per k-unit
+// (16 input features) it loads its two A fragments (2 x 16 B per lane) from the packed matrix in L2, S16_D units ahead
+// into a small register ring, reads the T B fragments of the unit from LDS and issues 2 T MFMAs.  The activations of
+// the workgroup live in ONE LDS buffer ([tile][32 k-units][64 lanes][16 B] = T x 32 KiB) that every layer rewrites IN
+// PLACE: all waves read all of it during the MFMA phase (the layer's whole output sits in 32 T accumulator registers per
+// wave), a barrier, then every wave overwrites the two blocks it owns.  Per layer and workgroup at T = 4: 2,048 MFMAs
+// (16,384 cycles per SIMD quad) against 512 KB from L2 (8,192 cycles at 64 B/clk/CU; the 9.2 MB of forward + transposed
+// matrices do not fit the 4 MB L2 of an XCD, so part of it comes from the memory-side cache) and 1 MB of LDS reads
+// (8,192 cycles).  Nothing spills.
+#include "ncw_mlp.h"
+
+namespace {
+
+constexpr int S16_WAVES = 8;
+constexpr int S16_KU = 32;  // k-units of a 512-wide layer
+constexpr int S16_D = 4;    // weight prefetch distance (k-units)
+
+typedef __attribute__((address_space(3))) bf16x8 s16_lfrag;
+typedef const __attribute__((address_space(1))) bf16x8* s16_gfrag;
+
+struct S16W { bf16x8 f[S16_D][2]; };  // register ring: units q .. q + D - 1 of the wave's two output blocks
+
+NCW_DEV bf16x8 s16_ld(const void* w, int rb_stride, int ob, int u, int lane) {
+    return ((s16_gfrag)w)[((size_t)u * rb_stride + ob) * 64 + lane];
+}
+
+// the first S16_D units of a matrix (issued a layer ahead: they land during the previous epilogue and the barriers)
+NCW_DEV void s16_prefetch(S16W& r, const void* w, int rb_stride, int wave, int lane) {
+#pragma unroll
+    for (int d = 0; d < S16_D; ++d) {
+        r.f[d][0] = s16_ld(w, rb_stride, wave, d, lane);
+        r.f[d][1] = s16_ld(w, rb_stride, wave + 8, d, lane);
+    }
+}
+
+// acc[j][t] += W[block wave + 8 j][.] . in[tile t][.] over NU k-units; r holds units 0 .. D-1 on entry and is free on exit
+template <int T, int NU>
+NCW_DEV void s16_mma(f32x16 (&acc)[2][T], S16W& r, const void* w, int rb_stride, int wave, const s16_lfrag* in, int lane) {
+#pragma unroll
+    for (int q = 0; q < NU; ++q) {
+        const bf16x8 a0 = r.f[q % S16_D][0], a1 = r.f[q % S16_D][1];
+        if (q + S16_D < NU) {
+            r.f[q % S16_D][0] = s16_ld(w, rb_stride, wave, q + S16_D, lane);
+            r.f[q % S16_D][1] = s16_ld(w, rb_stride, wave + 8, q + S16_D, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const bf16x8 b = in[(t * S16_KU + q) * 64 + lane];
+            acc[0][t] = NCW_MFMA_H(a0, b, acc[0][t], 0, 0, 0);
+            acc[1][t] = NCW_MFMA_H(a1, b, acc[1][t], 0, 0, 0);
+        }
+    }
+}
+
+// the 3 gamma k-units (32..34) of the forward-orientation skip layer against gbuf (units 0..2 of a tile)
+template <int T>
+NCW_DEV void s16_mma_gamma(f32x16 (&acc)[2][T], const void* w, int wave, const s16_lfrag* gbuf, int lane) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const bf16x8 g0 = s16_ld(w, 16, wave, S16_KU + q, lane), g1 = s16_ld(w, 16, wave + 8, S16_KU + q, lane);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            acc[0][t] = NCW_MFMA_H(g0, gbuf[(t * 4 + q) * 64 + lane], acc[0][t], 0, 0, 0);
+            acc[1][t] = NCW_MFMA_H(g1, gbuf[(t * 4 + q) * 64 + lane], acc[1][t], 0, 0, 0);
+        }
+    }
+}
+
+// one output block of one tile (gamma columns of a transposed matrix, the sdf row): acc += W[block ob][.] . in[tile t][.]
+template <int NU>
+NCW_DEV void s16_mma1(f32x16& acc, const void* w, int rb_stride, int ob, const s16_lfrag* in, int t, int lane) {
+#pragma unroll
+    for (int q = 0; q < NU; ++q)
+        acc = NCW_MFMA_H(s16_ld(w, rb_stride, ob, q, lane), in[(t * S16_KU + q) * 64 + lane], acc, 0, 0, 0);
+}
+
+NCW_DEV void s16_store_units(s16_lfrag* buf, int t, int ob, const f32x16& v, int lane) {
+    Act<PrecBF16, 1> o;
+    to_act_block<1>(o, 0, v);
+    buf[(t * S16_KU + 2 * ob) * 64 + lane] = o.f[0];
+    buf[(t * S16_KU + 2 * ob + 1) * 64 + lane] = o.f[1];
+}
+
+NCW_DEV f32x16 s16_bias(const float* bp, int ob, int lane) {
+    CVec<1> b1;
+    load_bias(b1, bp + ob * 32, lane);
+    return b1.v[0];
+}
+
+NCW_DEV f32x16 s16_zero() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+template <int T>
+NCW_DEV void s16_fill(f32x16 (&acc)[2][T], const f32x16& b0, const f32x16& b1) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) { acc[0][t] = b0; acc[1][t] = b1; }
+}
+
+NCW_DEV f32x16 s16_softplus(const f32x16& z) {
+    f32x16 y;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { float yy, s; softplus100<true>(z[r], yy, s); y[r] = yy; }
+    return y;
+}
+
+// phi'(z) = 1 - exp(-100 h) from the stashed post-activation h
+NCW_DEV f32x16 s16_sprime(const ncw_h16* __restrict__ st_h, size_t tile, int ob, int lane) {
+    f32x16 sv;
+    stash_load_block(sv, st_h, tile, 16, ob, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = 1.f - __builtin_amdgcn_exp2f(sv[r] * -144.26950408889634f);
+    return sv;
+}
+
+// abuf: the activations, rewritten in place by every layer; gbuf: per tile 4 units (gamma / qbar_0: 3, the d_sdf unit: 1)
+#define S16_LDS_DECL()                                                                \
+    __shared__ __attribute__((aligned(16))) char lds[T * S16_KU * 1024 + T * 4096];   \
+    s16_lfrag* const abuf = (s16_lfrag*)(ncw_lchar*)lds;                              \
+    s16_lfrag* const gbuf = abuf + T * S16_KU * 64;                                   \
+    const int lane = ncw_lane();                                                      \
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));        \
+    const int L = net.n_layers;                                                       \
+    const int64_t tile0 = (int64_t)blockIdx.x * T
+
+// ------------------------------------------------------------------------------------------------
+// sdf_infer: the sampler's SDF queries (renderer.py:482-566), the octree refresh and the 512^3 grid sweep
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(64 * S16_WAVES) void sdf_infer16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                    float* __restrict__ sdf) {
+    S16_LDS_DECL();
+    for (int tw = wave; tw < T; tw += S16_WAVES) {  // gamma of tile tw, straight into LDS as k-units 0..2
+        int64_t p = (tile0 + tw) * 32 + (lane & 31), ray;
+        if (p >= n) p = n - 1;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+        CVec<2> gam;
+        freq_encode<2, 3, 6, true>(gam, xs, lane);
+        Act<PrecBF16, 2> ga;
+        to_act(ga, gam);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gbuf[(tw * 4 + q) * 64 + lane] = ga.f[q];
+    }
+    S16W r;
+    f32x16 acc[2][T];
+    {   // layer 0: K = 39 (3 units)
+        bf16x8 w0[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) w0[j][q] = s16_ld(net.w[0], 16, wave + 8 * j, q, lane);
+        if (L - 1 > 1) s16_prefetch(r, net.w[1], 16, wave, lane);
+        const f32x16 b0 = s16_bias(net.b[0], wave, lane), b1 = s16_bias(net.b[0], wave + 8, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 a = j ? b1 : b0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a = NCW_MFMA_H(w0[j][q], gbuf[(t * 4 + q) * 64 + lane], a, 0, 0, 0);
+                s16_store_units(abuf, t, wave + 8 * j, s16_softplus(a), lane);
+            }
+    }
+    for (int l = 1; l < L - 1; ++l) {
+        const f32x16 b0 = s16_bias(net.b[l], wave, lane), b1 = s16_bias(net.b[l], wave + 8, lane);
+        __syncthreads();  // layer l-1 outputs of all waves are in abuf
+        s16_fill<T>(acc, b0, b1);
+        s16_mma<T, S16_KU>(acc, r, net.w[l], 16, wave, abuf, lane);
+        if (l + 1 < L - 1) s16_prefetch(r, net.w[l + 1], 16, wave, lane);
+        if (l == net.skip_layer) s16_mma_gamma<T>(acc, net.w[l], wave, gbuf, lane);
+        __syncthreads();  // every wave has read abuf: overwrite in place
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s16_store_units(abuf, t, wave + 8 * j, s16_softplus(acc[j][t]), lane);
+    }
+    __syncthreads();
+    for (int tw = wave; tw < T; tw += S16_WAVES) {  // sdf row
+        CVec<1> o;
+        load_bias(o, net.b[L - 1], lane);
+        s16_mma1<S16_KU>(o.v[0], net.w[L - 1], 1, 0, abuf, tw, lane);
+        const int64_t p = (tile0 + tw) * 32 + (lane & 31);
+        if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sdf_fwd: forward chain with the activation stash, feature layer, sdf row, then the analytic adjoint pass
+// t_{l-1} = (W_l^T t_l) * phi'(z_{l-1}) with the t_l stash and grad = J_gamma^T g_gamma (sdf_fwd_kernel, ncw_sdf.hip).
+// The gamma output blocks (16, 17) of the transposed skip layer and the two blocks of W_0^T are 2 blocks x T tiles
+// jobs: wave w < 2 T takes block (w & 1) of tile (w >> 1) and keeps that g_gamma block to the end (2 T <= 8).
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                  float* __restrict__ sdf, float* __restrict__ grad,
+                                                                  NcwSdfStash st) {
+    typedef ncw_h16 SE;
+    static_assert(2 * T <= S16_WAVES, "one gamma job per wave");
+    S16_LDS_DECL();
+    const int jb = wave & 1, jt = wave >> 1;
+    const bool gjob = wave < 2 * T;
+    if (wave < T) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        if (p >= n) p = n - 1;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+        CVec<2> gam;
+        freq_encode<2, 3, 6, true>(gam, xs, lane);
+        stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        Act<PrecBF16, 2> ga;
+        to_act(ga, gam);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gbuf[(wave * 4 + q) * 64 + lane] = ga.f[q];
+    }
+    S16W r;
+    f32x16 acc[2][T];
+    {   // layer 0
+        bf16x8 w0[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) w0[j][q] = s16_ld(net.w[0], 16, wave + 8 * j, q, lane);
+        s16_prefetch(r, L - 1 > 1 ? net.w[1] : net.w_feat, 16, wave, lane);
+        const f32x16 b0 = s16_bias(net.b[0], wave, lane), b1 = s16_bias(net.b[0], wave + 8, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 a = j ? b1 : b0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a = NCW_MFMA_H(w0[j][q], gbuf[(t * 4 + q) * 64 + lane], a, 0, 0, 0);
+                const f32x16 y = s16_softplus(a);
+                stash_store_block((SE*)st.h[1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
+                s16_store_units(abuf, t, wave + 8 * j, y, lane);
+            }
+    }
+    for (int l = 1; l < L - 1; ++l) {  // r = first units of w[l]
+        const f32x16 b0 = s16_bias(net.b[l], wave, lane), b1 = s16_bias(net.b[l], wave + 8, lane);
+        __syncthreads();
+        s16_fill<T>(acc, b0, b1);
+        s16_mma<T, S16_KU>(acc, r, net.w[l], 16, wave, abuf, lane);
+        s16_prefetch(r, l + 1 < L - 1 ? net.w[l + 1] : net.w_feat, 16, wave, lane);  // next: hidden or feature layer
+        if (l == net.skip_layer) s16_mma_gamma<T>(acc, net.w[l], wave, gbuf, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 y = s16_softplus(acc[j][t]);
+                stash_store_block((SE*)st.h[l + 1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
+                s16_store_units(abuf, t, wave + 8 * j, y, lane);
+            }
+    }
+    // ---- feature layer (r = first units of w_feat) and sdf row; then the adjoint's first vector ------------------
+    {
+        const bf16x8 wt1_0 = s16_ld(net.wt[L - 1], 16, wave, 0, lane), wt1_1 = s16_ld(net.wt[L - 1], 16, wave + 8, 0, lane);
+        const f32x16 b0 = s16_bias(net.b_feat, wave, lane), b1 = s16_bias(net.b_feat, wave + 8, lane);
+        __syncthreads();  // h_{L-1} complete in abuf
+        s16_fill<T>(acc, b0, b1);
+        s16_mma<T, S16_KU>(acc, r, net.w_feat, 16, wave, abuf, lane);
+        if (L - 2 >= 1) s16_prefetch(r, net.wt[L - 2], (L - 2 == net.skip_layer) ? 18 : 16, wave, lane);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) stash_store_block((SE*)st.feat, (size_t)(tile0 + t), 16, wave + 8 * j, acc[j][t], lane);
+        if (wave < T) {
+            CVec<1> o;
+            load_bias(o, net.b[L - 1], lane);
+            s16_mma1<S16_KU>(o.v[0], net.w[L - 1], 1, 0, abuf, wave, lane);
+            const int64_t p = (tile0 + wave) * 32 + (lane & 31);
+            if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+        }
+        // a_{L-2} = W_{L-1}^T e_0 (the same for every point); t_{L-2} = a * phi'(z_{L-2})
+        bf16x8 e0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) e0f[e] = (ncw_h16)0.f;
+        e0f[0] = (ncw_h16)(lane < 32 ? 1.f : 0.f);
+        const f32x16 a0 = NCW_MFMA_H(wt1_0, e0f, s16_zero(), 0, 0, 0), a1 = NCW_MFMA_H(wt1_1, e0f, s16_zero(), 0, 0, 0);
+        __syncthreads();  // the feature layer and the sdf row have read h_{L-1}: overwrite abuf with t_{L-2}
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 sv = s16_sprime((const SE*)st.h[L - 1], (size_t)(tile0 + t), wave + 8 * j, lane);
+                const f32x16& aa = j ? a1 : a0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sv[q] *= aa[q];
+                stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
+                s16_store_units(abuf, t, wave + 8 * j, sv, lane);
+            }
+    }
+    // ---- adjoint layers l = L-2 .. 1: t_{l-1} = (W_l^T t_l) * phi'(z_{l-1});  r = first units of wt[l] -------------
+    f32x16 gg = s16_zero();
+    for (int l = L - 2; l >= 1; --l) {
+        const bool skip = (l == net.skip_layer);
+        __syncthreads();  // t_l complete in abuf
+        s16_fill<T>(acc, s16_zero(), s16_zero());
+        s16_mma<T, S16_KU>(acc, r, net.wt[l], skip ? 18 : 16, wave, abuf, lane);
+        if (l - 1 >= 1) s16_prefetch(r, net.wt[l - 1], (l - 1 == net.skip_layer) ? 18 : 16, wave, lane);
+        if (skip && gjob) s16_mma1<S16_KU>(gg, net.wt[l], 18, 16 + jb, abuf, jt, lane);  // gamma columns of the skip layer
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 sv = s16_sprime((const SE*)st.h[l], (size_t)(tile0 + t), wave + 8 * j, lane);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sv[q] *= acc[j][t][q];
+                stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
+                s16_store_units(abuf, t, wave + 8 * j, sv, lane);
+            }
+    }
+    // ---- adjoint layer 0: g_gamma += W_0^T t_0 (2 out-blocks), then grad = J_gamma^T g_gamma ------------------------
+    __syncthreads();
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    int64_t p = (tile0 + jt) * 32 + (lane & 31), ray;
+    const bool valid = gjob && p < n;
+    if (gjob) {
+        s16_mma1<S16_KU>(gg, net.wt[0], 2, jb, abuf, jt, lane);
+        if (p >= n) p = n - 1;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+        const int h = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int f0 = 32 * jb + ncw_feat_of(q, 0);
+            if (f0 >= 39) continue;  // (block 1 holds features 32..38 only)
+            int comp;
+            const float dv = freq_feature_deriv<3, 6, true>(xs, f0 + 4 * h, comp);
+            const float c = gg[q] * dv;
+            nx += comp == 0 ? c : 0.f;
+            ny += comp == 1 ? c : 0.f;
+            nz += comp == 2 ? c : 0.f;
+        }
+        nx = half_pair_sum(nx); ny = half_pair_sum(ny); nz = half_pair_sum(nz);
+    }
+    // combine the two blocks of a tile (waves 2 jt and 2 jt + 1) through LDS (the gamma region is free now)
+    typedef __attribute__((address_space(3))) float lfloat;
+    lfloat* part = (lfloat*)gbuf;
+    if (gjob && jb == 1 && lane < 32) {
+        part[(jt * 32 + lane) * 3 + 0] = nx; part[(jt * 32 + lane) * 3 + 1] = ny; part[(jt * 32 + lane) * 3 + 2] = nz;
+    }
+    __syncthreads();
+    if (gjob && jb == 0 && lane < 32 && valid) {
+        grad[p * 3 + 0] = nx + part[(jt * 32 + lane) * 3 + 0];
+        grad[p * 3 + 1] = ny + part[(jt * 32 + lane) * 3 + 1];
+        grad[p * 3 + 2] = nz + part[(jt * 32 + lane) * 3 + 2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sdf_bwd (second order): (1) backward of the adjoint pass l = 0 .. L-2 (tbar = W qbar, abar = tbar phi',
+// zbar2 = tbar 100 t (1 - phi')), (2) backward of the forward pass l = L-1 .. 0 (ubar = W^T zbar,
+// zbar = ubar phi' + zbar2) -- the arithmetic and the stash of sdf_bwd_kernel (ncw_sdf.hip).
+// gbuf: units 0..2 of a tile = qbar_0 = J_gamma nbar, unit 3 = the d_sdf block.
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(64 * S16_WAVES) void sdf_bwd16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                  const float* __restrict__ d_sdf,
+                                                                  const float* __restrict__ d_grad, NcwSdfStash st) {
+    typedef ncw_h16 SE;
+    S16_LDS_DECL();
+    if (wave < T) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        const bool valid = p < n;
+        if (!valid) p = n - 1;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+        const float vmask = valid ? 1.f : 0.f;  // padded lanes must contribute nothing to the weight gradients
+        const float nb[3] = {d_grad[p * 3 + 0] * vmask, d_grad[p * 3 + 1] * vmask, d_grad[p * 3 + 2] * vmask};
+        const float dsdf = d_sdf[p] * vmask / net.scale;
+        const int h = lane >> 5;
+        CVec<2> q0;  // qbar_0 = J_gamma nbar
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (32 * rb + ncw_feat_of(q, 0) >= 39) {
+                    q0.v[rb][q] = 0.f;
+                    continue;
+                }
+                int comp;
+                const float dv = freq_feature_deriv<3, 6, true>(xs, 32 * rb + ncw_feat_of(q, 0) + 4 * h, comp);
+                q0.v[rb][q] = dv * (comp == 0 ? nb[0] : (comp == 1 ? nb[1] : nb[2]));
+            }
+        stash_store<2>((SE*)st.qbar[0], (size_t)(tile0 + wave), q0, lane);
+        Act<PrecBF16, 2> q0a;
+        to_act(q0a, q0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gbuf[(wave * 4 + q) * 64 + lane] = q0a.f[q];
+        CVec<1> zs, one;
+        cvec_zero(zs);
+        cvec_zero(one);
+        zs.v[0][0] = (lane < 32) ? dsdf : 0.f;
+        one.v[0][0] = (lane < 32) ? vmask : 0.f;
+        stash_store<1>((SE*)st.zsdf, (size_t)(tile0 + wave), zs, lane);
+        stash_store<1>((SE*)st.one, (size_t)(tile0 + wave), one, lane);
+        Act<PrecBF16, 1> zsa;
+        to_act(zsa, zs);
+        gbuf[(wave * 4 + 3) * 64 + lane] = zsa.f[0];
+    }
+    S16W r;
+    f32x16 acc[2][T];
+    // one output block of one tile: tbar -> zbar2_l (temporarily in zbar[l]), abar_l = qbar_{l+1} (stash + LDS)
+    auto adj_epilogue = [&](const f32x16& tbar, int l, int t, int ob) {
+        const f32x16 sv = s16_sprime((const SE*)st.h[l + 1], (size_t)(tile0 + t), ob, lane);
+        f32x16 tv, z2, ab;
+        stash_load_block(tv, (const SE*)st.t[l], (size_t)(tile0 + t), 16, ob, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            z2[q] = tbar[q] * 100.f * tv[q] * (1.f - sv[q]);  // a_l phi''(z_l) = 100 t_l (1 - s_l)
+            ab[q] = tbar[q] * sv[q];
+        }
+        stash_store_block((SE*)st.zbar[l], (size_t)(tile0 + t), 16, ob, z2, lane);
+        stash_store_block((SE*)st.qbar[l + 1], (size_t)(tile0 + t), 16, ob, ab, lane);
+        s16_store_units(abuf, t, ob, ab, lane);
+    };
+    {   // (1) layer 0: tbar = W_0 qbar_0 (3 units)
+        bf16x8 w0[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) w0[j][q] = s16_ld(net.w[0], 16, wave + 8 * j, q, lane);
+        s16_prefetch(r, 1 <= L - 2 ? net.w[1] : net.wt_feat, 16, wave, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 a = s16_zero();
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a = NCW_MFMA_H(w0[j][q], gbuf[(t * 4 + q) * 64 + lane], a, 0, 0, 0);
+                adj_epilogue(a, 0, t, wave + 8 * j);
+            }
+    }
+    for (int l = 1; l <= L - 2; ++l) {  // r = first units of w[l]
+        __syncthreads();
+        s16_fill<T>(acc, s16_zero(), s16_zero());
+        s16_mma<T, S16_KU>(acc, r, net.w[l], 16, wave, abuf, lane);
+        s16_prefetch(r, l + 1 <= L - 2 ? net.w[l + 1] : net.wt_feat, 16, wave, lane);
+        if (l == net.skip_layer) s16_mma_gamma<T>(acc, net.w[l], wave, gbuf, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) adj_epilogue(acc[j][t], l, t, wave + 8 * j);
+    }
+    // ---- (2) u = wt_feat dfeat + wt[L-1] d_sdf  (r = first units of wt_feat) -----------------------------------------
+    // zbar_l = u phi'(z_l) + zbar2_l  -> stash zbar[l] (+ LDS when a further layer consumes it)
+    auto fwd_epilogue = [&](const f32x16& u, int l, int t, int ob) {
+        const f32x16 sv = s16_sprime((const SE*)st.h[l + 1], (size_t)(tile0 + t), ob, lane);
+        f32x16 z2;
+        stash_load_block(z2, (const SE*)st.zbar[l], (size_t)(tile0 + t), 16, ob, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) z2[q] = u[q] * sv[q] + z2[q];
+        stash_store_block((SE*)st.zbar[l], (size_t)(tile0 + t), 16, ob, z2, lane);
+        if (l > 0) s16_store_units(abuf, t, ob, z2, lane);
+    };
+    {
+        // the dfeat blocks of this wave: stash -> B fragments, over qbar_{L-1} in abuf, which nobody reads (it only goes
+        // to the stash) and of which this wave owns exactly the units it overwrites
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 df;
+                stash_load_block(df, (const SE*)st.dfeat, (size_t)(tile0 + t), 16, wave + 8 * j, lane);
+                s16_store_units(abuf, t, wave + 8 * j, df, lane);
+            }
+        const bf16x8 wl0 = s16_ld(net.wt[L - 1], 16, wave, 0, lane), wl1 = s16_ld(net.wt[L - 1], 16, wave + 8, 0, lane);  // K = 1 unit
+        __syncthreads();  // dfeat complete in abuf
+        s16_fill<T>(acc, s16_zero(), s16_zero());
+        s16_mma<T, S16_KU>(acc, r, net.wt_feat, 16, wave, abuf, lane);
+        if (L - 2 > 0) s16_prefetch(r, net.wt[L - 2], (L - 2 == net.skip_layer) ? 18 : 16, wave, lane);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            acc[0][t] = NCW_MFMA_H(wl0, gbuf[(t * 4 + 3) * 64 + lane], acc[0][t], 0, 0, 0);
+            acc[1][t] = NCW_MFMA_H(wl1, gbuf[(t * 4 + 3) * 64 + lane], acc[1][t], 0, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fwd_epilogue(acc[j][t], L - 2, t, wave + 8 * j);
+    }
+    for (int l = L - 2; l >= 1; --l) {  // u = wt[l] zbar_l, zbar_{l-1} = u phi'(z_{l-1}) + zbar2_{l-1}
+        __syncthreads();
+        s16_fill<T>(acc, s16_zero(), s16_zero());
+        s16_mma<T, S16_KU>(acc, r, net.wt[l], (l == net.skip_layer) ? 18 : 16, wave, abuf, lane);
+        if (l - 1 > 0) s16_prefetch(r, net.wt[l - 1], (l - 1 == net.skip_layer) ? 18 : 16, wave, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fwd_epilogue(acc[j][t], l - 1, t, wave + 8 * j);
+    }
+}
+
+// T = 4 (128 points per workgroup: half the weight traffic per point) once that still gives every CU a workgroup,
+// T = 2 below that (the sampler's small launches, small batches)
+int s16_tiles_per_wg(int64_t tiles) {
+    static const int forced = getenv("NCW_SDF16_T") ? atoi(getenv("NCW_SDF16_T")) : 0;
+    if (forced == 2 || forced == 4) return forced;
+    return tiles >= 4 * 192 ? 4 : 2;
+}
+
+}  // namespace
+
+#define S16_LAUNCH(KERNEL, ...)                                                                                              \
+    do {                                                                                                                     \
+        const int64_t tiles = (n + 31) / 32;                                                                                 \
+        if (s16_tiles_per_wg(tiles) == 4)                                                                                    \
+            hipLaunchKernelGGL(KERNEL<4>, dim3((unsigned)((tiles + 3) / 4)), dim3(64 * S16_WAVES), 0, st, __VA_ARGS__);      \
+        else                                                                                                                 \
+            hipLaunchKernelGGL(KERNEL<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(64 * S16_WAVES), 0, st, __VA_ARGS__);      \
+        NCW_CHECK_LAUNCH();                                                                                                  \
+        return 0;                                                                                                            \
+    } while (0)
+
+int NCW_FN(ncw_sdf_infer16_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
+    S16_LAUNCH(sdf_infer16_kernel, *net, src, n, sdf);
+}
+
+int NCW_FN(ncw_sdf_fwd16_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
+                                 const NcwSdfStash& stash, hipStream_t st) {
+    S16_LAUNCH(sdf_fwd16_kernel, *net, src, n, sdf, grad, stash);
+}
+
+int NCW_FN(ncw_sdf_bwd16_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, const float* d_sdf, const float* d_grad,
+                                 const NcwSdfStash& stash, hipStream_t st) {
+    S16_LAUNCH(sdf_bwd16_kernel, *net, src, n, d_sdf, d_grad, stash);
+}

@@ -59,7 +59,7 @@ def test_sdf_train_f32(W, n_layers, skip):
         assert e < 2e-4, (k, e)
 
 
-@pytest.mark.parametrize("W,n_layers,skip", [(64, 8, (4,)), (256, 8, (4,))])
+@pytest.mark.parametrize("W,n_layers,skip", [(64, 8, (4,)), (256, 8, (4,)), (512, 8, (4,))])
 def test_sdf_train_bf16(W, n_layers, skip):
     outs, got, gref = _run(W, n_layers, skip, "bf16")
     for k, (a, b) in outs.items():
@@ -69,7 +69,7 @@ def test_sdf_train_bf16(W, n_layers, skip):
     assert worst < 0.25
 
 
-@pytest.mark.parametrize("W,n_layers,skip", [(64, 8, (4,)), (256, 8, (4,))])
+@pytest.mark.parametrize("W,n_layers,skip", [(64, 8, (4,)), (256, 8, (4,)), (512, 8, (4,))])
 def test_sdf_train_f16(W, n_layers, skip):
     """fp16 operands (the bf16 kernels compiled with the 16-bit type switched): 3 more mantissa bits than bf16.  Bounds =
     about 2x the errors measured on MI355X (outputs <= 1.6e-3, parameter gradients 1.3e-2 at W = 64, 3.5e-3 at W = 256;
@@ -84,8 +84,9 @@ def test_sdf_train_f16(W, n_layers, skip):
 
 
 def test_weights_through_lds_forward_kernel_in_a_subprocess():
-    """W = 256 bf16 defaults to the weights-stationary sdf_fwd (csrc/ncw_sdf8.hip); the weights-through-LDS kernel
-    (NCW_SDF_FWD8=0, the only one for f32 and other widths) must stay correct at that shape too: the tests of this
+    """W = 256 16-bit defaults to the weights-stationary sdf_fwd (csrc/ncw_sdf8.hip) and W = 512 16-bit to the
+    weights-from-L2 kernels (csrc/ncw_sdf16.hip); the weights-through-LDS kernels (NCW_SDF_FWD8=0 / NCW_SDF16=0, the only
+    ones for f32 and other widths) must stay correct at those shapes too: the tests of this
     file are re-run in a subprocess with the switch set (it is read once per process)."""
     import os
     import subprocess
@@ -93,7 +94,7 @@ def test_weights_through_lds_forward_kernel_in_a_subprocess():
 
     if os.environ.get("NCW_SDF_FWD8") is not None:
         pytest.skip("already inside a variant run")
-    env = dict(os.environ, NCW_SDF_FWD8="0")
+    env = dict(os.environ, NCW_SDF_FWD8="0", NCW_SDF16="0")  # NCW_SDF16=0: the generic kernels at W = 512 as well
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "not subprocess"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
