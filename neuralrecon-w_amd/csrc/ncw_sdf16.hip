@@ -16,11 +16,18 @@
 // (8,192 cycles).  Nothing spills.
 #include "ncw_mlp.h"
 
+#ifdef S16_EXP_NOSTASH  // timing experiment only: no stash stores (the backward reads garbage)
+#define stash_store_block(...) ((void)0)
+#endif
+
 namespace {
 
 constexpr int S16_WAVES = 8;
 constexpr int S16_KU = 32;  // k-units of a 512-wide layer
-constexpr int S16_D = 4;    // weight prefetch distance (k-units)
+#ifndef S16_DEPTH
+#define S16_DEPTH 4
+#endif
+constexpr int S16_D = S16_DEPTH;  // weight prefetch distance (k-units)
 
 typedef __attribute__((address_space(3))) bf16x8 s16_lfrag;
 typedef const __attribute__((address_space(1))) bf16x8* s16_gfrag;

@@ -98,3 +98,55 @@ def test_weights_through_lds_forward_kernel_in_a_subprocess():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "not subprocess"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_w512_four_tile_kernels_in_a_subprocess():
+    """csrc/ncw_sdf16.hip picks T = 4 tiles per workgroup only for launches of >= 768 tiles (24,576 points); the W = 512
+    cases of this file and of test_gpu_sdf.py are small, so they are re-run with NCW_SDF16_T=4 (read once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("NCW_SDF16_T") is not None:
+        pytest.skip("already inside a variant run")
+    env = dict(os.environ, NCW_SDF16_T="4")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(here, "test_gpu_sdf.py"), "-q", "-x",
+                        "-k", "512 and not subprocess"], env=env, capture_output=True, text=True, cwd=os.path.dirname(here))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("prec_name", ["f16", "bf16"])
+def test_w512_large_ragged_launch_matches_small_launches(prec_name):
+    """30,011 points (ragged, T = 4 path) through sdf_fwd + sdf_bwd at W = 512 against the same points in chunks of 4,000
+    (T = 2 path): the two tilings run the same arithmetic per point, so the outputs agree to 16-bit rounding of the
+    weight-streaming order (identical: every point's reduction order is the same) -- bitwise."""
+    import neuralrecon_w_amd as nw
+    from neuralrecon_w_amd.neuconw import points_struct
+    from neuralrecon_w_amd.stash import StashCache
+    from tests.test_gpu_sdf import _mk
+
+    prec = {"bf16": nw.PREC_BF16, "f16": nw.PREC_F16}[prec_name]
+    net = _mk(512, 8, (4,), seed=3)
+    g = torch.Generator().manual_seed(1)
+    n = 30011
+    x = ((torch.rand(n, 3, generator=g) * 2 - 1) * 0.9).cuda()
+    w_sdf, w_grad = torch.randn(n, generator=g).cuda(), torch.randn(n, 3, generator=g).cuda()
+
+    def run(xs, ws, wg):
+        m = xs.shape[0]
+        sdf, grad, ctx = net.fwd_stash(points_struct(x=xs), m, prec)
+        feat = ctx["arena"].to_rows(ctx["ids"]["feat"], 512)
+        ctx["arena"].from_rows(ctx["ids"]["dfeat"], torch.zeros(m, 512, device="cuda"))
+        net.bwd_stash(ctx, ws, wg)
+        zbar = ctx["arena"].to_rows(ctx["ids"]["zbar"][3], 512)
+        out = (sdf.clone(), grad.clone(), feat.clone(), zbar.clone())
+        StashCache.release(ctx["lease"])
+        return out
+
+    big = run(x, w_sdf, w_grad)
+    parts = [run(x[i:i + 4000].contiguous(), w_sdf[i:i + 4000].contiguous(), w_grad[i:i + 4000].contiguous())
+             for i in range(0, n, 4000)]
+    for k, name in enumerate(("sdf", "grad", "feat", "zbar[3]")):
+        small = torch.cat([p[k] for p in parts], 0)
+        assert torch.equal(big[k], small), (name, float((big[k] - small).abs().max()))
