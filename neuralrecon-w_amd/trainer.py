@@ -221,7 +221,9 @@ class TrainStep:
 
     def _update(self):
         if self.native:
-            self.opt.step()  # clip + Adam + mark_updated
+            # clip + Adam + mark_updated.  The gradient norm stays on the device (no sync); a NON-FINITE norm makes
+            # ncw_adam_step skip the update (fp16 overflow guard) -- callers that log should look at it now and then
+            self.last_grad_norm = self.opt.step()
             return
         if self.clip is not None:
             torch.nn.utils.clip_grad_norm_([self.fp.flat], self.clip)  # train.py:61

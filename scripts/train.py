@@ -87,8 +87,11 @@ def main():
                                         optimizer=step_fn.opt, global_step=step)
             if rank == 0 and step % args.log_every == 0:
                 now = time.perf_counter()
-                print("epoch %d step %d  loss %.5f  s_val %.5f  (%.1f ms/step)"
-                      % (epoch, step, float(loss), float(out["s_val"]), 1e3 * (now - t_last) / max(1, args.log_every)))
+                gn = float(getattr(step_fn, "last_grad_norm", float("nan")))
+                print("epoch %d step %d  loss %.5f  s_val %.5f  |grad| %.4g  (%.1f ms/step)%s"
+                      % (epoch, step, float(loss), float(out["s_val"]), gn, 1e3 * (now - t_last) / max(1, args.log_every),
+                         "" if gn == gn and abs(gn) != float("inf") else
+                         "  <- non-finite gradient norm: this update was skipped (fp16 overflow? try --prec bf16)"))
                 t_last = now
             step += 1
             if args.max_steps and step >= args.max_steps:

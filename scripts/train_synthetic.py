@@ -60,7 +60,9 @@ def main():
             if rank == 0:
                 print("step %d: octree refreshed, %d fine voxels" % (it + 1, int(voxel.dense_from_occupancy(data).sum())))
         if rank == 0 and (it % 20 == 0 or it == start + args.steps - 1):
-            print("step %5d  loss %.5f  s_val %.4f" % (it, float(loss), float(out["s_val"])))
+            gn = float(getattr(step_fn, "last_grad_norm", float("nan")))
+            print("step %5d  loss %.5f  s_val %.4f  |grad| %.4g%s" % (it, float(loss), float(out["s_val"]), gn,
+                  "" if gn == gn and abs(gn) != float("inf") else "  <- non-finite: update skipped (fp16 overflow? try --prec bf16)"))
     torch.cuda.synchronize()
     if rank == 0:
         dt = time.perf_counter() - t0
