@@ -274,8 +274,10 @@ class NeuconWRenderer:
     def _sdf_rays(self, rays_o, rays_d, z):
         R, n = z.shape
         out = torch.empty(R, n, device=z.device, dtype=torch.float32)
-        plan = self.neuconw.sdf_net.packed(self.prec)
-        L.check(L.get_lib().ncw_sdf_infer_rays(plan.net, self.prec, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), R, n,
+        sp = self.__dict__.get("sampler_prec")  # None = the training precision; see scripts/diag/sampler_prec.py
+        sp = self.prec if sp is None else sp
+        plan = self.neuconw.sdf_net.packed(sp)
+        L.check(L.get_lib().ncw_sdf_infer_rays(plan.net, sp, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), R, n,
                                                L.ptr(out), L.stream_ptr(z.device)), "ncw_sdf_infer_rays")
         return out
 
