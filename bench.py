@@ -18,6 +18,8 @@ Prints ONE JSON line (rank 0) with the driver contract keys plus
                  script: FETCH_SIZE x 2 per MI355X_MICROARCH.md + WRITE_SIZE), `step_traffic_gb` = all kernels of a step;
   `parity_mode`  the same step in the fp32 parity mode (the <= 1e-4 mode), a few steps timed in the same process;
   `alt_mode`     the same step in the other 16-bit type (bf16 when --prec f16), timed in the same process;
+  `bg_elimination` the same step as the PRODUCT runs it by default: the background NeRF only where the compositor can use
+                 its output (identical results; `value` itself evaluates every sample like the reference);
   `cpu_baseline` the CPU oracle on the first 256 rays of the SAME batch, timed on this box.
 Secondary rows (never the reported metric): --config shipped | voxel (BASELINE configs[2]) | grid512 (configs[4]).
 """
@@ -295,6 +297,9 @@ def main():
     ap.add_argument("--rays", type=int, default=R_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--bg-eliminate", action="store_true",
+                    help="secondary: time the MAIN leg with dead-background elimination (the product default) instead of "
+                         "evaluating the background NeRF on every sample like the reference; marked in the metric name")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 parity-mode timing (`parity_mode`)")
     ap.add_argument("--inner", action="store_true", help="(internal) the short run the PMC passes profile: timing loop only")
     ap.add_argument("--grid-width", type=int, default=None, choices=[256, 512], help="--config grid512: SDF width (default 512)")
@@ -375,11 +380,14 @@ def main():
     rays, ts, label, rgbs = synth_batch(R, 1000 + rank, dev)
     n_boundary = 0
 
-    def make_step(prec_):
-        """models + TrainStep in precision prec_ -> step(i).  LR rule of train.py:21-25: 1e-4 * world*batch / 4096; Adam
+    def make_step(prec_, bg_dense=True):
+        """models + TrainStep in precision prec_ -> step(i).  bg_dense=True: the background NeRF on every one of the
+        S + O samples of a ray like the reference evaluates it (the timed `value`); False = the product default, which
+        skips the samples whose result the compositor multiplies by 0 (reported as `bg_elimination`).  LR rule of train.py:21-25: 1e-4 * world*batch / 4096; Adam
         eps 1e-7 (utils/__init__.py:24-31); clip 0.99 (train.py:61).  TrainStep = render + loss + backward + one flat
         all-reduce + clip + Adam (trainer.py)."""
         emb_, neuconw_, nerf_, rdr_ = build_models(dev, prec_)
+        rdr_.bg_dense = bg_dense
         if args.config == "voxel":  # configs[2]: coarse octree -> ray near/far; fine octree -> +-SAMPLE_RANGE window + boundary samples
             from neuralrecon_w_amd import voxel
 
@@ -401,7 +409,7 @@ def main():
     if args.config == "voxel":
         n_boundary = 10
         globals().update(N_BOUNDARY=10)
-    step, train, (emb, neuconw, nerf, rdr) = make_step(prec)
+    step, train, (emb, neuconw, nerf, rdr) = make_step(prec, bg_dense=not args.bg_eliminate)
 
     if args.graph:  # setup, not warm-up: 3 eager steps + the capture happen before the W warm-up steps
         for i in range(4):
@@ -502,7 +510,7 @@ def main():
 
     # ---- the fp32 parity mode (the <= 1e-4 mode, tests/test_gpu_render.py) timed in the same process ---------------
     parity = None
-    alt = None
+    alt = elim = None
     if not args.no_parity_mode and world == 1 and args.prec in ("bf16", "f16") and not args.graph:
         del train, step
         torch.cuda.empty_cache()
@@ -518,6 +526,27 @@ def main():
         d_a = (time.perf_counter() - t1) / args.steps
         alt = {"dtype": alt_name, "value": R * S / d_a, "unit": "ray-samples/s", "ms_per_step": d_a * 1e3, "steps": args.steps}
         del train_a, step_a
+        torch.cuda.empty_cache()
+        # the product default: dead-background elimination (renderer.py _RenderFn.forward) -- identical outputs and
+        # gradients (tests/test_gpu_bg_select.py), the NeRF evaluated only where the compositor can use it
+        step_e, train_e, (_, _, _, rdr_e) = make_step(prec, bg_dense=False)
+        for i in range(5):
+            step_e(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step_e(5 + i)
+        torch.cuda.synchronize()
+        d_e = (time.perf_counter() - t1) / args.steps
+        with torch.no_grad():
+            o_e = rdr_e.render(rays, ts, label, background_rgb=bg, cos_anneal_ratio=0.0)
+        elim = {"value": R * S / d_e, "unit": "ray-samples/s", "ms_per_step": d_e * 1e3, "steps": args.steps, "dtype": args.prec,
+                "inside_fraction": float(o_e["inside_sphere"].float().mean()),
+                "note": "background NeRF evaluated only on primary samples outside the unit sphere + the outside samples "
+                        "(the rest is multiplied by 1 - inside_sphere = 0 in the compositor, renderer.py:693-708); outputs "
+                        "bitwise identical, gradients to summation order; `value` above evaluates all S + O samples like "
+                        "the reference"}
+        del train_e, step_e, rdr_e, o_e
         torch.cuda.empty_cache()
         step32, train32, _ = make_step(nw.PREC_F32)
         for i in range(2):
@@ -545,7 +574,9 @@ def main():
         names = {"headline": "BASELINE.json configs[1]", "shipped": "shipped yaml shape, secondary",
                  "voxel": "BASELINE.json configs[2] (voxel-guided), secondary"}
         line = {
-            "metric": ("ray-samples/sec (train step) at 1024 rays x 128 samples" if args.config == "headline" else
+            "metric": ("ray-samples/sec (train step) at 1024 rays x 128 samples [secondary: dead-background elimination]"
+                       if args.bg_eliminate and args.config == "headline" else
+                       "ray-samples/sec (train step) at 1024 rays x 128 samples" if args.config == "headline" else
                        "ray-samples/sec (train step) at %d rays x %d samples [secondary shape]" % (R, S)), "value": value,
             "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -559,7 +590,7 @@ def main():
                        "world_size": world, "ranks": ranks,
                        "submission": "hip-graph replay" if args.graph else "eager",
                        "final_loss": float(loss.detach())},
-            "roofline": roofline, "parity_mode": parity, "alt_mode": alt, "cpu_baseline": cpu,
+            "roofline": roofline, "parity_mode": parity, "alt_mode": alt, "bg_elimination": elim, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

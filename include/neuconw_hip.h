@@ -138,13 +138,19 @@ typedef struct NcwPoints {
     const float* sample_dist;  /* mode 2: [R]                                                */
     int32_t per_ray;
     int32_t mode;              /* 0: x;  1: o + d z;  2: section mid-point o + d (z_i + dist_i/2);
-                                  3: regular grid generated on chip (utils/visualization.py:46-50)  */
+                                  3: regular grid generated on chip (utils/visualization.py:46-50);
+                                  4: a SELECTION of the mode-2 points: point k of the launch is ray sample idx[k]
+                                     (= ray * per_ray + i), only the first min(n, *count) are processed, outputs
+                                     and cotangents stay addressed by the ray sample (dense [R, per_ray] arrays), the
+                                     stashes by k (ncw_bg_select; background NeRF kernels at W = 256, 16-bit only) */
     /* mode 3: point p (+ grid_start) of linspace(gmin, gmax, gdim)^3, meshgrid 'ij' (x slowest),
      * mapped to the unit sphere as (x - gorigin) / gradius. */
     float gmin[3], gmax[3], gorigin[3], gradius;
     int32_t gdim;
     int32_t _gpad;
     int64_t gstart;
+    const int32_t* idx;        /* mode 4: DEVICE int32[n] ray-sample indices                               */
+    const int32_t* count;      /* mode 4: DEVICE int32[1] number of valid entries of idx                  */
 } NcwPoints;
 
 /* config 5 (tools/extract_mesh.py / utils/visualization.py:37-85): sdf of `count` points of the regular grid
@@ -308,6 +314,9 @@ typedef struct NcwWgradDesc {
     int32_t rbx, rby, ld;
     int32_t ksplit;    /* ncw_wgrad_tiled only: > 0 overrides the launch-wide split-K for this product */
     int64_t n_points;  /* ncw_wgrad_tiled only: > 0 overrides the launch-wide point count            */
+    const int32_t* n_points_dev; /* ncw_wgrad_tiled only: DEVICE int32[1] or NULL; the product covers the first
+                                  * min(n_points, *n_points_dev) points of its stashes (a selection made on the
+                                  * device, NcwPoints mode 4); the K-slices re-divide that count */
 } NcwWgradDesc;
 /* descs: DEVICE array; wg_prefix: device int32[n_desc+1] exclusive prefix of
  * ceil(rbx/4)*ceil(rby/4)*ksplit workgroups per product; total_wgs = wg_prefix[n_desc]. */
@@ -439,6 +448,15 @@ typedef struct NcwCompositeGrad {
                         * per-point adjoints the MLP backward kernels round to fp16 stay in its normal range; the caller
                         * divides it back out of the parameter gradients (NcwUnpackDesc.scale), d_a and d_inv_s */
 } NcwCompositeGrad;
+
+/* Dead-background elimination (renderer.py:637,693-708 with trim_sphere): the background NeRF's density / colour of a
+ * primary sample whose section mid-point lies INSIDE the unit sphere is multiplied by (1 - inside_sphere) = 0 in the
+ * compositor, forward and backward; only the other samples need the NeRF at all.  Writes the ray-sample indices
+ * (r * M + i, ray-major, ascending) of the samples to evaluate -- i < S with |o + d mid_i| >= 1 and every i >= S (the
+ * n_outside samples) -- into idx[R * M], the exclusive prefix of the per-ray counts into ray_offsets[R + 1] and their
+ * number into count[1].  z_feed [R, M] = [z | z_outside], M = S + O. */
+int ncw_bg_select(const float* rays_o, const float* rays_d, const float* z_feed, const float* sample_dist, int R, int S,
+                  int O, int32_t* idx, int32_t* ray_offsets, int32_t* count, void* stream);
 
 int ncw_composite_fwd(const NcwCompositeIn* in, const NcwCompositeOut* out, void* stream);
 int ncw_composite_bwd(const NcwCompositeIn* in, const NcwCompositeGrad* g, void* stream);

@@ -263,6 +263,7 @@ extern "C" int NCW_FN(ncw_color_fwd)(const NcwColorNet* net, int prec, const Ncw
                                      void* stream) {
     NCW_FORWARD_F16(prec, ncw_color_fwd_f16(net, NCW_PREC_BF16, pts, n, normals, a, feat_stash, rgb, stash, stream));
     if (!color_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
+    if (pts->mode == 4) return NCW_E_UNSUPPORTED;  // point selections: background NeRF kernels only
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     NCW_COLOR_DISPATCH(color_fwd_kernel, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
@@ -274,6 +275,7 @@ extern "C" int NCW_FN(ncw_color_bwd)(const NcwColorNet* net, int prec, const Ncw
                                      const NcwColorStash* stash, void* stream) {
     NCW_FORWARD_F16(prec, ncw_color_bwd_f16(net, NCW_PREC_BF16, pts, n, rgb, d_rgb, d_grad, d_a, d_a_rows, dfeat_stash, stash, stream));
     if (!color_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
+    if (pts->mode == 4) return NCW_E_UNSUPPORTED;  // point selections: background NeRF kernels only
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     NCW_COLOR_DISPATCH(color_bwd_kernel, *net, *pts, n, rgb, d_rgb, d_grad, d_a, d_a_rows, dfeat_stash, *stash);

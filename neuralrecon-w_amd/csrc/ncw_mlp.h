@@ -16,6 +16,14 @@ NCW_DEV float grid_linspace(float start, float end, int steps, int i) {  // torc
     return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
 }
 
+// mode 4: points of the launch = min(n, *count); where outputs / cotangents of launch point p live (the ray sample)
+NCW_DEV int64_t points_count(const NcwPoints& s, int64_t n) {
+    if (s.mode != 4) return n;
+    const int64_t c = (int64_t)s.count[0];
+    return c < n ? c : n;
+}
+NCW_DEV int64_t point_slot(const NcwPoints& s, int64_t p) { return s.mode == 4 ? (int64_t)s.idx[p] : p; }
+
 NCW_DEV void load_point(const NcwPoints& s, int64_t p, float (&xs)[3], int64_t& ray) {
     if (s.mode == 3) {
         const int64_t q = p + s.gstart;
@@ -32,10 +40,11 @@ NCW_DEV void load_point(const NcwPoints& s, int64_t p, float (&xs)[3], int64_t& 
         ray = p;
         return;
     }
+    if (s.mode == 4) p = s.idx[p];  // a selection of the mode-2 points (ncw_bg_select)
     const int64_t r = p / s.per_ray;
     ray = r;
     float zz = s.z[p];
-    if (s.mode == 2) {
+    if (s.mode == 2 || s.mode == 4) {
         const int i = (int)(p - r * s.per_ray);
         const float dist = (i + 1 < s.per_ray) ? s.z[p + 1] - zz : s.sample_dist[r];
         zz = zz + dist * 0.5f;

@@ -261,6 +261,7 @@ extern "C" int NCW_FN(ncw_nerf_fwd)(const NcwNerfNet* net, int prec, const NcwPo
                                     const float* a, float* density, float* rgb, const NcwNerfStash* stash, void* stream) {
     NCW_FORWARD_F16(prec, ncw_nerf_fwd_f16(net, NCW_PREC_BF16, pts, x4, n, a, density, rgb, stash, stream));
     if (!nerf_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
+    if (pts->mode == 4 && (!pts->idx || !pts->count || x4)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (0.33 vs 0.40 ms per 135,168 points);
@@ -268,6 +269,7 @@ extern "C" int NCW_FN(ncw_nerf_fwd)(const NcwNerfNet* net, int prec, const NcwPo
     static const int fwd8 = getenv("NCW_NERF_FWD8") ? atoi(getenv("NCW_NERF_FWD8")) : 1;
     if (fwd8 > 0 && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 && net->n_head <= 4)
         return NCW_FN(ncw_nerf_fwd8_launch)(net, *pts, x4, n, a, density, rgb, *stash, st);
+    if (pts->mode == 4) return NCW_E_UNSUPPORTED;  // point selections: the W = 256 16-bit kernels only
     NCW_NERF_DISPATCH(nerf_fwd_kernel, *net, *pts, x4, n, a, density, rgb, *stash);
     return 0;
 }
@@ -284,6 +286,7 @@ extern "C" int NCW_FN(ncw_nerf_bwd)(const NcwNerfNet* net, int prec, const NcwPo
     if (bwd8 > 0 && d_a_rows == nullptr && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 &&
         net->n_head <= 4)
         return NCW_FN(ncw_nerf_bwd8_launch)(net, *pts, n, d_density, d_rgb, d_a, *stash, st);
+    if (pts->mode == 4) return NCW_E_UNSUPPORTED;
     NCW_NERF_DISPATCH(nerf_bwd_kernel, *net, *pts, n, d_density, d_rgb, d_a, d_a_rows, *stash);
     return 0;
 }

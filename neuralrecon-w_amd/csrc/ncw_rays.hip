@@ -934,3 +934,101 @@ extern "C" int ncw_ray_tail_bwd(const float* weights_sum, const int64_t* label, 
     NCW_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Dead-background elimination: which ray samples need the background NeRF at all (include/neuconw_hip.h, ncw_bg_select).
+// Three small launches: (1) one wave per ray counts its samples to keep (ballot), (2) one workgroup turns the counts into
+// exclusive offsets, (3) one wave per ray writes its indices at its offset in sample order -- the list is ray-major and
+// ascending whatever the launch shape (deterministic).  ~15 us for 1024 x 132 samples (a first single-workgroup version
+// with one THREAD per ray took 250 us: uncoalesced reads of z).
+// ------------------------------------------------------------------------------------------------
+struct BgSel {
+    const float *rays_o, *rays_d, *z, *sample_dist;
+    int R, S, O;
+};
+
+// keep flag of sample i of ray r: the n_outside samples always; a primary sample iff the compositor's own inside_sphere
+// (composite_fwd_kernel: section mid-point of the PRIMARY z, the last section ends sample_dist further) is 0
+NCW_DEV bool bg_keep(const BgSel& A, int r, int i, const float (&o)[3], const float (&d)[3]) {
+    const int M = A.S + A.O;
+    if (i >= A.S) return i < M;
+    const float zi = A.z[(size_t)r * M + i];
+    const float dist = (i + 1 < A.S) ? A.z[(size_t)r * M + i + 1] - zi : A.sample_dist[r];
+    const float zz = zi + dist * 0.5f;
+    const float x = o[0] + d[0] * zz, y = o[1] + d[1] * zz, w = o[2] + d[2] * zz;
+    return !(sqrtf(x * x + y * y + w * w) < 1.0f);  // inside_sphere = (|p| < 1): renderer.py:637
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void bg_select_ray_kernel(BgSel A, int32_t* __restrict__ offs, int32_t* __restrict__ idx) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= A.R) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int M = A.S + A.O;
+    const float o[3] = {A.rays_o[r * 3], A.rays_o[r * 3 + 1], A.rays_o[r * 3 + 2]};
+    const float d[3] = {A.rays_d[r * 3], A.rays_d[r * 3 + 1], A.rays_d[r * 3 + 2]};
+    int at = WRITE ? offs[r] : 0;
+    for (int i0 = 0; i0 < M; i0 += 64) {
+        const int i = i0 + lane;
+        const bool keep = i < M && bg_keep(A, r, i, o, d);
+        const unsigned long long m = __ballot(keep);
+        if (WRITE && keep) idx[at + __popcll(m & ((1ull << lane) - 1ull))] = r * M + i;
+        at += __popcll(m);
+    }
+    if (!WRITE && lane == 0) offs[r] = at;
+}
+
+// offs[r] (counts) -> exclusive prefix, offs[R] = count[0] = total; one workgroup, rays in chunks of its size
+__global__ __launch_bounds__(1024) void bg_select_scan_kernel(int R, int32_t* __restrict__ offs, int32_t* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < R; r0 += blockDim.x) {
+        const int r = r0 + tid;
+        const int cnt = r < R ? offs[r] : 0;
+        int v = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(v, off, 64);
+            if (lane >= off) v += u;
+        }
+        if (lane == 63) wsum[wave] = v;
+        __syncthreads();
+        int wbase = 0, total = 0;
+        for (int w = 0; w < nw; ++w) {
+            if (w < wave) wbase += wsum[w];
+            total += wsum[w];
+        }
+        const int base = base_s;
+        if (r < R) offs[r] = base + wbase + v - cnt;
+        __syncthreads();
+        if (tid == 0) base_s = base + total;
+        __syncthreads();
+    }
+    if (tid == 0) { offs[R] = base_s; count[0] = base_s; }
+}
+
+extern "C" int ncw_bg_select(const float* rays_o, const float* rays_d, const float* z_feed, const float* sample_dist, int R,
+                             int S, int O, int32_t* idx, int32_t* ray_offsets, int32_t* count, void* stream) {
+    if (R < 0 || S < 0 || O < 0 || !idx || !count || !ray_offsets ||
+        (R > 0 && (!rays_o || !rays_d || !z_feed || !sample_dist)))
+        return NCW_E_BADARG;
+    if ((int64_t)R * (S + O) > 0x7fffffffLL) return NCW_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    BgSel A;
+    A.rays_o = rays_o; A.rays_d = rays_d; A.z = z_feed; A.sample_dist = sample_dist; A.R = R; A.S = S; A.O = O;
+    if (R > 0) {
+        hipLaunchKernelGGL(bg_select_ray_kernel<false>, dim3((R + 3) / 4), dim3(256), 0, st, A, ray_offsets, idx);
+        NCW_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(bg_select_scan_kernel, dim3(1), dim3(1024), 0, st, R, ray_offsets, count);
+    NCW_CHECK_LAUNCH();
+    if (R > 0) {
+        hipLaunchKernelGGL(bg_select_ray_kernel<true>, dim3((R + 3) / 4), dim3(256), 0, st, A, ray_offsets, idx);
+        NCW_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -421,6 +421,7 @@ static bool sdf16_on(const NcwSdfNet* net, int prec) {
 
 static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, int64_t n, float* sdf, void* stream) {
     if (!sdf_net_ok(net) || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
+    if (src.mode == 4) return NCW_E_UNSUPPORTED;  // point selections: background NeRF kernels only
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     // W = 256 bf16: variant 3 = the fine-interleaved kernel of ncw_pp.hip (default: 0.165 ms per 131,072 points),
@@ -473,6 +474,7 @@ extern "C" int NCW_FN(ncw_sdf_fwd)(const NcwSdfNet* net, int prec, const NcwPoin
                                    const NcwSdfStash* stash, void* stream) {
     NCW_FORWARD_F16(prec, ncw_sdf_fwd_f16(net, NCW_PREC_BF16, pts, n, sdf, grad, stash, stream));
     if (!sdf_net_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
+    if (pts->mode == 4) return NCW_E_UNSUPPORTED;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (0.57 vs 0.67 ms per 131,072 points);
@@ -489,6 +491,7 @@ extern "C" int NCW_FN(ncw_sdf_bwd)(const NcwSdfNet* net, int prec, const NcwPoin
                                    const float* d_grad, const NcwSdfStash* stash, void* stream) {
     NCW_FORWARD_F16(prec, ncw_sdf_bwd_f16(net, NCW_PREC_BF16, pts, n, d_sdf, d_grad, stash, stream));
     if (!sdf_net_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
+    if (pts->mode == 4) return NCW_E_UNSUPPORTED;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_bwd16_launch)(net, *pts, n, d_sdf, d_grad, *stash, st);

@@ -421,13 +421,15 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t tile0 = (int64_t)blockIdx.x * SB_TILES;
     const int D = net.D;
+    n = points_count(src, n);            // mode 4: the selection's size, read on the device
+    if (tile0 * 32 >= n) return;         // (uniform: before any barrier)
     int64_t pp = 0;
     bool pvalid = false;
     if (wave < SB_TILES) {
         int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
         pvalid = p < n;
         if (!pvalid) p = n - 1;
-        pp = p;
+        pp = point_slot(src, p);         // density / rgb are addressed by the ray sample
         float p4[4];
         if (x4) {
             p4[0] = x4[p * 4 + 0]; p4[1] = x4[p * 4 + 1]; p4[2] = x4[p * 4 + 2]; p4[3] = x4[p * 4 + 3];
@@ -661,10 +663,13 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
     const int D = net.D, NH = net.n_head;
     const int hb = wave & 3, hp = wave >> 2, ta = 2 * hp, tb = 2 * hp + 1;
     typedef const __attribute__((address_space(1))) bf16x8* gfrag;
+    n = points_count(src, n);            // mode 4: the selection's size, read on the device
+    if (tile0 * 32 >= n) return;         // (uniform: before any barrier)
     if (wave < SB_TILES) {
         int64_t p = (tile0 + wave) * 32 + (lane & 31);
         const bool valid = p < n;
         if (!valid) p = n - 1;
+        p = point_slot(src, p);          // d_density / d_rgb are addressed by the ray sample
         const float vm = valid ? 1.f : 0.f;
         CVec<1> zr, zal;
         cvec_zero(zr);
@@ -756,6 +761,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
             int64_t p = (tile0 + t) * 32 + (lane & 31);
             const bool valid = p < n;
             if (!valid) p = n - 1;
+            p = point_slot(src, p);
             const int64_t ray = (src.mode == 0) ? p : p / src.per_ray;
             sb_accumulate_d_a(b, qa, d_a, ray, net.n_a, valid, lane);
         }

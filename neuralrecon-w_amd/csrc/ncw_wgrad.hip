@@ -241,6 +241,10 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const NcwWgradDesc* __re
     const int local = blockIdx.x - prefix[d];
     if (D.ksplit > 0) ksplit = D.ksplit;                    // per-product split (load balancing)
     if (D.n_points > 0) ntiles = (D.n_points + 31) / 32;    // per-product point count (merged launches)
+    if (D.n_points_dev != nullptr) {                        // a selection sized on the device (NcwPoints mode 4):
+        const int64_t nt = ((int64_t)D.n_points_dev[0] + 31) / 32;  // the K-slices re-divide the tiles that exist
+        ntiles = nt < ntiles ? nt : ntiles;
+    }
     const int quad = local / ksplit, ks = local - quad * ksplit;
     const int nqj = (D.rby + YB - 1) / YB;
     const int qi = quad / nqj, qj = quad - qi * nqj;

@@ -15,7 +15,7 @@ PREC_BF16 = 1
 PREC_F16 = 2  # fp16 operands, f32 accumulate; backward needs the loss scale (renderer.grad_scale)
 MAX_LAYERS = 12
 MAX_SEGS = 4
-ABI_VERSION = 7  # 6: ray prologue / inv_s / loss launches, NcwCompositeOut.weights_max;  5: ncw_scatter_add_rows;  4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
+ABI_VERSION = 8  # 8: NcwPoints mode 4 (idx / count), NcwWgradDesc.n_points_dev, ncw_bg_select;  7: fp16 (prec 2), grad_scale / grad_mul;  6: ray prologue / inv_s / loss launches, NcwCompositeOut.weights_max;  5: ncw_scatter_add_rows;  4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
 
 
 class NcwSeg(C.Structure):
@@ -54,7 +54,8 @@ class NcwPoints(C.Structure):
     _fields_ = [("x", C.c_void_p), ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("z", C.c_void_p),
                 ("sample_dist", C.c_void_p), ("per_ray", C.c_int32), ("mode", C.c_int32),
                 ("gmin", C.c_float * 3), ("gmax", C.c_float * 3), ("gorigin", C.c_float * 3), ("gradius", C.c_float),
-                ("gdim", C.c_int32), ("_gpad", C.c_int32), ("gstart", C.c_int64)]
+                ("gdim", C.c_int32), ("_gpad", C.c_int32), ("gstart", C.c_int64),
+                ("idx", C.c_void_p), ("count", C.c_void_p)]
 
 
 class NcwSdfStash(C.Structure):
@@ -67,7 +68,7 @@ class NcwSdfStash(C.Structure):
 class NcwWgradDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dense", C.c_void_p), ("dbias", C.c_void_p),
                 ("rbx", C.c_int32), ("rby", C.c_int32), ("ld", C.c_int32), ("ksplit", C.c_int32),
-                ("n_points", C.c_int64)]
+                ("n_points", C.c_int64), ("n_points_dev", C.c_void_p)]
 
 
 class NcwColorNet(C.Structure):
@@ -177,6 +178,7 @@ _PROTOS = {
     "ncw_upsample": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_float, C.c_int, _VP, _VP]),
     "ncw_sort_merge": (C.c_int, [_VP, C.c_int, _VP, C.c_int, _VP, _VP, C.c_int, _VP, _VP, _VP]),
     "ncw_boundary": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP]),
+    "ncw_bg_select": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP]),
     "ncw_composite_fwd": (C.c_int, [C.POINTER(NcwCompositeIn), C.POINTER(NcwCompositeOut), _VP]),
     "ncw_composite_bwd": (C.c_int, [C.POINTER(NcwCompositeIn), C.POINTER(NcwCompositeGrad), _VP]),
     "ncw_abi_version": (C.c_int, []),

@@ -90,7 +90,19 @@ class NeRF(_PackedNet):
         plan.net, plan.slots = net, sl
         return plan
 
-    def fwd_stash(self, pts, n, prec, a, x4=None):
+    def supports_selection(self, prec):
+        """Point selections (NcwPoints mode 4, dead-background elimination) exist in the W = 256 16-bit kernels only."""
+        import os
+
+        if os.environ.get("NCW_NERF_FWD8", "1") == "0" or os.environ.get("NCW_NERF_BWD8", "1") == "0":
+            return False  # the weights-through-LDS kernels were asked for: they take whole launches only
+        return prec != L.PREC_F32 and self.W == 256 and 1 <= self.n_head <= 4
+
+    def fwd_stash(self, pts, n, prec, a, x4=None, select=None):
+        """select = (S, O): pts are the R x (S + O) mode-2 samples of z_feed; evaluate only those the compositor can use --
+        primary samples (i < S) outside the unit sphere and the O outside samples (ncw_bg_select).  density / rgb stay
+        dense [n] (zero where skipped: the compositor selects, never multiplies, there); the stashes are compact and the
+        weight-gradient products are sized by the device count ctx["sel_count"]."""
         dev = self._first_param().device
         plan = self.packed(prec)
         RBN, RBH = self.W // 32, self.W // 64
@@ -116,14 +128,34 @@ class NeRF(_PackedNet):
 
         ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev)), build)
         ar, ids, st = ent["arena"], ent["ids"], ent["stash"]
-        density = torch.empty(n, device=dev, dtype=torch.float32)
-        rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
+        sel_count = None
+        if select is not None:
+            S_, O_ = select
+            assert x4 is None and pts.mode == 2 and pts.per_ray == S_ + O_ and self.supports_selection(prec)
+            if "sel_idx" not in ent:  # per lease: the weight-gradient table caches the count's address
+                ent["sel_idx"] = torch.empty(n, device=dev, dtype=torch.int32)
+                ent["sel_count"] = torch.zeros(1, device=dev, dtype=torch.int32)
+                ent["sel_offs"] = torch.empty(n // (S_ + O_) + 1, device=dev, dtype=torch.int32)
+            sel_count = ent["sel_count"]
+            L.check(L.get_lib().ncw_bg_select(pts.rays_o, pts.rays_d, pts.z, pts.sample_dist, n // (S_ + O_), S_, O_,
+                                              L.ptr(ent["sel_idx"]), L.ptr(ent["sel_offs"]), L.ptr(sel_count),
+                                              L.stream_ptr(dev)), "ncw_bg_select")
+            keep_src = pts
+            pts = points_struct(mode=4, idx=ent["sel_idx"], count=sel_count)
+            pts.rays_o, pts.rays_d, pts.z, pts.sample_dist = keep_src.rays_o, keep_src.rays_d, keep_src.z, keep_src.sample_dist
+            pts.per_ray = keep_src.per_ray
+            pts._keep = pts._keep + [keep_src]
+            density = torch.zeros(n, device=dev, dtype=torch.float32)
+            rgb = torch.zeros(n, 3, device=dev, dtype=torch.float32)
+        else:
+            density = torch.empty(n, device=dev, dtype=torch.float32)
+            rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
         a = a.contiguous().float()
         x4c = x4.contiguous().float() if x4 is not None else None
         L.check(L.get_lib().ncw_nerf_fwd(plan.net, prec, pts, L.ptr(x4c), n, L.ptr(a), L.ptr(density), L.ptr(rgb), st,
                                          L.stream_ptr(dev)), "ncw_nerf_fwd")
         return density, rgb, dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, keep=(a, x4c),
-                                  lease=ent)
+                                  lease=ent, sel_count=sel_count)
 
     def bwd_stash(self, ctx, d_density, d_rgb, d_a, d_a_rows=None):
         """d_a [R,n_a] accumulates with atomics -- or, with d_a_rows [n,n_a], every point's row is stored instead

@@ -15,8 +15,9 @@ from .packing import PackPlan
 from .stash import StashArena, StashCache, WgradBatch
 
 
-def points_struct(x=None, rays_o=None, rays_d=None, z=None, sample_dist=None, mode=0):
-    """Build the NcwPoints host struct (keeps the tensors alive on the returned object)."""
+def points_struct(x=None, rays_o=None, rays_d=None, z=None, sample_dist=None, mode=0, idx=None, count=None):
+    """Build the NcwPoints host struct (keeps the tensors alive on the returned object).  mode 4: a device-made selection
+    (idx int32 [n], count int32 [1]) of the mode-2 ray samples (rayops.bg_select)."""
     p = L.NcwPoints()
     keep = []
 
@@ -30,6 +31,10 @@ def points_struct(x=None, rays_o=None, rays_d=None, z=None, sample_dist=None, mo
     p.x, p.rays_o, p.rays_d, p.z, p.sample_dist = _p(x), _p(rays_o), _p(rays_d), _p(z), _p(sample_dist)
     p.per_ray = int(z.shape[1]) if z is not None else 1
     p.mode = mode
+    if mode == 4:
+        assert idx.dtype == torch.int32 and count.dtype == torch.int32 and idx.is_contiguous()
+        keep += [idx, count]
+        p.idx, p.count = idx.data_ptr(), count.data_ptr()
     p._keep = keep
     return p
 

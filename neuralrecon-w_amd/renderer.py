@@ -47,7 +47,16 @@ class _RenderFn(torch.autograd.Function):
             z_feed, _ = rayops.sort_merge(z, z_out)
             pts_bg = points_struct(rays_o=rays_o, rays_d=rays_d, z=z_feed, sample_dist=sample_dist, mode=2)
             M = z_feed.shape[1]
-            density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det)
+            # Dead-background elimination: with trim_sphere the compositor takes the background NeRF only where a primary
+            # sample's section mid-point is OUTSIDE the unit sphere (renderer.py:637,693-708: everything else is
+            # multiplied by 1 - inside_sphere = 0, forward and backward) and at the n_outside samples; the reference
+            # evaluates the NeRF on all S + O samples all the same.  Identical outputs and gradients; bg_dense=True
+            # evaluates everything like the reference.  (z_feed = [z | z_out]: the outside samples start beyond far.)
+            ordered_ = rdr.reproducible if rdr.reproducible is not None else (prec == L.PREC_F32)
+            select = None
+            if rdr.trim_sphere and not rdr.bg_dense and not ordered_ and nerf.supports_selection(prec):
+                select = (S, M - S)
+            density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select)
             density, bg_rgb = density.view(R, M), bg_rgb.view(R, M, 3)
         pts_in = points_struct(rays_o=rays_o, rays_d=rays_d, z=z, sample_dist=sample_dist, mode=2)
         sdf, grad, sctx = neuconw.sdf_net.fwd_stash(pts_in, R * S, prec)
@@ -115,7 +124,9 @@ class _RenderFn(torch.autograd.Function):
             plans.append(nctx["plan"])
         # every weight-gradient product of the step (SDF, colour, background NeRF) in ONE launch; the product
         # list only depends on the (cached) stash arenas: build it once per lease combination
-        tag = (cctx["arena"].buf.data_ptr(), nctx["arena"].buf.data_ptr() if ctx.use_bg else None, prec)
+        sel = nctx.get("sel_count") if ctx.use_bg else None
+        tag = (cctx["arena"].buf.data_ptr(), nctx["arena"].buf.data_ptr() if ctx.use_bg else None, prec,
+               None if sel is None else sel.data_ptr())
         batch = sctx["lease"].get("wgrad_batch")
         if batch is None or batch.tag != tag:
             batch = WgradBatch(dev, prec, R * S)
@@ -123,7 +134,7 @@ class _RenderFn(torch.autograd.Function):
             neuconw.sdf_net.add_wgrads(sctx, batch)
             neuconw.color_net.add_wgrads(cctx, batch)
             if ctx.use_bg:
-                b_bg = WgradBatch(dev, prec, R * (comp.S + comp.O))
+                b_bg = WgradBatch(dev, prec, R * (comp.S + comp.O), n_dev=nctx.get("sel_count"))
                 nerf.add_wgrads(nctx, b_bg)
                 batch.extend(b_bg)
             sctx["lease"]["wgrad_batch"] = batch
@@ -261,6 +272,9 @@ class NeuconWRenderer:
                              "ray's samples in LDS (RAY_MAXN 512).  Note config/defaults.py's N_SAMPLES = N_IMPORTANCE = "
                              "512 is overridden by every shipped scene yaml (8 + 16)."
                              % (self.n_samples + self.n_importance + (self.boundary_samples or 0) + self.n_outside))
+        # bg_dense=True: evaluate the background NeRF on every sample like the reference does, instead of only where the
+        # compositor can use it (dead-background elimination, _RenderFn.forward); NEUCONW_BG_DENSE=1 sets the default
+        self.bg_dense = os.environ.get("NEUCONW_BG_DENSE", "0") not in ("0", "")
         # loss scale of the fp16 mode (prec = PREC_F16; unused otherwise): a power of two, see _RenderFn.backward
         self.grad_scale = float(os.environ.get("NEUCONW_F16_LOSS_SCALE", "1024"))
         # sync_free=True keeps render() free of device->host synchronisations (see sfm_depth_loss below);

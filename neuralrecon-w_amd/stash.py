@@ -63,18 +63,23 @@ class WgradBatch:
 
     TARGET_WGS = 768
 
-    def __init__(self, device, prec, n_points):
+    def __init__(self, device, prec, n_points, n_dev=None):
+        """n_dev: device int32[1] -- the products cover only the first min(n_points, n_dev[0]) points of their stashes (a
+        selection made on the device, NcwPoints mode 4; 16-bit tiled launch only)."""
         self.device = torch.device(device)
         self.prec = prec
         self.n = int(n_points)
+        self.n_dev = 0 if n_dev is None else int(n_dev.data_ptr())
+        self._keep_dev = n_dev
         self.items = []
 
     def add(self, x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr=0, n=None):
-        self.items.append((x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr, self.n if n is None else int(n)))
+        self.items.append((x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr, self.n if n is None else int(n), self.n_dev))
 
     def extend(self, other):
         """Take over another batch's products (they keep their own point count)."""
         self.items.extend(other.items)
+        self.__dict__.setdefault("_keep_other", []).append(other._keep_dev)
 
     _scratch = {}  # device -> K-slice slabs of the ordered (fp32) weight-gradient launches
     _cache = {}  # content-addressed device tables: (items, prec, tile) -> (table, prefix, n_desc, wgs, ksplit, n)
@@ -90,11 +95,14 @@ class WgradBatch:
         if hit is None:
             xb, yb = (4, 4) if tile is None else ((4, 8) if tile == 0 else (8, 8))
             descs, prefix = [], [0]
-            for (x, rbx, y, rby, dense, ld, db, ni), ksp in zip(items, ksplits):
+            for (x, rbx, y, rby, dense, ld, db, ni, ndev), ksp in zip(items, ksplits):
                 d = L.NcwWgradDesc()
                 d.x, d.y, d.dense, d.dbias = x, y, dense, db
                 d.rbx, d.rby, d.ld = rbx, rby, ld
                 d.ksplit, d.n_points = (ksp, ni) if tile is not None else (0, 0)
+                if ndev:
+                    assert tile is not None, "device-sized products need the 16-bit tiled launch"
+                    d.n_points_dev = ndev
                 descs.append(d)
                 prefix.append(prefix[-1] + ((rbx + xb - 1) // xb) * ((rby + yb - 1) // yb) * ksp)
             arr = (L.NcwWgradDesc * len(descs))(*descs)

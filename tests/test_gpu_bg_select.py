@@ -1,0 +1,104 @@
+"""GPU: dead-background elimination (ncw_bg_select + NcwPoints mode 4 + NcwWgradDesc.n_points_dev).  With trim_sphere the
+compositor multiplies the background NeRF's output of a primary sample inside the unit sphere by 1 - inside_sphere = 0
+(/root/reference rendering/renderer.py:637,693-708), forward and backward, so the 16-bit modes evaluate the NeRF only
+where it can matter.  Nothing observable may change: rendered outputs bitwise, parameter gradients to summation order."""
+import pytest
+import torch
+
+from tests._build import build_system, loss_from_outputs, named_params
+from tests._util import rel_err, synth_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays_crossing_the_sphere(R, seed):
+    """rays whose sampled interval [near, far] leaves the unit sphere on both ends for many samples"""
+    rays, ts, label, rgbs = synth_rays(R, seed, 64)
+    rays = rays.clone()
+    rays[:, 6] = 0.6   # near: |o + d z| ~ 1.4 -> outside
+    rays[:, 7] = 3.6   # far:  ~1.6 -> outside
+    return rays, ts, label, rgbs
+
+
+def test_selection_list_matches_torch():
+    from neuralrecon_w_amd import lib as L
+
+    R, S, O = 1500, 37, 4  # more rays than one pass of the kernel's workgroup (1024)
+    g = torch.Generator().manual_seed(3)
+    o = torch.tensor([0.0, 0.0, -2.0]) + 0.1 * torch.randn(R, 3, generator=g)
+    d = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.1 * torch.randn(R, 3, generator=g), dim=-1)
+    z = torch.sort(0.6 + 3.0 * torch.rand(R, S, generator=g), dim=-1).values
+    z_out = z[:, -1:] + 0.5 + torch.sort(torch.rand(R, O, generator=g), dim=-1).values
+    sd = torch.full((R,), 3.0 / S)
+    zf = torch.cat([z, z_out], -1)
+    dist = torch.cat([z[:, 1:] - z[:, :-1], sd[:, None]], -1)
+    mid = z + dist * 0.5
+    inside = (o[:, None, :] + d[:, None, :] * mid[..., None]).norm(dim=-1) < 1.0
+    need = torch.cat([~inside, torch.ones(R, O, dtype=torch.bool)], -1)
+    want = torch.nonzero(need.reshape(-1)).reshape(-1).int()
+    oc, dc, zc, sc = o.cuda(), d.cuda(), zf.cuda().contiguous(), sd.cuda()
+    idx = torch.full((R * (S + O),), -1, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    offs = torch.empty(R + 1, dtype=torch.int32, device="cuda")
+    L.check(L.get_lib().ncw_bg_select(L.ptr(oc), L.ptr(dc), L.ptr(zc), L.ptr(sc), R, S, O, L.ptr(idx), L.ptr(offs), L.ptr(cnt),
+                                      L.stream_ptr(oc.device)), "ncw_bg_select")
+    n = int(cnt)
+    assert int(offs[0]) == 0 and int(offs[R]) == n and bool((offs[1:] - offs[:-1] >= O).all())
+    # a mid-point within rounding of |p| = 1 may fall either way between torch's norm and the kernel's sqrt: allow a few
+    got = idx[:n].cpu()
+    sym = set(got.tolist()) ^ set(want.tolist())
+    assert len(sym) <= 4, (n, want.numel(), sorted(sym)[:10])
+    assert bool((got[1:] > got[:-1]).all()), "ray-major, ascending"
+    assert 0.05 < float(inside.float().mean()) < 0.95  # the case exercises both branches
+
+
+@pytest.mark.parametrize("prec_name", ["f16", "bf16"])
+def test_elimination_changes_nothing(prec_name):
+    import neuralrecon_w_amd as nw
+
+    prec = {"f16": nw.PREC_F16, "bf16": nw.PREC_BF16}[prec_name]
+    res = {}
+    for dense in (True, False):
+        emb, neuconw, nerf, rdr = build_system(W=256, n_a=48, n_vocab=64, nerf_w=256, color_hidden=256, head=128, seed=5,
+                                               prec=prec, n_samples=32, n_importance=32)
+        rdr.bg_dense = dense
+        rays, ts, label, rgbs = _rays_crossing_the_sphere(96, 7)
+        out = rdr.render(rays.cuda(), ts.cuda(), label.cuda(), perturb_overwrite=0, background_rgb=torch.zeros(1, 3).cuda(),
+                         cos_anneal_ratio=0.3)
+        loss = loss_from_outputs(out, rgbs.cuda())
+        loss.backward()
+        res[dense] = (out, float(loss), {k: p.grad.detach().clone() for k, p in named_params(emb, neuconw, nerf).items()
+                                         if p.grad is not None})
+    (od, ld, gd), (oe, le, ge) = res[True], res[False]
+    ins = od["inside_sphere"]
+    frac = float(ins.float().mean())
+    assert 0.1 < frac < 0.95, frac  # both kinds of primary samples present
+    for k in ("color", "depth", "weights_sum", "weights", "color_bg", "gradient_error"):
+        assert torch.equal(od[k], oe[k]), (k, float((od[k] - oe[k]).abs().max()))
+    assert ld == le
+    worst = max(rel_err(ge[k], gd[k]) for k in gd)
+    print("%s: inside fraction %.2f, worst parameter-gradient difference dense vs eliminated %.2e" % (prec_name, frac, worst))
+    assert set(gd) == set(ge) and worst < 2e-5, worst  # f32 atomics of the weight-gradient slices: summation order only
+
+
+def test_selection_is_refused_elsewhere():
+    """mode-4 points reach only the W = 256 16-bit background kernels: every other entry point refuses them loudly"""
+    import neuralrecon_w_amd as nw
+    from neuralrecon_w_amd import lib as L
+    from neuralrecon_w_amd.neuconw import points_struct
+    from tests.test_gpu_sdf import _mk
+
+    net = _mk(64, 8, (4,))
+    idx = torch.zeros(64, dtype=torch.int32, device="cuda")
+    cnt = torch.ones(1, dtype=torch.int32, device="cuda")
+    z = torch.rand(2, 32, device="cuda")
+    pts = points_struct(rays_o=torch.zeros(2, 3, device="cuda"), rays_d=torch.ones(2, 3, device="cuda"), z=z,
+                        sample_dist=torch.ones(2, device="cuda"), mode=2)
+    pts4 = points_struct(mode=4, idx=idx, count=cnt)
+    pts4.rays_o, pts4.rays_d, pts4.z, pts4.sample_dist, pts4.per_ray = pts.rays_o, pts.rays_d, pts.z, pts.sample_dist, 32
+    plan = net.packed(nw.PREC_BF16)
+    out = torch.empty(64, device="cuda")
+    rc = L.get_lib().ncw_sdf_infer_points(plan.net, nw.PREC_BF16, pts4, 64, L.ptr(out), L.stream_ptr(out.device))
+    assert rc == -2  # NCW_E_UNSUPPORTED
+    emb, neuconw, nerf, rdr = build_system(seed=1, prec=nw.PREC_F32)  # W = 64 background net, fp32
+    assert not nerf.supports_selection(nw.PREC_F32) and not nerf.supports_selection(nw.PREC_F16)
