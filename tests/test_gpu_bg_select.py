@@ -102,3 +102,28 @@ def test_selection_is_refused_elsewhere():
     assert rc == -2  # NCW_E_UNSUPPORTED
     emb, neuconw, nerf, rdr = build_system(seed=1, prec=nw.PREC_F32)  # W = 64 background net, fp32
     assert not nerf.supports_selection(nw.PREC_F32) and not nerf.supports_selection(nw.PREC_F16)
+
+
+def test_elimination_under_graph_capture():
+    """TrainStep(capture=True) in the fp16 mode: the selection, the device-sized launches and the zero-filled dense outputs
+    inside a HIP graph replay like the eager step."""
+    import neuralrecon_w_amd as nw
+
+    R, steps = 64, 6
+    rays, ts, label, rgbs = [t.cuda() for t in _rays_crossing_the_sphere(R, 12)]
+    bg = torch.zeros(1, 3, device="cuda")
+    curves = []
+    for capture in (False, True):
+        emb, neuconw, nerf, rdr = build_system(W=256, n_a=48, n_vocab=64, nerf_w=256, color_hidden=256, head=128, seed=6,
+                                               prec=nw.PREC_F16, n_samples=16, n_importance=16)
+        rdr.sync_free = True
+        assert nerf.supports_selection(nw.PREC_F16) and not rdr.bg_dense
+        train = nw.TrainStep(rdr, [emb, neuconw, nerf], loss_from_outputs, lr=1e-3, eps=1e-7, clip=0.99, capture=capture,
+                             capture_warmup=3)
+        curves.append([float(train(rays, ts, label, rgbs, background_rgb=bg, cos_anneal_ratio=0.1 * i, perturb_overwrite=0)[0])
+                       for i in range(steps)])
+        if capture:
+            assert train._graphs is not None
+    for a, b in zip(*curves):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), curves  # 16-bit runs separate through Adam's sign steps
+    assert curves[0][-1] < curves[0][0]
