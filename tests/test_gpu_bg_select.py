@@ -31,10 +31,10 @@ def test_selection_list_matches_torch():
     z_out = z[:, -1:] + 0.5 + torch.sort(torch.rand(R, O, generator=g), dim=-1).values
     sd = torch.full((R,), 3.0 / S)
     zf = torch.cat([z, z_out], -1)
-    dist = torch.cat([z[:, 1:] - z[:, :-1], sd[:, None]], -1)
-    mid = z + dist * 0.5
-    inside = (o[:, None, :] + d[:, None, :] * mid[..., None]).norm(dim=-1) < 1.0
-    need = torch.cat([~inside, torch.ones(R, O, dtype=torch.bool)], -1)
+    from oracle import neuconw_oracle as Or
+
+    need = Or.bg_needed(o, d, z, sd, O)  # pinned to the reference's inside_sphere (tests/test_reference_bg_is_dead.py)
+    inside = ~need[:, :S]
     want = torch.nonzero(need.reshape(-1)).reshape(-1).int()
     oc, dc, zc, sc = o.cuda(), d.cuda(), zf.cuda().contiguous(), sd.cuda()
     idx = torch.full((R * (S + O),), -1, dtype=torch.int32, device="cuda")
