@@ -62,6 +62,7 @@ class WgradBatch:
     (scripts/bench_wgrad.py: 5.2 TB/s of stash bytes, against 4.3 TB/s for one launch per network/shape).  f32: the exact kernel, one launch per point count."""
 
     TARGET_WGS = 768
+    SEL_FRACTION = 0.125
 
     def __init__(self, device, prec, n_points, n_dev=None):
         """n_dev: device int32[1] -- the products cover only the first min(n_points, n_dev[0]) points of their stashes (a
@@ -124,7 +125,11 @@ class WgradBatch:
             def cost(it):
                 # a quad costs the same whatever its real block count (missing blocks are re-reads of a
                 # valid one, L2 hits): weighting by HBM bytes instead measured 1.55 ms vs 1.02 ms per step
-                return (it[7] + 31) // 32
+                tiles = (it[7] + 31) // 32
+                # a product sized on the device (dead-background elimination) is planned at SEL_FRACTION of its stash:
+                # the split only balances the launch, the kernel clamps to the real count (95 % of the primary samples
+                # of the bench batch are inside the sphere: 7 % of the S + O samples remain)
+                return max(1, int(tiles * self.SEL_FRACTION)) if it[8] else tiles
             total = sum(cost(it) * quads(it) for it in items)
             per_wg = max(1.0, total / self.TARGET_WGS)
             ksplits = []
