@@ -499,6 +499,8 @@ def main():
             inner_steps, inner_warm = 3, 2
             inner = ["--inner", "--steps", str(inner_steps), "--warmup", str(inner_warm), "--prec", args.prec, "--rays", str(R),
                      "--config", args.config, "--no-cpu-baseline", "--no-pmc", "--no-parity-mode"]
+            if args.bg_eliminate:
+                inner.append("--bg-eliminate")
             per_kernel, step_bytes = pmc_traffic(inner, inner_steps + inner_warm)
             if per_kernel:
                 sel = [v for k, v in per_kernel.items() if PMC_KERNEL.get(dom, "\0") in k]
