@@ -449,13 +449,14 @@ typedef struct NcwCompositeGrad {
                         * divides it back out of the parameter gradients (NcwUnpackDesc.scale), d_a and d_inv_s */
 } NcwCompositeGrad;
 
-/* Dead-background elimination (renderer.py:637,693-708 with trim_sphere): the background NeRF's density / colour of a
- * primary sample whose section mid-point lies INSIDE the unit sphere is multiplied by (1 - inside_sphere) = 0 in the
- * compositor, forward and backward; only the other samples need the NeRF at all.  Writes the ray-sample indices
- * (r * M + i, ray-major, ascending) of the samples to evaluate -- i < S with |o + d mid_i| >= 1 and every i >= S (the
- * n_outside samples) -- into idx[R * M], the exclusive prefix of the per-ray counts into ray_offsets[R + 1] and their
- * number into count[1].  z_feed [R, M] = [z | z_outside], M = S + O. */
-int ncw_bg_select(const float* rays_o, const float* rays_d, const float* z_feed, const float* sample_dist, int R, int S,
+/* Dead-background elimination (renderer.py:637,693-708 with trim_sphere): the background NeRF's density / colour in
+ * column i < S of the [R, S + O] background arrays is multiplied by 1 - inside_sphere[i] in the compositor, forward and
+ * backward, where inside_sphere[i] belongs to PRIMARY sample i (section mid-point of z [R, S], the last section ending
+ * sample_dist further) -- an index pairing, wherever the i-th point of z_feed lies; only the other columns need the NeRF
+ * at all.  Writes the ray-sample indices (r * M + i, M = S + O, ray-major, ascending) of the columns to evaluate -- i < S
+ * with inside_sphere[i] == 0 and every i >= S (the n_outside samples) -- into idx[R * M], the exclusive prefix of the
+ * per-ray counts into ray_offsets[R + 1] and their number into count[1]. */
+int ncw_bg_select(const float* rays_o, const float* rays_d, const float* z, const float* sample_dist, int R, int S,
                   int O, int32_t* idx, int32_t* ray_offsets, int32_t* count, void* stream);
 
 int ncw_composite_fwd(const NcwCompositeIn* in, const NcwCompositeOut* out, void* stream);

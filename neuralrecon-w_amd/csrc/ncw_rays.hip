@@ -953,8 +953,10 @@ struct BgSel {
 NCW_DEV bool bg_keep(const BgSel& A, int r, int i, const float (&o)[3], const float (&d)[3]) {
     const int M = A.S + A.O;
     if (i >= A.S) return i < M;
-    const float zi = A.z[(size_t)r * M + i];
-    const float dist = (i + 1 < A.S) ? A.z[(size_t)r * M + i + 1] - zi : A.sample_dist[r];
+    // A.z = the PRIMARY z [R, S]: the compositor pairs column i < S of the background arrays with primary sample i by
+    // INDEX (background_alpha[:, :n_samples] * (1 - inside_sphere), renderer.py:693), wherever z_feed's i-th point lies
+    const float zi = A.z[(size_t)r * A.S + i];
+    const float dist = (i + 1 < A.S) ? A.z[(size_t)r * A.S + i + 1] - zi : A.sample_dist[r];
     const float zz = zi + dist * 0.5f;
     const float x = o[0] + d[0] * zz, y = o[1] + d[1] * zz, w = o[2] + d[2] * zz;
     return !(sqrtf(x * x + y * y + w * w) < 1.0f);  // inside_sphere = (|p| < 1): renderer.py:637
@@ -1011,15 +1013,15 @@ __global__ __launch_bounds__(1024) void bg_select_scan_kernel(int R, int32_t* __
     if (tid == 0) { offs[R] = base_s; count[0] = base_s; }
 }
 
-extern "C" int ncw_bg_select(const float* rays_o, const float* rays_d, const float* z_feed, const float* sample_dist, int R,
+extern "C" int ncw_bg_select(const float* rays_o, const float* rays_d, const float* z, const float* sample_dist, int R,
                              int S, int O, int32_t* idx, int32_t* ray_offsets, int32_t* count, void* stream) {
     if (R < 0 || S < 0 || O < 0 || !idx || !count || !ray_offsets ||
-        (R > 0 && (!rays_o || !rays_d || !z_feed || !sample_dist)))
+        (R > 0 && (!rays_o || !rays_d || (S > 0 && !z) || !sample_dist)))
         return NCW_E_BADARG;
     if ((int64_t)R * (S + O) > 0x7fffffffLL) return NCW_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     BgSel A;
-    A.rays_o = rays_o; A.rays_d = rays_d; A.z = z_feed; A.sample_dist = sample_dist; A.R = R; A.S = S; A.O = O;
+    A.rays_o = rays_o; A.rays_d = rays_d; A.z = z; A.sample_dist = sample_dist; A.R = R; A.S = S; A.O = O;
     if (R > 0) {
         hipLaunchKernelGGL(bg_select_ray_kernel<false>, dim3((R + 3) / 4), dim3(256), 0, st, A, ray_offsets, idx);
         NCW_CHECK_LAUNCH();

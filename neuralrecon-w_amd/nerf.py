@@ -99,8 +99,9 @@ class NeRF(_PackedNet):
         return prec != L.PREC_F32 and self.W == 256 and 1 <= self.n_head <= 4
 
     def fwd_stash(self, pts, n, prec, a, x4=None, select=None):
-        """select = (S, O): pts are the R x (S + O) mode-2 samples of z_feed; evaluate only those the compositor can use --
-        primary samples (i < S) outside the unit sphere and the O outside samples (ncw_bg_select).  density / rgb stay
+        """select = (z, O): pts are the R x (S + O) mode-2 samples of z_feed, z [R, S] the primary samples; evaluate only the
+        columns the compositor can use -- i < S where primary sample i is outside the unit sphere, and the O outside
+        samples (ncw_bg_select).  density / rgb stay
         dense [n] (zero where skipped: the compositor selects, never multiplies, there); the stashes are compact and the
         weight-gradient products are sized by the device count ctx["sel_count"]."""
         dev = self._first_param().device
@@ -130,21 +131,23 @@ class NeRF(_PackedNet):
         ar, ids, st = ent["arena"], ent["ids"], ent["stash"]
         sel_count = None
         if select is not None:
-            S_, O_ = select
+            z_prim, O_ = select
+            z_prim = z_prim.contiguous().float()
+            S_ = int(z_prim.shape[1])
             assert x4 is None and pts.mode == 2 and pts.per_ray == S_ + O_ and self.supports_selection(prec)
             if "sel_idx" not in ent:  # per lease: the weight-gradient table caches the count's address
                 ent["sel_idx"] = torch.empty(n, device=dev, dtype=torch.int32)
                 ent["sel_count"] = torch.zeros(1, device=dev, dtype=torch.int32)
                 ent["sel_offs"] = torch.empty(n // (S_ + O_) + 1, device=dev, dtype=torch.int32)
             sel_count = ent["sel_count"]
-            L.check(L.get_lib().ncw_bg_select(pts.rays_o, pts.rays_d, pts.z, pts.sample_dist, n // (S_ + O_), S_, O_,
+            L.check(L.get_lib().ncw_bg_select(pts.rays_o, pts.rays_d, L.ptr(z_prim), pts.sample_dist, n // (S_ + O_), S_, O_,
                                               L.ptr(ent["sel_idx"]), L.ptr(ent["sel_offs"]), L.ptr(sel_count),
                                               L.stream_ptr(dev)), "ncw_bg_select")
             keep_src = pts
             pts = points_struct(mode=4, idx=ent["sel_idx"], count=sel_count)
             pts.rays_o, pts.rays_d, pts.z, pts.sample_dist = keep_src.rays_o, keep_src.rays_d, keep_src.z, keep_src.sample_dist
             pts.per_ray = keep_src.per_ray
-            pts._keep = pts._keep + [keep_src]
+            pts._keep = pts._keep + [keep_src, z_prim]
             density = torch.zeros(n, device=dev, dtype=torch.float32)
             rgb = torch.zeros(n, 3, device=dev, dtype=torch.float32)
         else:

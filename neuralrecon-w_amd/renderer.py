@@ -51,11 +51,11 @@ class _RenderFn(torch.autograd.Function):
             # sample's section mid-point is OUTSIDE the unit sphere (renderer.py:637,693-708: everything else is
             # multiplied by 1 - inside_sphere = 0, forward and backward) and at the n_outside samples; the reference
             # evaluates the NeRF on all S + O samples all the same.  Identical outputs and gradients; bg_dense=True
-            # evaluates everything like the reference.  (z_feed = [z | z_out]: the outside samples start beyond far.)
+            # evaluates everything like the reference.  (Columns are paired with primary samples by index, as there.)
             ordered_ = rdr.reproducible if rdr.reproducible is not None else (prec == L.PREC_F32)
             select = None
             if rdr.trim_sphere and not rdr.bg_dense and not ordered_ and nerf.supports_selection(prec):
-                select = (S, M - S)
+                select = (z, M - S)
             density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select)
             density, bg_rgb = density.view(R, M), bg_rgb.view(R, M, 3)
         pts_in = points_struct(rays_o=rays_o, rays_d=rays_d, z=z, sample_dist=sample_dist, mode=2)

@@ -28,15 +28,13 @@ def test_selection_list_matches_torch():
     o = torch.tensor([0.0, 0.0, -2.0]) + 0.1 * torch.randn(R, 3, generator=g)
     d = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.1 * torch.randn(R, 3, generator=g), dim=-1)
     z = torch.sort(0.6 + 3.0 * torch.rand(R, S, generator=g), dim=-1).values
-    z_out = z[:, -1:] + 0.5 + torch.sort(torch.rand(R, O, generator=g), dim=-1).values
     sd = torch.full((R,), 3.0 / S)
-    zf = torch.cat([z, z_out], -1)
     from oracle import neuconw_oracle as Or
 
     need = Or.bg_needed(o, d, z, sd, O)  # pinned to the reference's inside_sphere (tests/test_reference_bg_is_dead.py)
     inside = ~need[:, :S]
     want = torch.nonzero(need.reshape(-1)).reshape(-1).int()
-    oc, dc, zc, sc = o.cuda(), d.cuda(), zf.cuda().contiguous(), sd.cuda()
+    oc, dc, zc, sc = o.cuda(), d.cuda(), z.cuda().contiguous(), sd.cuda()  # the PRIMARY z: columns pair by index
     idx = torch.full((R * (S + O),), -1, dtype=torch.int32, device="cuda")
     cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
     offs = torch.empty(R + 1, dtype=torch.int32, device="cuda")
