@@ -424,8 +424,8 @@ static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, i
     if (src.mode == 4) return NCW_E_UNSUPPORTED;  // point selections: background NeRF kernels only
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    // W = 256 bf16: variant 3 = the fine-interleaved kernel of ncw_pp.hip (default: 0.165 ms per 131,072 points),
-    // 2 = the weights-stationary burst kernel of ncw_sdf8.hip (0.170 ms with the polynomial Softplus, 0.198 before it),
+    // W = 256, 16-bit: variant 3 = the fine-interleaved kernel of ncw_pp.hip (default: 0.165-0.175 ms per 131,072 points),
+    // 2 = the weights-stationary burst kernel of ncw_sdf8.hip (0.198 ms),
     // 0 = the weights-through-LDS kernel below (0.26 ms).
     static const int variant8 = getenv("NCW_SDF_INFER8") ? atoi(getenv("NCW_SDF_INFER8")) : 3;
     if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_infer16_launch)(net, src, n, sdf, st);
