@@ -20,7 +20,9 @@ Prints ONE JSON line (rank 0) with the driver contract keys plus
   `alt_mode`     the same step in the other 16-bit type (bf16 when --prec f16), timed in the same process;
   `bg_elimination` the same step as the PRODUCT runs it by default: the background NeRF only where the compositor can use
                  its output (identical results; `value` itself evaluates every sample like the reference);
-  `cpu_baseline` the CPU oracle on the first 256 rays of the SAME batch, timed on this box.
+  `cpu_baseline` the CPU oracle on the first 256 rays of the SAME batch, timed on this box;
+  `parity`       the measured error of the timed program: GPU render + loss of those 256 rays in the timed dtype vs the
+                 oracle, at the initial operating point and at inv_s = 403 (where NeuS trains), fp32 mode beside it.
 Secondary rows (never the reported metric): --config shipped | voxel (BASELINE configs[2]) | grid512 (configs[4]).
 """
 import argparse
@@ -132,24 +134,37 @@ def kernel_flops(R):
     }
 
 
+ORACLE_CFG = None
+
+
+def _oracle_setup(sample_rays, seed, variance=None):
+    """The oracle's inputs for the first `sample_rays` rays of rank 0's timed batch: the same networks (same seed, same
+    initial weights as build_models on the GPU), optionally with SingleVarianceNetwork.variance overridden."""
+    emb, neuconw, nerf, _ = build_models("cpu", 0)
+    sd = {"embedding_a.weight": emb.weight.detach()}
+    sd.update({"neuconw." + k: v.detach() for k, v in neuconw.state_dict().items() if not k.startswith("xyz_enc")})
+    sd.update({"nerf." + k: v.detach() for k, v in nerf.state_dict().items()})
+    if variance is not None:
+        sd["neuconw.deviation_network.variance"] = torch.tensor(float(variance))
+    cfg = dict(n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, n_outside=N_OUTSIDE, up_sample_steps=UP_STEPS,
+               s_val_base=S_VAL_BASE, render_bg=True, trim_sphere=True, mesh_mask_list=["sky"], depth_loss=True,
+               igr_weight=1e-4, mask_weight=0.1, depth_weight=0.1, skip_in=(4,), multires=6, multires_view=4)
+    batch = [t[:sample_rays] for t in synth_batch(R_PER_GPU, seed, "cpu")]  # rank 0's batch, first rays
+    return sd, cfg, batch
+
+
 def cpu_baseline(sample_rays=256, repeats=2, max_threads=32, seed=1000):
     """The CPU oracle (oracle/neuconw_oracle.py, pinned to the real reference by tests/golden) timed on
-    this box's host cores on a bounded sample of the same workload (same nets, same sampler shape)."""
+    this box's host cores on a bounded sample of the same workload (same nets, same sampler shape).
+    Returns (cpu_baseline dict, reference outputs of that sample for the `parity` object)."""
     from oracle import neuconw_oracle as O
 
     # torch's intra-op pool stops scaling (and thrashes) far below a 256-core host's core count at this
     # problem size: use at most `max_threads` threads and report exactly that number as `cores`.
     cores = min(os.cpu_count() or 1, max_threads)
     torch.set_num_threads(cores)
-    emb, neuconw, nerf, _ = build_models("cpu", 0)
-    sd = {"embedding_a.weight": emb.weight.detach()}
-    sd.update({"neuconw." + k: v.detach() for k, v in neuconw.state_dict().items() if not k.startswith("xyz_enc")})
-    sd.update({"nerf." + k: v.detach() for k, v in nerf.state_dict().items()})
+    sd, cfg, (rays, ts, label, rgbs) = _oracle_setup(sample_rays, seed)
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
-    cfg = dict(n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, n_outside=N_OUTSIDE, up_sample_steps=UP_STEPS,
-               s_val_base=S_VAL_BASE, render_bg=True, trim_sphere=True, mesh_mask_list=["sky"], depth_loss=True,
-               igr_weight=1e-4, mask_weight=0.1, depth_weight=0.1, skip_in=(4,), multires=6, multires_view=4)
-    rays, ts, label, rgbs = [t[:sample_rays] for t in synth_batch(R_PER_GPU, seed, "cpu")]  # rank 0's batch, first rays
     times = []
     for i in range(repeats + 1):
         t0 = time.perf_counter()
@@ -159,10 +174,57 @@ def cpu_baseline(sample_rays=256, repeats=2, max_threads=32, seed=1000):
         times.append(time.perf_counter() - t0)
     t = sorted(times[1:])[len(times[1:]) // 2]
     S = N_SAMPLES + N_IMPORTANCE
+    ref = {k: out[k].detach() for k in ("color", "depth", "weights_sum")}
+    ref["loss"] = float(loss.detach())
     return {"value": sample_rays * S / t, "unit": "ray-samples/s", "cores": cores, "kind": "port",
             "sample": "the first %d rays of the timed %d-ray batch x %d samples (BASELINE.md 3), same networks / sampler, "
-                      "fp32 torch-CPU oracle, render+loss+backward, median of %d after 1 warm-up (%.2f s/step)"
-                      % (sample_rays, R_PER_GPU, S, repeats, t)}
+                      "fp32 torch-CPU oracle (the analytic-adjoint restatement: 6 M_sdf per sample where the reference's "
+                      "double forward + autograd.grad spends ~9 M_sdf, SURVEY 8d -- this flatters the CPU side slightly), "
+                      "render+loss+backward, median of %d after 1 warm-up (%.2f s/step)"
+                      % (sample_rays, R_PER_GPU, S, repeats, t)}, ref
+
+
+def oracle_outputs(sample_rays=256, seed=1000, variance=None):
+    """Forward-only oracle evaluation of the same sample (fp64), optionally at another variance (inv_s = exp(10 variance))."""
+    from oracle import neuconw_oracle as O
+
+    sd, cfg, (rays, ts, label, rgbs) = _oracle_setup(sample_rays, seed, variance)
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    with torch.no_grad():
+        out = O.render(sd, cfg, rays.double(), ts, label, 0.5, torch.zeros(1, 3, dtype=torch.float64))
+        loss = O.neuconw_loss(out, rgbs.double(), cfg)
+    ref = {k: out[k] for k in ("color", "depth", "weights_sum")}
+    ref["loss"] = float(loss)
+    return ref
+
+
+def gpu_outputs(dev, prec, sample_rays=256, seed=1000, variance=None):
+    """The product's render + loss of the same sample, same (initial) weights, in the TIMED precision, deterministic
+    sampling (perturb 0) like the oracle leg."""
+    emb, neuconw, nerf, rdr = build_models(dev, prec)
+    if variance is not None:
+        with torch.no_grad():
+            neuconw.deviation_network.variance.fill_(float(variance))
+    rays, ts, label, rgbs = [t[:sample_rays] for t in synth_batch(R_PER_GPU, seed, dev)]
+    with torch.no_grad():
+        out = rdr.render(rays, ts, label, perturb_overwrite=0, background_rgb=torch.zeros(1, 3, device=dev),
+                         cos_anneal_ratio=0.5)
+        loss = loss_fn_torch(out, rgbs)
+    got = {k: out[k].detach().cpu() for k in ("color", "depth", "weights_sum")}
+    got["loss"] = float(loss)
+    return got
+
+
+def _rel(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def parity_errors(got, ref):
+    """max |gpu - oracle| / max |oracle| per output (the north star's '1e-4 rel' measure) + the loss difference."""
+    e = {"colour": _rel(got["color"], ref["color"]), "depth": _rel(got["depth"], ref["depth"]),
+         "weights_sum": _rel(got["weights_sum"], ref["weights_sum"]), "loss": abs(got["loss"] - ref["loss"])}
+    return {k: float("%.3g" % v) for k, v in e.items()}
 
 
 # entry point -> substring of the kernel name the PMC passes report it under
@@ -294,7 +356,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--prec", default="f16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--rays", type=int, default=R_PER_GPU)
+    ap.add_argument("--rays", type=int, default=None,
+                    help="rays per GPU (default 1024 = the metric's batch; --config shipped: 2048 = scripts/train.sh:16-19)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--bg-eliminate", action="store_true",
@@ -331,6 +394,8 @@ def main():
         os.execvp(sys.executable, cmd)
     if args.config == "shipped":  # config/train_brandenburg_gate.yaml: SDF 8x512, N_SAMPLES 8, N_IMPORTANCE 16
         globals().update(W_SDF=512, N_SAMPLES=8, N_IMPORTANCE=16, M_SDF=2097664, M_SDF1=1835520, M_COL=585344)
+    if args.rays is None:  # the reference's recipe trains 2048 rays per GPU (scripts/train.sh:16-19)
+        args.rays = 2048 if args.config == "shipped" else R_PER_GPU
 
     import neuralrecon_w_amd as nw
     from neuralrecon_w_amd import lib as L
@@ -566,11 +631,28 @@ def main():
                           % (roofline["step_algorithmic_tflop"] / d32 / 157.3 if roofline else float("nan"))}
 
     cpu = None
+    parity_obj = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline()
+            cpu, ref32 = cpu_baseline()
         except Exception as e:  # the baseline must never take the bench line down
-            cpu = {"value": None, "unit": "ray-samples/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+            cpu, ref32 = {"value": None, "unit": "ray-samples/s", "cores": os.cpu_count(), "kind": "port",
+                          "sample": "failed: %r" % (e,)}, None
+        # ---- measured error of the program that was timed: the GPU render + loss of the oracle leg's 256 rays (same
+        # batch, same initial weights, deterministic sampling) in the TIMED dtype, against the oracle -- at the initial
+        # operating point (variance 0.3, inv_s 20) and where NeuS trains (variance 0.6: inv_s = exp(6) = 403)
+        if ref32 is not None and args.config == "headline":
+            try:
+                parity_obj = {"dtype": args.prec, "rays": 256, "measure": "max|gpu - oracle| / max|oracle| (loss: absolute)",
+                              "oracle": "fp32 torch-CPU oracle of the cpu_baseline leg (inv_s 20); fp64 oracle at inv_s 403"}
+                parity_obj.update(parity_errors(gpu_outputs(dev, prec), ref32))
+                ref_t = oracle_outputs(variance=0.6)
+                parity_obj["at_inv_s_403"] = parity_errors(gpu_outputs(dev, prec, variance=0.6), ref_t)
+                if prec != nw.PREC_F32:
+                    parity_obj["f32_mode"] = parity_errors(gpu_outputs(dev, nw.PREC_F32), ref32)
+                    parity_obj["f32_mode_at_inv_s_403"] = parity_errors(gpu_outputs(dev, nw.PREC_F32, variance=0.6), ref_t)
+            except Exception as e:
+                parity_obj = {"dtype": args.prec, "error": "failed: %r" % (e,)}
 
     if rank == 0:
         names = {"headline": "BASELINE.json configs[1]", "shipped": "shipped yaml shape, secondary",
@@ -592,7 +674,8 @@ def main():
                        "world_size": world, "ranks": ranks,
                        "submission": "hip-graph replay" if args.graph else "eager",
                        "final_loss": float(loss.detach())},
-            "roofline": roofline, "parity_mode": parity, "alt_mode": alt, "bg_elimination": elim, "cpu_baseline": cpu,
+            "roofline": roofline, "parity": parity_obj, "parity_mode": parity, "alt_mode": alt, "bg_elimination": elim,
+            "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

@@ -94,6 +94,7 @@ typedef struct NcwUnpackDesc {
     int32_t accumulate;  /* 1: add into d_* (torch .grad accumulation), 0: overwrite     */
     int32_t nseg;
     NcwSeg seg[NCW_MAX_SEGS];
+    const float* grad_mul_dev; /* device scalar multiplied on top of grad_mul (the dynamic 1 / loss scale) or NULL */
 } NcwUnpackDesc;
 int ncw_unpack_grads(const NcwUnpackDesc* descs, const int32_t* row_prefix, int n, int total_rows,
                      void* stream);
@@ -354,6 +355,30 @@ int ncw_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
                   float beta1, float beta2, float eps, float bias_correction2_sqrt, const float* total_norm,
                   float max_norm, void* stream);
 
+/* The same update with every step-dependent quantity on the DEVICE (trainer.FlatAdam): `state` holds the applied-step
+ * counter and the scalars derived from it, so a skipped step does not advance Adam's bias correction, nothing is a
+ * per-step kernel argument (HIP-graph capturable), and the fp16 loss scale adapts without a device->host round trip.
+ * Two launches: a one-thread prologue that reads total_norm (device scalar or NULL) and updates `state` / `loss_scale`,
+ * then the elementwise update.
+ *   finite norm:  step += 1; coef = max_norm > 0 ? min(max_norm / (norm + 1e-6), 1) : 1; step_size = lr / (1 - beta1^step)
+ *                 and bc2_sqrt = sqrt(1 - beta2^step) in double; after `growth_interval` consecutive finite steps the loss
+ *                 scale doubles (<= scale_max);
+ *   non-finite:   nothing is written to param / grad / moments, step stays, skipped += 1, the loss scale halves (>= scale_min).
+ * loss_scale: device float[2] = {scale, 1 / scale} (read by NcwCompositeGrad.grad_scale_dev / NcwUnpackDesc.grad_mul_dev) or
+ * NULL; growth_interval 0 = never grow.  lr_dev: device scalar overriding `lr` (schedulers under graph replay) or NULL.
+ * The reference's recipe has no counterpart for the scale (fp32 training, train.py:48-62). */
+typedef struct NcwAdamState {
+    int32_t step;      /* applied (non-skipped) steps: Adam's t */
+    int32_t good;      /* consecutive finite steps since the last scale change */
+    int32_t skipped;   /* total skipped steps */
+    int32_t skip_now;  /* 1: the step being applied was skipped */
+    float coef, step_size, bc2_sqrt, last_norm;
+} NcwAdamState;
+int ncw_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, NcwAdamState* state,
+                      const float* total_norm, float lr, const float* lr_dev, float beta1, float beta2, float eps,
+                      float max_norm, float* loss_scale, int growth_interval, float scale_min, float scale_max,
+                      void* stream);
+
 /* Layout converters between row-major f32 [n, F] and the stash layout (rb = ceil(F/32) blocks,
  * element type by prec).  Used at the module boundary (NeuconW.forward returning feature vectors,
  * tests); padded lanes / features are written as zero. */
@@ -447,6 +472,7 @@ typedef struct NcwCompositeGrad {
     float grad_scale;  /* multiplies every upstream cotangent on load (0 = 1): the fp16 mode's loss scale, so that the
                         * per-point adjoints the MLP backward kernels round to fp16 stay in its normal range; the caller
                         * divides it back out of the parameter gradients (NcwUnpackDesc.scale), d_a and d_inv_s */
+    const float* grad_scale_dev; /* device scalar multiplied on top of grad_scale (the dynamic loss scale) or NULL */
 } NcwCompositeGrad;
 
 /* Dead-background elimination (renderer.py:637,693-708 with trim_sphere): the background NeRF's density / colour in

@@ -28,7 +28,7 @@ DEFAULTS = {
                                  "SEMANTIC_MAP_PATH": "semantic_maps", "WITH_SEMANTICS": True}},
     "TRAINER": {"WORLD_SIZE": 1, "CANONICAL_BS": 2048, "CANONICAL_LR": 1e-3, "SCALING": None, "SAVE_DIR": "checkpoints",
                 "VAL_FREQ": 0.125, "SAVE_FREQ": 5000, "OPTIMIZER": "adam", "LR": None, "WEIGHT_DECAY": 0,
-                "LR_SCHEDULER": "cosine", "SEED": 66},
+                "LR_SCHEDULER": "cosine", "DECAY_STEP": [], "DECAY_GAMMA": 0.1, "SEED": 66},
 }
 
 
@@ -70,6 +70,27 @@ def scale_lr(cfg, world_size, batch_size):
     t["SCALING"] = t["TRUE_BATCH_SIZE"] / t["CANONICAL_BS"]
     t["LR"] = t["CANONICAL_LR"] * t["SCALING"]
     return t["LR"]
+
+
+def lr_at_epoch(cfg, base_lr, epoch, num_epochs):
+    """The learning rate the reference's scheduler (utils/__init__.py:45-61 `get_scheduler`, stepped once per epoch by
+    PyTorch-Lightning) holds DURING epoch `epoch` (0-based):
+      'none'   -> base_lr (every shipped scene yaml);
+      'cosine' -> CosineAnnealingLR(T_max=num_epochs, eta_min=1e-8) in closed form;
+      'steplr' -> MultiStepLR(milestones=DECAY_STEP, gamma=DECAY_GAMMA);
+      'poly'   -> upstream raises NameError (LambdaLR is never imported, POLY_EXP is not in config/defaults.py)."""
+    import math
+
+    t = cfg["TRAINER"]
+    kind = t.get("LR_SCHEDULER", "none")
+    if kind in (None, "none"):
+        return base_lr
+    if kind == "cosine":
+        eta_min = 1e-8
+        return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * epoch / max(1, num_epochs))) / 2.0
+    if kind == "steplr":
+        return base_lr * float(t.get("DECAY_GAMMA", 0.1)) ** sum(1 for m in (t.get("DECAY_STEP") or []) if epoch >= m)
+    raise NotImplementedError("TRAINER.LR_SCHEDULER = %r (the reference itself fails on 'poly': LambdaLR is not imported)" % (kind,))
 
 
 def build_system(cfg, device, prec=None):

@@ -50,6 +50,101 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, f
     }
 }
 
+// ---- device-resident optimiser state (NcwAdamState): applied-step counter, bias corrections, clip coefficient and the
+// fp16 loss scale all live on the device, so (a) a skipped (non-finite) step does not advance the bias-correction
+// step, (b) the loss scale backs off / grows without a device->host round trip, (c) the whole update is HIP-graph
+// capturable (nothing step-dependent is a kernel argument).
+__global__ void adam_prep_kernel(NcwAdamState* __restrict__ st, const float* __restrict__ total_norm, float lr,
+                                 const float* __restrict__ lr_dev, float beta1, float beta2, float max_norm,
+                                 float* __restrict__ loss_scale, int growth_interval, float scale_min, float scale_max) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float tn = total_norm ? total_norm[0] : 0.f;
+    const bool finite = tn < __builtin_inff() && tn == tn;
+    if (!finite) {
+        st->skip_now = 1;
+        st->skipped += 1;
+        st->good = 0;
+        if (loss_scale) {  // back off: halve (a power of two stays exact), never below scale_min
+            const float s = fmaxf(loss_scale[0] * 0.5f, scale_min);
+            loss_scale[0] = s;
+            loss_scale[1] = 1.f / s;
+        }
+        return;
+    }
+    st->skip_now = 0;
+    const int t = st->step + 1;
+    st->step = t;
+    st->good += 1;
+    if (loss_scale && growth_interval > 0 && st->good >= growth_interval) {
+        const float s = fminf(loss_scale[0] * 2.f, scale_max);
+        loss_scale[0] = s;
+        loss_scale[1] = 1.f / s;
+        st->good = 0;
+    }
+    const double l = lr_dev ? (double)lr_dev[0] : (double)lr;
+    // torch's non-capturable path computes both corrections in double on the host (_single_tensor_adam)
+    const double bc1 = 1.0 - pow((double)beta1, (double)t);
+    const double bc2 = 1.0 - pow((double)beta2, (double)t);
+    st->step_size = (float)(l / bc1);
+    st->bc2_sqrt = (float)sqrt(bc2);
+    st->coef = (total_norm && max_norm > 0.f) ? fminf(max_norm / (tn + 1e-6f), 1.f) : 1.f;  // clip_grad_norm_
+    st->last_norm = tn;
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, int64_t n, float beta1, float beta2, float eps,
+                                                       const NcwAdamState* __restrict__ st) {
+    if (st->skip_now) return;  // nothing is written: one overflowed fp16 step must not poison parameters and moments
+    const float coef = st->coef, step_size = st->step_size, bc2_sqrt = st->bc2_sqrt;
+    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+    if (i4 + 4 <= n) {
+        f32x4 pp = *reinterpret_cast<f32x4*>(p + i4), gg = *reinterpret_cast<f32x4*>(g + i4);
+        f32x4 mm = *reinterpret_cast<f32x4*>(m + i4), vv = *reinterpret_cast<f32x4*>(v + i4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gc = gg[c] * coef;
+            gg[c] = gc;
+            mm[c] = mm[c] + w1 * (gc - mm[c]);
+            vv[c] = vv[c] * beta2 + w2 * gc * gc;
+            const float denom = sqrtf(vv[c]) / bc2_sqrt + eps;
+            pp[c] = pp[c] - step_size * (mm[c] / denom);
+        }
+        *reinterpret_cast<f32x4*>(p + i4) = pp;
+        *reinterpret_cast<f32x4*>(g + i4) = gg;
+        *reinterpret_cast<f32x4*>(m + i4) = mm;
+        *reinterpret_cast<f32x4*>(v + i4) = vv;
+    } else {
+        for (int64_t i = i4; i < n; ++i) {
+            const float gc = g[i] * coef;
+            g[i] = gc;
+            const float mi = m[i] + w1 * (gc - m[i]);
+            const float vi = v[i] * beta2 + w2 * gc * gc;
+            m[i] = mi;
+            v[i] = vi;
+            p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        }
+    }
+}
+
+extern "C" int ncw_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, NcwAdamState* state,
+                                 const float* total_norm, float lr, const float* lr_dev, float beta1, float beta2, float eps,
+                                 float max_norm, float* loss_scale, int growth_interval, float scale_min, float scale_max,
+                                 void* stream) {
+    if (n <= 0) return 0;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !state) return NCW_E_BADARG;
+    if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return NCW_E_BADARG;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, total_norm, lr, lr_dev, beta1, beta2,
+                       max_norm, loss_scale, growth_interval, scale_min, scale_max);
+    NCW_CHECK_LAUNCH();
+    const int64_t quads = (n + 3) / 4;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, state);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int ncw_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float step_size,
                              float beta1, float beta2, float eps, float bias_correction2_sqrt, const float* total_norm,
                              float max_norm, void* stream) {

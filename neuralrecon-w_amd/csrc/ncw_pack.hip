@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(const NcwUnpackDesc* __rest
     const float* drow = D.dw + (size_t)(D.drow0 + i) * D.ldw;
     const float* vrow = D.src + (size_t)row * D.ld;
     float* out = D.d_src + (size_t)row * D.ld;
-    const float gm = D.grad_mul != 0.f ? D.grad_mul : 1.0f;
+    const float gm = (D.grad_mul != 0.f ? D.grad_mul : 1.0f) * (D.grad_mul_dev ? D.grad_mul_dev[0] : 1.0f);
     const float scale = D.scale * gm;
     const int accumulate = D.accumulate;
     if (D.g == nullptr) {
@@ -209,7 +209,7 @@ extern "C" int ncw_stash_to_rows(int prec, const void* stash, int64_t n, int F, 
     return 0;
 }
 
-extern "C" int ncw_abi_version(void) { return 8; }
+extern "C" int ncw_abi_version(void) { return 9; }
 
 extern "C" int ncw_device_info(char* buf, int buflen) {
     int cnt = 0;

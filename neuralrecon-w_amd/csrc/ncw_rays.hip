@@ -412,6 +412,7 @@ struct CompBwd {
     const float *d_color, *d_wsum, *d_depth, *d_eik;
     float *d_sdf, *d_grad, *d_rgb, *d_density, *d_bg_rgb, *d_inv_s;
     float grad_scale;  // every upstream cotangent is multiplied by it on load (fp16 loss scaling; a power of two is exact)
+    const float* grad_scale_dev;  // dynamic part of the scale (device scalar) or nullptr
 };
 
 // suffix-exclusive sum: out[i] = sum_{k>i} a[k]
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs A, CompBwd 
     const float dx = A.rays_d[r * 3], dy = A.rays_d[r * 3 + 1], dz = A.rays_d[r * 3 + 2];
     const float inv_s = A.inv_s[0], sdist = A.sample_dist[r], c = A.cos_anneal_dev ? A.cos_anneal_dev[0] : A.cos_anneal;
     const float* zr = A.z + (size_t)r * S;
-    const float gs = G.grad_scale;
+    const float gs = G.grad_scale_dev ? G.grad_scale * G.grad_scale_dev[0] : G.grad_scale;
     const float dcr = G.d_color[r * 3] * gs, dcg = G.d_color[r * 3 + 1] * gs, dcb = G.d_color[r * 3 + 2] * gs;
     float dws = G.d_wsum[r] * gs;
     if (A.background_rgb)
@@ -692,6 +693,7 @@ extern "C" int ncw_composite_bwd(const NcwCompositeIn* in, const NcwCompositeGra
     G.d_sdf = g->d_sdf; G.d_grad = g->d_grad; G.d_rgb = g->d_rgb; G.d_density = g->d_density; G.d_bg_rgb = g->d_bg_rgb;
     G.d_inv_s = g->d_inv_s;
     G.grad_scale = g->grad_scale != 0.f ? g->grad_scale : 1.0f;
+    G.grad_scale_dev = g->grad_scale_dev;
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((in->R + 3) / 4), dim3(256), 0, (hipStream_t)stream, A, G);
     NCW_CHECK_LAUNCH();
     return 0;

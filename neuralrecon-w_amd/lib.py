@@ -15,7 +15,7 @@ PREC_BF16 = 1
 PREC_F16 = 2  # fp16 operands, f32 accumulate; backward needs the loss scale (renderer.grad_scale)
 MAX_LAYERS = 12
 MAX_SEGS = 4
-ABI_VERSION = 8  # 8: NcwPoints mode 4 (idx / count), NcwWgradDesc.n_points_dev, ncw_bg_select;  7: fp16 (prec 2), grad_scale / grad_mul;  6: ray prologue / inv_s / loss launches, NcwCompositeOut.weights_max;  5: ncw_scatter_add_rows;  4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
+ABI_VERSION = 9  # 9: device-resident optimiser state (ncw_adam_step_dev, NcwAdamState), dynamic loss scale (grad_scale_dev / grad_mul_dev);  8: NcwPoints mode 4 (idx / count), NcwWgradDesc.n_points_dev, ncw_bg_select;  7: fp16 (prec 2), grad_scale / grad_mul;  6: ray prologue / inv_s / loss launches, NcwCompositeOut.weights_max;  5: ncw_scatter_add_rows;  4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
 
 
 class NcwSeg(C.Structure):
@@ -37,8 +37,13 @@ class NcwUnpackDesc(C.Structure):
         ("d_src", C.c_void_p), ("d_g", C.c_void_p), ("d_bias", C.c_void_p),
         ("ld", C.c_int32), ("ldw", C.c_int32), ("row0", C.c_int32), ("nrows", C.c_int32), ("drow0", C.c_int32),
         ("scale", C.c_float), ("grad_mul", C.c_float), ("accumulate", C.c_int32), ("nseg", C.c_int32),
-        ("seg", NcwSeg * MAX_SEGS),
+        ("seg", NcwSeg * MAX_SEGS), ("grad_mul_dev", C.c_void_p),
     ]
+
+
+class NcwAdamState(C.Structure):
+    _fields_ = [("step", C.c_int32), ("good", C.c_int32), ("skipped", C.c_int32), ("skip_now", C.c_int32),
+                ("coef", C.c_float), ("step_size", C.c_float), ("bc2_sqrt", C.c_float), ("last_norm", C.c_float)]
 
 
 class NcwSdfNet(C.Structure):
@@ -121,7 +126,7 @@ NcwCompositeGrad = _ptr_struct(
     "NcwCompositeGrad",
     ["d_color", "d_weights_sum", "d_depth", "d_eik_num", "d_sdf", "d_grad", "d_rgb", "d_density", "d_bg_rgb",
      "d_inv_s"],
-    [("grad_scale", C.c_float)],
+    [("grad_scale", C.c_float), ("grad_scale_dev", C.c_void_p)],
 )
 
 _VP = C.c_void_p
@@ -136,6 +141,9 @@ _PROTOS = {
                                    C.c_void_p, C.c_void_p]),
     "ncw_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
+    "ncw_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int,
+                                    C.c_float, C.c_float, C.c_void_p]),
     "ncw_wgrad_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "ncw_wgrad_tiled_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "ncw_sdf_infer_points": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p,

@@ -17,6 +17,7 @@ class _LossFn(torch.autograd.Function):
         dev = color.device
         f = lambda t: None if t is None else t.detach().reshape(-1).float().contiguous()  # noqa: E731
         color_c, rgbs_c = color.detach().float().contiguous(), rgbs.detach().float().contiguous()
+        assert ge is None or ge.numel() == 1  # NeuconWLoss.__call__ reduces anything else first
         ge_c, me_c, sfm_c = f(ge), f(me), f(sfm)
         R = color_c.shape[0]
         n_me, n_sfm = (0 if me_c is None else me_c.numel()), (0 if sfm_c is None else sfm_c.numel())
@@ -62,7 +63,10 @@ class NeuconWLoss:
         if not inputs["color"].is_cuda:
             raise L.NeuconwHipError("NeuconWLoss: tensors are not on a GPU; the hot path has no CPU fallback")
         w = (self.coef, self.igr_weight, self.mask_weight, self.depth_weight)
-        return _LossFn.apply(inputs["color"], targets, inputs["gradient_error"], inputs["mask_error"] if self.use_mask else None,
+        ge = inputs["gradient_error"]
+        if ge.numel() != 1:  # losses.py:29 takes .mean(); render() returns the batch-global scalar (renderer.py:763-765),
+            ge = ge.mean()   # any other shape is reduced here by torch (with its autograd) before the fused launch
+        return _LossFn.apply(inputs["color"], targets, ge, inputs["mask_error"] if self.use_mask else None,
                              inputs["sfm_depth_loss"] if self.use_depth else None, w)
 
     def terms(self, inputs, targets):

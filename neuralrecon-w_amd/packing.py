@@ -152,12 +152,14 @@ class PackPlan:
         L.check(lib.ncw_pack_weights(L.ptr(self._pack_tab), L.ptr(self._pack_prefix), self._pack_n,
                                      self._pack_rows, L.stream_ptr(self.device)), "ncw_pack_weights")
 
-    def unpack_grads(self, accumulate_into, accumulate=False, grad_mul=1.0):
+    def unpack_grads(self, accumulate_into, accumulate=False, grad_mul=1.0, grad_mul_dev=None):
         """accumulate_into: dict id(param) -> grad tensor (same shape, fp32, contiguous).  Writes (or,
         with accumulate=True, adds) the parameter gradients from the dense gradient arena.  The device
         descriptor table is cached by content, so the steady state does no host->device copy.
-        grad_mul multiplies everything written (1 / loss scale in the fp16 mode)."""
-        key = (bool(accumulate), float(grad_mul)) + tuple(accumulate_into[id(u["weight"])].data_ptr() for u in self._unpack) \
+        grad_mul (host float) and grad_mul_dev (1-element device tensor, read at run time) multiply everything written
+        (1 / loss scale in the fp16 mode)."""
+        gm_ptr = grad_mul_dev.data_ptr() if grad_mul_dev is not None else 0
+        key = (bool(accumulate), float(grad_mul), gm_ptr) + tuple(accumulate_into[id(u["weight"])].data_ptr() for u in self._unpack) \
             + tuple(u["weight"].data_ptr() for u in self._unpack)
         cache = self.__dict__.setdefault("_unpack_cache", {})
         hit = cache.get(key)
@@ -181,6 +183,7 @@ class PackPlan:
             d.row0, d.nrows, d.drow0 = u["row0"], u["nrows"], u["drow0"]
             d.scale = u["scale"]
             d.grad_mul = float(grad_mul)
+            d.grad_mul_dev = gm_ptr
             d.accumulate = 1 if accumulate else 0
             d.nseg = len(u["segs"])
             for i, (c0, nc, dc0) in enumerate(u["segs"]):

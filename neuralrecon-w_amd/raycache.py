@@ -113,11 +113,12 @@ class RayCache:
         k = batch["keep"]
         return batch["rays"][k], batch["ts"][k], batch["semantics"][k], batch["rgbs"][k]
 
-    def epoch(self, batch_size, generator=None, drop_last=False):
-        """Shuffled batches of one epoch (DataLoader(shuffle=True): a uniform permutation; drawn on the device)."""
+    def epoch(self, batch_size, generator=None, drop_last=False, max_batches=None):
+        """Shuffled batches of one epoch (DataLoader(shuffle=True): a uniform permutation; drawn on the device).
+        max_batches: stop after that many (every rank of a data-parallel job must run the same number of steps)."""
         n = len(self)
         perm = torch.randperm(n, device=self.device, generator=generator)
-        for s in range(0, n, batch_size):
-            if drop_last and s + batch_size > n:
+        for i, s in enumerate(range(0, n, batch_size)):
+            if (drop_last and s + batch_size > n) or (max_batches is not None and i >= max_batches):
                 return
             yield self.batch(perm[s:s + batch_size])

@@ -111,7 +111,7 @@ class CompositeCtx:
         L.check(lib.ncw_composite_fwd(self.cin, s, L.stream_ptr(dev)), "ncw_composite_fwd")
         return o
 
-    def backward(self, d_color, d_weights_sum, d_depth, d_eik_num, grad_scale=1.0):
+    def backward(self, d_color, d_weights_sum, d_depth, d_eik_num, grad_scale=1.0, grad_scale_dev=None):
         R, S, M, dev = self.R, self.S, self.S + self.O, self.dev
         z = lambda t, shape: _f(t).reshape(shape) if t is not None else torch.zeros(shape, device=dev)  # noqa: E731
         ups = dict(d_color=z(d_color, (R, 3)), d_weights_sum=z(d_weights_sum, (R,)), d_depth=z(d_depth, (R,)),
@@ -125,6 +125,8 @@ class CompositeCtx:
         for k, v in list(ups.items()) + list(g.items()):
             setattr(s, k, v.data_ptr() if v is not None else 0)
         s.grad_scale = float(grad_scale)  # every returned adjoint carries this factor (fp16 loss scaling)
+        # ... times this device scalar (the dynamic loss scale the optimiser adapts, trainer.FlatAdam), if given
+        s.grad_scale_dev = grad_scale_dev.data_ptr() if grad_scale_dev is not None else 0
         lib = L.get_lib()
         L.check(lib.ncw_composite_bwd(self.cin, s, L.stream_ptr(dev)), "ncw_composite_bwd")
         self._keep = ups

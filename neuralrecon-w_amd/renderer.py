@@ -92,8 +92,11 @@ class _RenderFn(torch.autograd.Function):
         # stashes), whose normal range ends at 6e-5 -- the loss's 1/(3R) alone puts them below it.  The compositor
         # backward multiplies its upstream by the (power-of-two) loss scale; it is divided back out of the parameter
         # gradients (unpack), d_a and d_var below, all in f32.
-        gscale = float(rdr.grad_scale) if prec == L.PREC_F16 else 1.0
-        g = comp.backward(d_color, d_wsum, d_depth, d_eik, grad_scale=gscale)
+        # The scale is a DEVICE scalar (rdr.loss_scale: {scale, 1 / scale}), so the optimiser can halve it after an
+        # overflowed step and grow it back (trainer.FlatAdam / ncw_adam_step_dev) without a device->host round trip.
+        sc = rdr.loss_scale.tensor(dev) if prec == L.PREC_F16 else None
+        sc_mul, sc_inv = (sc[0:1], sc[1:2]) if sc is not None else (None, None)
+        g = comp.backward(d_color, d_wsum, d_depth, d_eik, grad_scale_dev=sc_mul)
         R, S = comp.R, comp.S
         d_grad = g["d_grad"].view(R * S, 3)
         dfeat_ptr = sctx["arena"].ptr(sctx["ids"]["dfeat"])
@@ -151,7 +154,7 @@ class _RenderFn(torch.autograd.Function):
             flat, views = rdr._grad_views(ctx.params)
             direct = all(p.grad is not None and p.grad.data_ptr() == views[id(p)].data_ptr() for p in ctx.params)
         if direct:
-            keep = [pl.unpack_grads(views, accumulate=True, grad_mul=1.0 / gscale) for pl in plans]
+            keep = [pl.unpack_grads(views, accumulate=True, grad_mul_dev=sc_inv) for pl in plans]
         else:
             tmp = torch.zeros(sum(p.numel() for p in ctx.params), device=dev, dtype=torch.float32)
             tviews, off = {}, 0
@@ -161,14 +164,14 @@ class _RenderFn(torch.autograd.Function):
                 tviews[id(p)] = v
                 out.append(v)
                 off += p.numel()
-            keep = [pl.unpack_grads(tviews, grad_mul=1.0 / gscale) for pl in plans]
+            keep = [pl.unpack_grads(tviews, grad_mul_dev=sc_inv) for pl in plans]
         ctx._keep = (keep, batch)
         d_var = torch.empty(1, device=dev, dtype=torch.float32)  # 10 inv_s [clamp inactive] sum_r d_inv_s[r], fixed order
         L.check(lib.ncw_inv_s_bwd(L.ptr(g["d_inv_s"]), R, L.ptr(ctx.inv_s), L.ptr(d_var), L.stream_ptr(dev)), "ncw_inv_s_bwd")
         d_var = d_var.reshape(ctx.variance.shape)
-        if gscale != 1.0:
-            d_a.mul_(1.0 / gscale)
-            d_var = d_var * (1.0 / gscale)
+        if sc_inv is not None:
+            d_a.mul_(sc_inv)
+            d_var = d_var * sc_inv
         ctx.guard.release()
         return (None, None, None, None, None, None, None, None, d_a, d_var) + tuple(out)
 
@@ -230,7 +233,39 @@ class _RayTailFn(torch.autograd.Function):
         return d_wsum, d_depth, d_num, None, None, None, None, None, None, None
 
 
+class LossScale:
+    """The fp16 mode's loss scale as device data: float[2] = {scale, 1 / scale} (powers of two).  The compositor backward
+    multiplies its upstream cotangents by [0] (NcwCompositeGrad.grad_scale_dev), the weight-norm backward / d_a / d_var
+    multiply by [1] (NcwUnpackDesc.grad_mul_dev); `ncw_adam_step_dev` updates both in place.  The reference trains in fp32
+    and has no counterpart (train.py:48-62)."""
+
+    def __init__(self, init):
+        self.init, self.buf = float(init), None
+
+    def tensor(self, device):
+        if self.buf is None or self.buf.device != torch.device(device):
+            self.buf = torch.tensor([self.init, 1.0 / self.init], device=device, dtype=torch.float32)
+        return self.buf
+
+    def set(self, value):
+        self.init = float(value)
+        if self.buf is not None:
+            self.buf.copy_(torch.tensor([self.init, 1.0 / self.init]))
+
+    def value(self):
+        """Current scale (synchronises when it lives on the device)."""
+        return self.init if self.buf is None else float(self.buf[0])
+
+
 class NeuconWRenderer:
+    @property
+    def grad_scale(self):
+        return self.loss_scale.value()
+
+    @grad_scale.setter
+    def grad_scale(self, v):
+        self.loss_scale.set(v)
+
     def __init__(self, nerf, neuconw, embeddings, n_samples, n_importance, n_outside, up_sample_steps, perturb,
                  origin, radius, s_val_base=0, spc_options=None, sample_range=None, boundary_samples=None,
                  nerf_far_override=False, render_bg=True, trim_sphere=True, save_sample=False,
@@ -275,8 +310,10 @@ class NeuconWRenderer:
         # bg_dense=True: evaluate the background NeRF on every sample like the reference does, instead of only where the
         # compositor can use it (dead-background elimination, _RenderFn.forward); NEUCONW_BG_DENSE=1 sets the default
         self.bg_dense = os.environ.get("NEUCONW_BG_DENSE", "0") not in ("0", "")
-        # loss scale of the fp16 mode (prec = PREC_F16; unused otherwise): a power of two, see _RenderFn.backward
-        self.grad_scale = float(os.environ.get("NEUCONW_F16_LOSS_SCALE", "1024"))
+        # loss scale of the fp16 mode (prec = PREC_F16; unused otherwise): a power of two kept on the device, see
+        # _RenderFn.backward.  `grad_scale` (property) reads / sets it; trainer.FlatAdam adapts it (halves after a step
+        # with a non-finite gradient norm, doubles after `growth_interval` clean steps).
+        self.loss_scale = LossScale(float(os.environ.get("NEUCONW_F16_LOSS_SCALE", "1024")))
         # sync_free=True keeps render() free of device->host synchronisations (see sfm_depth_loss below);
         # the default reproduces the reference's output shapes exactly.
         self.sync_free = False

@@ -79,34 +79,76 @@ class FlatParams:
                 off, k = self.slices[id(p)]
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
 
-    def allreduce(self, world_size=None, group=None):
-        """Mean of the flat gradient over ranks: one RCCL all-reduce over xGMI, in place."""
+    def allreduce(self, world_size=None, group=None, async_op=False):
+        """Mean of the flat gradient over ranks: ONE all-reduce (RCCL over xGMI), in place.  async_op=True returns a
+        handle whose wait() completes the mean (the caller overlaps host work / independent launches with the wire
+        time); RCCL averages in the collective (ReduceOp.AVG), gloo sums and the division is one more launch."""
         if not dist.is_available() or not dist.is_initialized():
-            return
+            return None
         world_size = dist.get_world_size(group) if world_size is None else world_size
         if world_size == 1:
-            return
-        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
-        self.flat_grad.div_(world_size)
+            return None
+        avg = dist.get_backend(group) == "nccl"
+        work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group,
+                               async_op=True)
+        h = _ReduceHandle(work, None if avg else (self.flat_grad, world_size))
+        if async_op:
+            return h
+        h.wait()
+        return None
 
     def broadcast(self, src=0, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.broadcast(self.flat.data, src=src, group=group)
 
 
-class FlatAdam:
-    """Adam over trainer.FlatParams with the global-norm clip folded in: ONE `ncw_adam_step` launch per step
-    (+ one norm reduction) instead of torch's multi-tensor norm / clamp / mul / fused-Adam sequence.  Same
-    arithmetic as torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False) after
-    torch.nn.utils.clip_grad_norm_(params, clip) (tests/test_gpu_trainer.py); bias corrections are computed in
-    double on the host like torch's non-capturable path."""
+class _ReduceHandle:
+    def __init__(self, work, div):
+        self.work, self.div = work, div
 
-    def __init__(self, flat_params, lr, betas=(0.9, 0.999), eps=1e-7, clip=None):
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            if self.div is not None:
+                self.div[0].div_(self.div[1])
+
+
+class FlatAdam:
+    """Adam over trainer.FlatParams with the global-norm clip folded in: `ncw_adam_step_dev` (a one-thread prologue +
+    ONE elementwise launch, after one norm reduction) instead of torch's multi-tensor norm / clamp / mul / fused-Adam
+    sequence.  Same arithmetic as torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False) after
+    torch.nn.utils.clip_grad_norm_(params, clip) (tests/test_gpu_trainer.py).
+
+    Everything step-dependent lives on the DEVICE (`state`: NcwAdamState): the applied-step counter (a step skipped for a
+    non-finite gradient norm does not advance Adam's bias correction), the bias corrections (computed in double like
+    torch's non-capturable path), the clip coefficient -- so the update is HIP-graph capturable -- and, in the fp16 mode,
+    the loss scale (`loss_scale`: the renderer's device {scale, 1 / scale}): halved after a non-finite step, doubled after
+    `growth_interval` consecutive clean steps (torch.cuda.amp.GradScaler's policy and defaults)."""
+
+    def __init__(self, flat_params, lr, betas=(0.9, 0.999), eps=1e-7, clip=None, loss_scale=None, growth_interval=2000,
+                 scale_min=1.0, scale_max=65536.0):
         self.fp = flat_params
         self.lr, self.betas, self.eps, self.clip = float(lr), (float(betas[0]), float(betas[1])), float(eps), clip
-        self.step_count = 0
         self.exp_avg = torch.zeros_like(flat_params.flat_grad)
         self.exp_avg_sq = torch.zeros_like(flat_params.flat_grad)
+        self.state = torch.zeros(8, device=flat_params.flat_grad.device, dtype=torch.int32)  # NcwAdamState
+        self.loss_scale, self.growth_interval = loss_scale, int(growth_interval)
+        self.scale_min, self.scale_max = float(scale_min), float(scale_max)
+        self.lr_dev = None  # optional device scalar overriding `lr` (a scheduler under graph replay)
+
+    # applied (non-skipped) steps: Adam's t.  Lives on the device; reading it synchronises (checkpoints, tests)
+    @property
+    def step_count(self):
+        return int(self.state[0])
+
+    @step_count.setter
+    def step_count(self, v):
+        self.state[0] = int(v)
+
+    @property
+    def skipped_steps(self):
+        return int(self.state[2])
 
     def step(self):
         from . import lib as L
@@ -114,16 +156,14 @@ class FlatAdam:
         fp = self.fp
         if not fp.flat_grad.is_cuda:
             raise L.NeuconwHipError("FlatAdam: parameters are not on a GPU; there is no CPU fallback")
-        self.step_count += 1
         b1, b2 = self.betas
-        step_size = self.lr / (1.0 - b1 ** self.step_count)
-        bc2_sqrt = (1.0 - b2 ** self.step_count) ** 0.5
-        norm = torch.linalg.vector_norm(fp.flat_grad) if self.clip is not None else None
-        L.check(L.get_lib().ncw_adam_step(L.ptr(fp.flat.data), L.ptr(fp.flat_grad), L.ptr(self.exp_avg),
-                                          L.ptr(self.exp_avg_sq), fp.flat_grad.numel(), step_size, b1, b2, self.eps,
-                                          bc2_sqrt, L.ptr(norm),
-                                          float(self.clip) if self.clip is not None else 0.0,
-                                          L.stream_ptr(fp.flat_grad.device)), "ncw_adam_step")
+        need_norm = self.clip is not None or self.loss_scale is not None
+        norm = torch.linalg.vector_norm(fp.flat_grad) if need_norm else None
+        L.check(L.get_lib().ncw_adam_step_dev(
+            L.ptr(fp.flat.data), L.ptr(fp.flat_grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), fp.flat_grad.numel(),
+            L.ptr(self.state), L.ptr(norm), self.lr, L.ptr(self.lr_dev), b1, b2, self.eps,
+            float(self.clip) if self.clip is not None else 0.0, L.ptr(self.loss_scale), self.growth_interval,
+            self.scale_min, self.scale_max, L.stream_ptr(fp.flat_grad.device)), "ncw_adam_step_dev")
         fp.mark_updated()
         return norm
 
@@ -135,7 +175,8 @@ class FlatAdam:
         """The state in torch.optim.Adam's own `state_dict()` layout for the parameters in `param_order` (the order
         the reference's `get_optimizer` hands them to Adam: utils/__init__.py:10-31 over [embedding_a, {neuconw, nerf}],
         neuconw_system.py:70-136) -- what a PyTorch-Lightning checkpoint stores under `optimizer_states[0]`, so the
-        reference can resume from it.  Parameters that are not in the flat storage are skipped."""
+        moments load into a stock torch.optim.Adam built the reference's way.  Parameters that are not in the flat storage
+        are skipped."""
         state, ids = {}, []
         for i, p in enumerate(param_order):
             ids.append(i)
@@ -178,12 +219,11 @@ class TrainStep:
     loss_fn(outputs, targets) -> scalar is the user's (NeuconWLoss, losses.py:21-43).
 
     capture=True records the step ONCE into HIP graphs (torch.cuda.CUDAGraph) after `capture_warmup` eager
-    steps and replays it afterwards: the ~130 launches of a step (C-ABI kernels, the loss' elementwise ops,
-    autograd, clip, fused Adam) are submitted as one graph launch, which removes the host-side launch gaps
-    of this launch-bound tail.  Everything that varies between steps is device data: the batch is copied
+    steps and replays it afterwards: the launches of a step (C-ABI kernels, the loss, autograd glue, norm, clip + Adam)
+    are submitted as one graph launch.  Everything that varies between steps is device data: the batch is copied
     into static buffers, `cos_anneal_ratio` is a device scalar read by the compositor kernels, Adam's step
-    counter is a device tensor (capturable=True), the sampler's jitter comes from torch's graph-safe Philox
-    state.  Requirements: fixed batch shape, a loss_fn without host syncs, renderer.sync_free (set here).
+    counter, bias corrections and the fp16 loss scale live in device state (FlatAdam / ncw_adam_step_dev), the
+    sampler's jitter comes from torch's graph-safe Philox state.  Requirements: fixed batch shape, a loss_fn without host syncs, renderer.sync_free (set here).
     With world_size > 1 the gradient all-reduce stays an eager RCCL call between two graphs."""
 
     def __init__(self, renderer, modules, loss_fn, lr, eps=1e-7, betas=(0.9, 0.999), clip=0.99, world_size=1,
@@ -195,16 +235,20 @@ class TrainStep:
         self.fp = FlatParams(modules, renderer)
         self.fp.broadcast(group=group)
         kw = dict(lr=lr, eps=eps, betas=betas)
-        # eager: clip + Adam as ONE C-ABI launch (FlatAdam); captured: torch's capturable Adam (device step counter)
-        self.native = (not self.capture) if native_optimizer is None else bool(native_optimizer)
-        if self.native and self.capture:
-            raise ValueError("the native optimiser keeps its step counter on the host: not capturable")
-        if self.native:
-            self.opt = FlatAdam(self.fp, clip=clip, **kw)
-            return
+        # clip + Adam as ONE C-ABI call (FlatAdam: device-resident step state, so it is graph-capturable too);
+        # native_optimizer=False keeps stock torch.optim.Adam over the flat buffer (eager only)
+        self.native = True if native_optimizer is None else bool(native_optimizer)
         if self.capture:
             renderer.sync_free = True
-            kw["capturable"] = True
+            if not self.native:
+                raise ValueError("TrainStep(capture=True) needs the native optimiser (torch's path checks the gradient "
+                                 "norm on the host)")
+        if self.native:
+            from . import lib as L
+
+            ls = renderer.loss_scale.tensor(self.fp.flat_grad.device) if getattr(renderer, "prec", None) == L.PREC_F16 else None
+            self.opt = FlatAdam(self.fp, clip=clip, loss_scale=ls, **kw)
+            return
         try:
             self.opt = torch.optim.Adam([self.fp.flat], fused=True, **kw)
         except (RuntimeError, TypeError, ValueError):
@@ -222,17 +266,30 @@ class TrainStep:
     def _update(self):
         if self.native:
             # clip + Adam + mark_updated.  The gradient norm stays on the device (no sync); a NON-FINITE norm makes
-            # ncw_adam_step skip the update (fp16 overflow guard) -- callers that log should look at it now and then
+            # ncw_adam_step_dev skip the update and halve the fp16 loss scale -- callers that log can look at
+            # last_grad_norm / opt.skipped_steps now and then
             self.last_grad_norm = self.opt.step()
             return
-        if self.clip is not None:
-            torch.nn.utils.clip_grad_norm_([self.fp.flat], self.clip)  # train.py:61
+        # stock torch optimiser (eager only): the same guard on the host -- one overflowed fp16 step must not turn every
+        # parameter and both Adam moments into NaN through the clip coefficient
+        norm = torch.nn.utils.clip_grad_norm_([self.fp.flat], self.clip if self.clip is not None else float("inf"))  # train.py:61
+        self.last_grad_norm = norm
+        if not bool(torch.isfinite(norm)):
+            self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
+            ls = getattr(self.renderer, "loss_scale", None)
+            if ls is not None and ls.buf is not None:
+                ls.set(max(ls.value() * 0.5, 1.0))
+            return
         self.opt.step()
         self.fp.mark_updated()
 
     def eager_step(self, rays, ts, label, targets, background_rgb=None, cos_anneal_ratio=0.0, **render_kw):
         loss, out = self._fwd_bwd(rays, ts, label, targets, background_rgb, cos_anneal_ratio, render_kw)
-        self.fp.allreduce(self.world_size, self.group)
+        # ONE all-reduce of the flat gradient (train.py:53-55 accelerator='ddp'), issued asynchronously: the collective
+        # runs on RCCL's stream while the host queues the norm / optimiser launches, which wait for it on the device
+        h = self.fp.allreduce(self.world_size, self.group, async_op=True)
+        if h is not None:
+            h.wait()
         self._update()
         return loss, out
 
@@ -297,24 +354,30 @@ class TrainStep:
 # whose `state_dict` holds `embedding_a.*`, `neuconw.*`, `nerf.*` (train.py:32-38, neuconw_system.py:376-400)
 # and reads them back by prefix (utils/__init__.py:64-98 `extract_model_state_dict` / `load_ckpt`, used by
 # tools/extract_mesh.py:130-134).  These two functions write / read exactly that layout; the optimiser state is
-# written in torch.optim.Adam's own state_dict layout in the reference's parameter order, so checkpoints -- weights AND
-# Adam moments -- move between the reference and this package in both directions (tests/test_checkpoint_io.py).
+# written in torch.optim.Adam's own state_dict layout in the reference's parameter order, so weights (through the
+# reference's load_ckpt) and Adam moments (through torch.optim.Adam.load_state_dict) move in both directions
+# (tests/test_checkpoint_io.py).
 # ---------------------------------------------------------------------------------------------------
 def reference_param_order(embedding_a, neuconw, nerf):
     """`get_parameters([embedding_a, {"neuconw": neuconw, "nerf": nerf}])` of the reference (utils/__init__.py:10-21)."""
     return list(embedding_a.parameters()) + list(neuconw.parameters()) + list(nerf.parameters())
 
 
-def save_checkpoint(path, embedding_a, neuconw, nerf, optimizer=None, global_step=0, extra=None):
-    """Writes {'state_dict': {prefix.key: tensor}, 'global_step': ..., ['optimizer_states': [...]]}."""
+def save_checkpoint(path, embedding_a, neuconw, nerf, optimizer=None, global_step=0, extra=None, epoch=0):
+    """Writes {'state_dict': {prefix.key: tensor}, 'global_step', 'epoch', ['optimizer_states': [...]]} plus the keys
+    PyTorch-Lightning 1.4.8's `resume_from_checkpoint` looks up ('lr_schedulers', 'callbacks',
+    'pytorch-lightning_version').  TESTED round trips: the reference's `load_ckpt` / `extract_model_state_dict` (weights)
+    and a stock `torch.optim.Adam` (moments), tests/test_checkpoint_io.py; PL's own restore path is not exercised here
+    (PL is not installable in this image)."""
     sd = {}
     for prefix, mod in (("embedding_a", embedding_a), ("neuconw", neuconw), ("nerf", nerf)):
         for k, v in mod.state_dict().items():
             sd[prefix + "." + k] = v.detach().cpu().clone()   # clone: parameters may be views of the flat buffer
-    ckpt = {"state_dict": sd, "global_step": int(global_step)}
+    ckpt = {"state_dict": sd, "global_step": int(global_step), "epoch": int(epoch), "lr_schedulers": [], "callbacks": {},
+            "pytorch-lightning_version": "1.4.8"}
     if optimizer is not None:
         if hasattr(optimizer, "torch_state_dict"):  # FlatAdam -> torch.optim.Adam's layout in the reference's parameter
-            # order (utils/__init__.py:10-31 over [embedding_a, {neuconw, nerf}]), which PL's resume expects
+            # order (utils/__init__.py:10-31 over [embedding_a, {neuconw, nerf}])
             ckpt["optimizer_states"] = [optimizer.torch_state_dict(reference_param_order(embedding_a, neuconw, nerf))]
         else:
             ckpt["optimizer_states"] = [optimizer.state_dict()]

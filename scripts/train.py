@@ -10,7 +10,8 @@
   * Adam(eps 1e-7), lr = CANONICAL_LR * world * batch / CANONICAL_BS, grad-norm clip 0.99, ONE flat RCCL all-reduce;
   * cos_anneal_ratio = min(1, step / ANNEAL_END); every UPDATE_FREQ steps the fine octree is rebuilt from the current SDF
     (coarse octree from the COLMAP points: voxel.octree_from_sfm); checkpoints every SAVE_FREQ steps in the reference's
-    PyTorch-Lightning layout (state_dict keys + torch.optim.Adam optimizer state), readable by its load_ckpt / resume.
+    PyTorch-Lightning layout (state_dict keys + torch.optim.Adam optimizer state), readable by its load_ckpt;
+  * LR_SCHEDULER none / cosine / steplr stepped per epoch like PL steps the reference's scheduler (config.lr_at_epoch).
 """
 import argparse
 import os
@@ -34,7 +35,8 @@ def main():
     ap.add_argument("--num_epochs", type=int, default=20)
     ap.add_argument("--max_steps", type=int, default=0, help="stop after this many steps (0 = run the epochs out)")
     ap.add_argument("--exp_name", default="exp")
-    ap.add_argument("--prec", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--prec", default=None, choices=["bf16", "f16", "f32"],
+                    help="training precision; default = the package default (NEUCONW_PREC, f16: neuconw.default_prec)")
     ap.add_argument("--ckpt_path", default="", help="resume from this checkpoint")
     ap.add_argument("--log_every", type=int, default=100)
     args = ap.parse_args()
@@ -49,7 +51,7 @@ def main():
     cfg = C.load_config(args.cfg_path, {"DATASET": {"ROOT_DIR": args.root_dir}} if args.root_dir else None)
     lr = C.scale_lr(cfg, world, args.batch_size)
     torch.manual_seed(cfg["TRAINER"]["SEED"])  # pl.seed_everything (train.py:18): identical initial weights on every rank
-    prec = {"bf16": nw.PREC_BF16, "f16": nw.PREC_F16, "f32": nw.PREC_F32}[args.prec]
+    prec = {None: None, "bf16": nw.PREC_BF16, "f16": nw.PREC_F16, "f32": nw.PREC_F32}[args.prec]
     emb, neuconw, nerf, rdr, scene = C.build_system(cfg, dev, prec)
     rdr.sync_free = True
     n, pt = cfg["NEUCONW"], cfg["DATASET"]["PHOTOTOURISM"]
@@ -57,8 +59,19 @@ def main():
     names = raycache.local_splits(raycache.list_splits(root, pt["CACHE_DIR"]), world, rank)
     cache = raycache.RayCache(root, pt["CACHE_DIR"], names, dev, img_downscale=pt["IMG_DOWNSCALE"],
                               with_semantics=pt["WITH_SEMANTICS"], ray_mask_list=n["RAY_MASK_LIST"], prefilter=True)
+    # Every rank runs the SAME number of steps per epoch: with the black-listed rays removed at load time the ranks'
+    # caches differ in length, and a rank that leaves the loop early would strand the others in the gradient all-reduce
+    # (the reference pads its chunks to equal length and filters inside the batch: datasets/data.py:83-119).
+    steps_per_epoch = len(cache) // args.batch_size
+    if world > 1:
+        t = torch.tensor([steps_per_epoch], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        steps_per_epoch = int(t.item())
+    if steps_per_epoch < 1:
+        raise SystemExit("a rank holds fewer than --batch_size rays (%d)" % len(cache))
     if rank == 0:
-        print("[rank 0] %d cache chunk(s), %d rays resident on %s; lr %.3g" % (len(names), len(cache), dev, lr))
+        print("[rank 0] %d cache chunk(s), %d rays resident on %s; %d steps/epoch; lr %.3g"
+              % (len(names), len(cache), dev, steps_per_epoch, lr))
     step_fn = nw.TrainStep(rdr, [emb, neuconw, nerf], C.neuconw_loss(cfg), lr=lr, eps=1e-7, clip=0.99, world_size=world)
     order = trainer.reference_param_order(emb, neuconw, nerf)
     step = 0
@@ -74,8 +87,11 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(cfg["TRAINER"]["SEED"] + rank)
     t0, t_last, done = time.perf_counter(), time.perf_counter(), False
-    for epoch in range(args.num_epochs):
-        for b in cache.epoch(args.batch_size, generator=gen, drop_last=True):
+    first_epoch = step // steps_per_epoch
+    for epoch in range(first_epoch, args.num_epochs):
+        if hasattr(step_fn.opt, "lr"):  # utils/__init__.py:45-61: the scheduler steps once per epoch
+            step_fn.opt.lr = C.lr_at_epoch(cfg, lr, epoch, args.num_epochs)
+        for b in cache.epoch(args.batch_size, generator=gen, drop_last=True, max_batches=steps_per_epoch):
             rdr.nerf_far_override = False  # neuconw_system.py:343: training always reads near / far from the cache
             ratio = 1.0 if n["ANNEAL_END"] == 0 else min(1.0, step / n["ANNEAL_END"])
             loss, out = step_fn(b["rays"], b["ts"], b["semantics"], b["rgbs"], background_rgb=bg, cos_anneal_ratio=ratio)
@@ -84,14 +100,15 @@ def main():
             if step % cfg["TRAINER"]["SAVE_FREQ"] == 0 and rank == 0:  # :367-374
                 os.makedirs(save_dir, exist_ok=True)
                 trainer.save_checkpoint(os.path.join(save_dir, "iter_%d.ckpt" % step), emb, neuconw, nerf,
-                                        optimizer=step_fn.opt, global_step=step)
+                                        optimizer=step_fn.opt, global_step=step, epoch=epoch)
             if rank == 0 and step % args.log_every == 0:
                 now = time.perf_counter()
                 gn = float(getattr(step_fn, "last_grad_norm", float("nan")))
                 print("epoch %d step %d  loss %.5f  s_val %.5f  |grad| %.4g  (%.1f ms/step)%s"
                       % (epoch, step, float(loss), float(out["s_val"]), gn, 1e3 * (now - t_last) / max(1, args.log_every),
                          "" if gn == gn and abs(gn) != float("inf") else
-                         "  <- non-finite gradient norm: this update was skipped (fp16 overflow? try --prec bf16)"))
+                         "  <- non-finite gradient norm: this update was skipped and the fp16 loss scale halved (now %g; "
+                         "%d skipped so far)" % (rdr.grad_scale, step_fn.opt.skipped_steps)))
                 t_last = now
             step += 1
             if args.max_steps and step >= args.max_steps:

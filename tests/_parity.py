@@ -1,0 +1,89 @@
+"""One composed train step (render + loss + backward) on the GPU against the fp64 CPU oracle, at a chosen operating point
+of the NeuS variance network: shared by tests/test_gpu_fullsize.py and scripts/diag/trained_point_parity.py.
+
+The reference's SingleVarianceNetwork (models/neuconw.py:173-179) drives sigmoid(sdf * inv_s) (rendering/renderer.py:624-632)
+with inv_s = exp(10 * variance), which grows from 20 (init_val 0.3) to several hundred during training: an SDF error that
+is invisible at initialisation is multiplied by 150-1100 there."""
+import math
+
+import torch
+
+from tests._build import build_system, loss_from_outputs, named_params, state_dict_cpu
+from tests._util import rel_err, synth_rays
+
+CFG = dict(n_outside=4, up_sample_steps=2, s_val_base=3, render_bg=True, trim_sphere=True, mesh_mask_list=["sky"],
+           depth_loss=True, igr_weight=0.1, mask_weight=0.1, depth_weight=0.1, skip_in=(4,), multires=6, multires_view=4)
+
+
+def perturb_weights(neuconw, g_jit=0.1, v_jit=0.0, seed=11):
+    """weight_g x (1 + g_jit N(0,1)) (exercises weight-norm) and weight_v + v_jit mean|v| N(0,1): a
+    NON-sphere SDF (the geometric initialisation alone is a distance-to-sphere function).  Drawn on the CPU from a
+    fixed seed so that the numbers do not depend on the device RNG."""
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in neuconw.named_parameters():
+            if n.endswith("weight_g") and g_jit > 0:
+                p.mul_((1.0 + g_jit * torch.randn(p.shape, generator=gen)).to(p.device))
+            elif n.endswith("weight_v") and v_jit > 0:
+                p.add_((v_jit * float(p.abs().mean()) * torch.randn(p.shape, generator=gen)).to(p.device))
+
+
+_ORACLE_CACHE = {}
+
+
+def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=True, cos_anneal=0.3):
+    """-> dict(errs={color, depth, weights_sum, gradient_error}, loss, loss_ref, grad_worst, inv_s).
+    Gradient errors are scaled by the largest gradient of their network (the fp32 reference's own gradients of ~1e-7
+    tensors carry ~1e-1 relative noise: tests/test_gpu_fullsize.py)."""
+    from oracle import neuconw_oracle as O
+
+    emb, neuconw, nerf, rdr = build_system(W=W, n_a=48, n_vocab=100, nerf_w=256, color_hidden=256, head=128, seed=seed,
+                                           prec=prec, n_samples=ns, n_importance=ni)
+    perturb_weights(neuconw, 0.1, v_jit)
+    with torch.no_grad():
+        neuconw.deviation_network.variance.fill_(float(variance))
+    rays, ts, label, rgbs = synth_rays(R, 77, 100)
+    out = rdr.render(rays.cuda(), ts.cuda(), label.cuda(), perturb_overwrite=0, background_rgb=torch.zeros(1, 3).cuda(),
+                     cos_anneal_ratio=cos_anneal)
+    loss = loss_from_outputs(out, rgbs.cuda())
+    if with_grads:
+        loss.backward()
+    key = (W, ns, ni, R, float(variance), float(v_jit), seed, with_grads, cos_anneal)
+    hit = _ORACLE_CACHE.get(key)
+    if hit is None:  # the oracle result does not depend on the GPU precision: shared by the parametrised cases
+        sd = state_dict_cpu(emb, neuconw, nerf, torch.float64)
+        sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+        cfg = dict(CFG, n_samples=ns, n_importance=ni)
+        ref = O.render(sd, cfg, rays.double(), ts, label, cos_anneal, torch.zeros(1, 3, dtype=torch.float64))
+        lref = O.neuconw_loss(ref, rgbs.double(), cfg)
+        gref = None
+        if with_grads:
+            names = list(sd)
+            gref = dict(zip(names, torch.autograd.grad(lref, [sd[k] for k in names], allow_unused=True)))
+        hit = ({k: ref[k].detach() for k in ("color", "depth", "weights_sum", "gradient_error")}, float(lref.detach()), gref)
+        if len(_ORACLE_CACHE) > 16:
+            _ORACLE_CACHE.clear()
+        _ORACLE_CACHE[key] = hit
+    ref, lref, gref = hit
+    errs = {k: rel_err(out[k].detach().cpu(), ref[k]) for k in ("color", "depth", "weights_sum", "gradient_error")}
+    res = dict(errs=errs, loss=float(loss.detach()), loss_ref=lref, inv_s=math.exp(10.0 * variance), grad_worst=None,
+               grad_errs={})
+    if with_grads:
+        params = named_params(emb, neuconw, nerf)
+
+        def net_of(k):
+            return k.split(".")[0] if not k.startswith("neuconw.") else ".".join(k.split(".")[:2])
+
+        scale = {}
+        for k, g in gref.items():
+            if g is not None:
+                scale[net_of(k)] = max(scale.get(net_of(k), 0.0), float(g.abs().max()))
+        worst = 0.0
+        for k, g in gref.items():
+            if g is None:
+                continue
+            e = float((params[k].grad.cpu().double() - g.double()).abs().max()) / scale[net_of(k)]
+            res["grad_errs"][k] = e
+            worst = max(worst, e)
+        res["grad_worst"] = worst
+    return res

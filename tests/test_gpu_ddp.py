@@ -1,0 +1,78 @@
+"""GPU: the HIP TrainStep with world_size > 1 (train.py:21-25,53-55, rendering/renderer.py:757-765).
+The lease has ONE GPU: the ranks share cuda:0 and gloo carries the collectives -- the data path (shard -> render -> loss
+-> backward -> ONE flat all-reduce -> clip + Adam) is the one `bench.py --gpus N` runs over RCCL."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from tests._util import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(script_args, env_extra, nproc=2, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_stay_identical_and_match_the_per_shard_oracle():
+    """Config 4 in miniature: 2 ranks x 48 rays.  fp32 mode: averaged gradient == mean of the per-shard oracle gradients
+    within 2e-3 of the network's largest gradient (the single-rank tolerance of tests/test_gpu_fullsize.py); fp16 mode
+    (the timed default, f32 atomics -> order-dependent local gradients): within the single-rank fp16 tolerance.  In both,
+    the replicas are bit-identical after every one of 3 steps although they were initialised differently."""
+    out = _torchrun([os.path.join(ROOT, "tests", "_ddp_worker.py")], {"NCW_DDP_PRECS": "f32,f16"})
+    assert out["world"] == 2
+    r32, r16 = out["results"]["f32"], out["results"]["f16"]
+    print(json.dumps(out["results"], indent=1))
+    for r in (r32, r16):
+        assert r["replicas_identical"] and r["finite"] and r["applied_steps"] == 3 and r["skipped"] == 0
+        assert r["param_abs_sums"][0] != r["param_abs_sums"][-1]  # the parameters did move
+    assert r32["grad_err_vs_shard_oracle_mean"] < 2e-3, r32
+    assert r16["grad_err_vs_shard_oracle_mean"] < 0.1, r16
+
+
+def test_two_ranks_at_the_bench_width():
+    """The same at W = 256 / colour 256 / NeRF 256 (the headline networks) in the timed fp16 mode, 2 x 32 rays."""
+    out = _torchrun([os.path.join(ROOT, "tests", "_ddp_worker.py")], {"NCW_DDP_PRECS": "f16", "NCW_DDP_W": "256", "NCW_DDP_R": "32"})
+    r = out["results"]["f16"]
+    print(json.dumps(r, indent=1))
+    assert r["replicas_identical"] and r["finite"] and r["applied_steps"] == 3
+    assert r["grad_err_vs_shard_oracle_mean"] < 0.05, r
+
+
+def test_bench_gpus_2_prints_one_line_with_world_2():
+    """`python bench.py --gpus 2` end to end (self-launch, 2 ranks sharing GPU 0 over gloo through the
+    NCW_BENCH_ONE_GPU_TEST hook): ONE JSON line, world_size 2, value = both ranks' ray-samples / max-over-ranks time."""
+    env = dict(os.environ, NCW_DIST_BACKEND="gloo", NCW_BENCH_ONE_GPU_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--rays", "256",
+                        "--no-cpu-baseline", "--no-pmc", "--no-parity-mode"], capture_output=True, text=True, env=env,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["global_rays"] == 512
+    assert out["scaling"] == "weak" and out["value"] > 0 and len(out["config"]["ranks"]) == 2
+    assert abs(out["value"] - 2 * 256 * 128 / (out["ms_per_step"] * 1e-3)) < 1e-3 * out["value"]

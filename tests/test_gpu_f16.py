@@ -1,5 +1,6 @@
 """GPU: the fp16 mode (prec = PREC_F16: the bf16 kernels compiled a second time with the 16-bit type switched, csrc/ncw_common.h)
-and its loss scale (NeuconWRenderer.grad_scale -> NcwCompositeGrad.grad_scale -> NcwUnpackDesc.grad_mul).  Parity against
+and its loss scale (NeuconWRenderer.loss_scale, device {scale, 1/scale} -> NcwCompositeGrad.grad_scale_dev ->
+NcwUnpackDesc.grad_mul_dev; adapted by trainer.FlatAdam / ncw_adam_step_dev).  Parity against
 the oracle is in test_gpu_fullsize.py / test_gpu_sdf.py / test_gpu_sdf_train.py; here: what the loss scale is for, that it
 cancels, that training in fp16 follows training in fp32, and the optimiser's non-finite guard."""
 import pytest
@@ -75,20 +76,60 @@ def test_fp16_training_follows_fp32():
 
 
 def test_adam_step_skips_a_non_finite_gradient_norm():
+    """A skipped step writes nothing, does not advance Adam's bias-correction step (device counter), and halves the loss
+    scale; `growth_interval` clean steps double it again (torch.cuda.amp.GradScaler's policy)."""
     from neuralrecon_w_amd.trainer import FlatAdam, FlatParams
 
     torch.manual_seed(0)
     lin = torch.nn.Linear(1000, 1, bias=False).cuda()
     fp = FlatParams([lin])
-    opt = FlatAdam(fp, lr=1e-2, eps=1e-7, clip=0.99)
+    scale = torch.tensor([1024.0, 1.0 / 1024.0], device="cuda")
+    opt = FlatAdam(fp, lr=1e-2, eps=1e-7, clip=0.99, loss_scale=scale, growth_interval=2)
     fp.flat_grad.copy_(torch.randn_like(fp.flat_grad))
     opt.step()
     before = fp.flat.detach().clone()
+    m_before = opt.exp_avg.clone()
     fp.flat_grad.copy_(torch.randn_like(fp.flat_grad))
     fp.flat_grad[17] = float("inf")  # what one overflowed fp16 adjoint does to the norm
     opt.step()
     torch.cuda.synchronize()
-    assert torch.equal(fp.flat, before)  # nothing written: parameters (and moments) survive
+    assert torch.equal(fp.flat, before) and torch.equal(opt.exp_avg, m_before)  # nothing written
+    assert opt.step_count == 1 and opt.skipped_steps == 1
+    assert scale.tolist() == [512.0, 1.0 / 512.0]
     fp.flat_grad.copy_(torch.randn_like(fp.flat_grad))
+    fp.flat_grad[3] = float("nan")
     opt.step()
+    assert opt.step_count == 1 and opt.skipped_steps == 2 and float(scale[0]) == 256.0
+    for _ in range(2):
+        fp.flat_grad.copy_(torch.randn_like(fp.flat_grad))
+        opt.step()
     assert bool(torch.isfinite(fp.flat).all()) and not torch.equal(fp.flat, before)
+    assert opt.step_count == 3 and scale.tolist() == [512.0, 1.0 / 512.0]  # two clean steps: doubled once
+
+
+def test_dynamic_loss_scale_recovers_from_an_overflowing_scale():
+    """fp16 TrainStep started with a loss scale that overflows fp16 (2^24 on O(1e-4) adjoints): the first steps come
+    out non-finite and are skipped while the device-resident scale halves; training then proceeds.  No host sync is
+    involved: the compositor backward and the weight-norm backward read the scale from the device."""
+    import neuralrecon_w_amd as nw
+    from tests._build import build_system, loss_from_outputs
+    from tests._util import synth_rays
+
+    emb, neuconw, nerf, rdr = build_system(seed=3, prec=nw.PREC_F16)
+    rdr.sync_free = True
+    rdr.grad_scale = 2.0 ** 40
+    train = nw.TrainStep(rdr, [emb, neuconw, nerf], loss_from_outputs, lr=1e-3, eps=1e-7, clip=0.99)
+    assert train.opt.loss_scale.data_ptr() == rdr.loss_scale.tensor(train.fp.flat.device).data_ptr()
+    rays, ts, label, rgbs = [t.cuda() for t in synth_rays(64, seed=12, n_vocab=64)]
+    bg = torch.zeros(1, 3, device="cuda")
+    p0 = train.fp.flat.detach().clone()
+    losses = []
+    for i in range(60):
+        loss, _ = train(rays, ts, label, rgbs, background_rgb=bg, cos_anneal_ratio=0.0, perturb_overwrite=0)
+        losses.append(float(loss))
+    skipped, applied, final = train.opt.skipped_steps, train.opt.step_count, rdr.grad_scale
+    print("skipped %d applied %d final scale 2^%d; loss %.4f -> %.4f" % (skipped, applied, round(__import__("math").log2(final)),
+                                                                         losses[0], losses[-1]))
+    assert skipped >= 5 and applied >= 10 and skipped + applied == 60
+    assert final < 2.0 ** 36 and bool(torch.isfinite(train.fp.flat).all()) and not torch.equal(train.fp.flat, p0)
+    assert losses[-1] < losses[0]

@@ -83,16 +83,15 @@ def test_captured_step_replays_like_eager():
             losses.append(float(loss))
         if capture:
             assert train._graphs is not None  # steps 3.. were graph replays
-        nstep = (train.opt.step_count if train.native  # eager: FlatAdam (C ABI); captured: torch's capturable Adam
-                 else float(train.opt.state[train.fp.flat]["step"]))
+        assert train.native  # both: FlatAdam through the C ABI; its step counter / bias corrections live on the device
+        nstep = train.opt.step_count
         runs.append((losses, named_params(emb, neuconw, nerf), float(out["color"].abs().sum()), nstep))
     (la, pa, ca, na), (lb, pb, cb, nb) = runs
     assert na == nb == steps  # Adam's bias correction advanced once per replay
     for a, b in zip(la, lb):
         assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (la, lb)
     assert la[0] != la[-1]
-    # Eager = FlatAdam through the C ABI, captured = torch's capturable fused Adam: two implementations of the same
-    # update.  The weight-gradient atomics are order-dependent in the last bit and Adam turns the sign of a ~0
+    # The weight-gradient atomics are order-dependent in the last bit and Adam turns the sign of a ~0
     # gradient into a +-lr step, so single elements may differ by a fraction of lr; a bookkeeping error (stale
     # packed weights, a wrong step count: >= 16 % of EVERY update, i.e. >= 1e-4 here) would move the bulk.
     diffs = torch.cat([(pa[k] - pb[k]).abs().reshape(-1) for k in pa])
@@ -103,7 +102,8 @@ def test_captured_step_replays_like_eager():
 
 
 def test_flat_adam_matches_torch_adam():
-    """ncw_adam_step (clip + Adam in one launch) against clip_grad_norm_ + torch.optim.Adam on the same flat data."""
+    """ncw_adam_step_dev (clip + Adam, step state on the device) against clip_grad_norm_ + torch.optim.Adam on the same
+    flat data."""
     from neuralrecon_w_amd.trainer import FlatAdam, FlatParams
 
     torch.manual_seed(0)
