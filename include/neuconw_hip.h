@@ -69,6 +69,9 @@ typedef struct NcwPackDesc {
     float scale;         /* e.g. 1/sqrt(2) folded into the skip layer             */
     int32_t nseg;
     NcwSeg seg[NCW_MAX_SEGS];
+    int32_t residual;    /* 16-bit only: 1 = store the ROUNDING RESIDUAL lo = h16(w - h16(w)) instead of h16(w): the
+                          * second half of a split (hi + lo) weight matrix, NcwSdfNet.w_lo */
+    int32_t _pad;
 } NcwPackDesc;
 
 /* descs: device array of n descriptors; row_prefix: device int32[n+1] exclusive prefix sum of
@@ -117,6 +120,15 @@ typedef struct NcwSdfNet {
     int32_t rb;           /* hidden width / 32 (2, 8 or 16)                 */
     int32_t multires;     /* 6                                              */
     float scale;          /* SDFNetwork.scale                               */
+    int32_t _pad;
+    /* Split-precision VALUE path (fp16 mode, W = 256): w_lo[l] = the rounding residuals of w[l] in the same packed layout
+     * (NcwPackDesc.residual), or all NULL.  When present, ncw_sdf_infer* and the forward sweep of ncw_sdf_fwd evaluate
+     * sdf with activations AND weights as fp16 hi + lo pairs, three MFMAs per product (hi.hi + lo.hi + hi.lo, f32
+     * accumulate): ~2^-22 relative, i.e. fp32-like SDF values at fp16 MFMA rate.  sigmoid(sdf * inv_s) multiplies an SDF
+     * error by inv_s = exp(10 variance) -- 20 at initialisation, several hundred where NeuS trains (models/neuconw.py:
+     * 173-179, rendering/renderer.py:624-632) -- so the 5e-4 of a plain fp16 evaluation is 0.2 in the sigmoid's argument there.
+     * The adjoint / backward passes and the feature rows stay plain fp16. */
+    const void* w_lo[NCW_MAX_LAYERS];
 } NcwSdfNet;
 
 /* a-2 `sdf(x)` (neuconw.py:281-282): x [n,3] f32 -> sdf [n] f32.  No grad, last layer 1 row. */

@@ -45,10 +45,13 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
     typedef NerfShapes<P, RBN, RBH> SH;
     NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
+    n = points_count(src, n);  // mode 4 (dead-background elimination): the selection's size, read on the device
+    if ((int64_t)blockIdx.x * (blockDim.x >> 6) * 32 >= n) return;  // surplus workgroup (uniform: before any barrier / DMA)
     ring_prologue(ring, net.w_p[0], SH::FCB_P0);
     int64_t tile, p, ray;
     bool valid;
     tile_setup(n, tile, p, valid, lane);
+    const int64_t ps = point_slot(src, p);  // density / rgb are addressed by the ray sample
     float p4[4];
     if (x4) {
         p4[0] = x4[p * 4 + 0]; p4[1] = x4[p * 4 + 1]; p4[2] = x4[p * 4 + 2]; p4[3] = x4[p * 4 + 3];
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
         CVec<1> o;
         load_bias(o, net.b_alpha, lane);
         mma_stream<RBN, 1, 32 * RBN, SH::SLOT>(o, ha, ring, (const WE*)net.w_alpha, net.w_feat, SH::FCB_P, lane);
-        if (valid && lane < 32) density[p] = o.v[0][0];
+        if (valid && lane < 32) density[ps] = o.v[0][0];
     }
     Act<P, RBN + 3> cat1;
     {
@@ -142,9 +145,9 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
     load_bias(o, net.b_rgb, lane);
     mma_stream<RBH, 1, 32 * RBH, SH::SLOT>(o, ea, ring, (const WE*)net.w_rgb, nullptr, 0, lane);
     if (valid && lane < 32) {  // raw rgb, no sigmoid (nerf.py:181)
-        rgb[p * 3 + 0] = o.v[0][0];
-        rgb[p * 3 + 1] = o.v[0][1];
-        rgb[p * 3 + 2] = o.v[0][2];
+        rgb[ps * 3 + 0] = o.v[0][0];
+        rgb[ps * 3 + 1] = o.v[0][1];
+        rgb[ps * 3 + 2] = o.v[0][2];
     }
 }
 
@@ -159,19 +162,22 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void nerf_bwd_kernel(NcwNerfN
     typedef NerfShapes<P, RBN, RBH, 2> SH;
     NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
+    n = points_count(src, n);  // mode 4: the selection's size, read on the device
+    if ((int64_t)blockIdx.x * (blockDim.x >> 6) * 32 >= n) return;  // surplus workgroup (uniform: before any barrier / DMA)
     ring_prologue(ring, net.wt_rgb, SH::FCB_TRGB);
     int64_t tile, p, ray;
     bool valid;
     tile_setup(n, tile, p, valid, lane);
-    ray = (src.mode == 0) ? p : p / src.per_ray;
+    const int64_t ps = point_slot(src, p);  // cotangents (and the d_a_rows row) are addressed by the ray sample
+    ray = (src.mode == 0) ? ps : ps / src.per_ray;
     const float vm = valid ? 1.f : 0.f;
 
     CVec<1> zr;
     cvec_zero(zr);
     if (lane < 32) {
-        zr.v[0][0] = d_rgb[p * 3 + 0] * vm;
-        zr.v[0][1] = d_rgb[p * 3 + 1] * vm;
-        zr.v[0][2] = d_rgb[p * 3 + 2] * vm;
+        zr.v[0][0] = d_rgb[ps * 3 + 0] * vm;
+        zr.v[0][1] = d_rgb[ps * 3 + 1] * vm;
+        zr.v[0][2] = d_rgb[ps * 3 + 2] * vm;
     }
     stash_store<1>((SE*)st.zrgb, tile, zr, lane);
     Act<P, 1> zra;
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void nerf_bwd_kernel(NcwNerfN
         mma_stream<RBH, RBN + 3, 32 * RBH, SH::SLOT>(q, zea, ring, (const WE*)net.wt_a[0], net.wt_feat, SH::FCB_P, lane);
         CVec<3> qa;
         qa.v[0] = q.v[RBN]; qa.v[1] = q.v[RBN + 1]; qa.v[2] = q.v[RBN + 2];
-        accumulate_d_a(qa, d_a, ray, net.n_a, valid, lane, d_a_rows, p);
+        accumulate_d_a(qa, d_a, ray, net.n_a, valid, lane, d_a_rows, ps);
         CVec<RBN> zf;
 #pragma unroll
         for (int rb = 0; rb < RBN; ++rb) zf.v[rb] = q.v[rb];
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, 2) void nerf_bwd_kernel(NcwNerfN
         to_act(zfa, zf);
         CVec<1> zal;
         cvec_zero(zal);
-        zal.v[0][0] = (lane < 32) ? d_density[p] * vm : 0.f;
+        zal.v[0][0] = (lane < 32) ? d_density[ps] * vm : 0.f;
         stash_store<1>((SE*)st.zalpha, tile, zal, lane);
         Act<P, 1> zala;
         to_act(zala, zal);
@@ -269,7 +275,6 @@ extern "C" int NCW_FN(ncw_nerf_fwd)(const NcwNerfNet* net, int prec, const NcwPo
     static const int fwd8 = getenv("NCW_NERF_FWD8") ? atoi(getenv("NCW_NERF_FWD8")) : 1;
     if (fwd8 > 0 && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 && net->n_head <= 4)
         return NCW_FN(ncw_nerf_fwd8_launch)(net, *pts, x4, n, a, density, rgb, *stash, st);
-    if (pts->mode == 4) return NCW_E_UNSUPPORTED;  // point selections: the W = 256 16-bit kernels only
     NCW_NERF_DISPATCH(nerf_fwd_kernel, *net, *pts, x4, n, a, density, rgb, *stash);
     return 0;
 }
@@ -278,6 +283,7 @@ extern "C" int NCW_FN(ncw_nerf_bwd)(const NcwNerfNet* net, int prec, const NcwPo
                                     const float* d_rgb, float* d_a, float* d_a_rows, const NcwNerfStash* stash, void* stream) {
     NCW_FORWARD_F16(prec, ncw_nerf_bwd_f16(net, NCW_PREC_BF16, pts, n, d_density, d_rgb, d_a, d_a_rows, stash, stream));
     if (!nerf_ok(net) || !pts || !stash || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
+    if (pts->mode == 4 && (!pts->idx || !pts->count)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (0.44 vs 0.49 ms per 135,168 points);
@@ -286,7 +292,6 @@ extern "C" int NCW_FN(ncw_nerf_bwd)(const NcwNerfNet* net, int prec, const NcwPo
     if (bwd8 > 0 && d_a_rows == nullptr && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 &&
         net->n_head <= 4)
         return NCW_FN(ncw_nerf_bwd8_launch)(net, *pts, n, d_density, d_rgb, d_a, *stash, st);
-    if (pts->mode == 4) return NCW_E_UNSUPPORTED;
     NCW_NERF_DISPATCH(nerf_bwd_kernel, *net, *pts, n, d_density, d_rgb, d_a, d_a_rows, *stash);
     return 0;
 }

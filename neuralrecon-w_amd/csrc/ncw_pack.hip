@@ -64,8 +64,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const NcwPackDesc* __restrict
             const int k = transpose ? o_log : k_log;
             const size_t idx = packed_index(o, k, rb_out, prec);
             if (prec == NCW_PREC_F32) reinterpret_cast<float*>(dst_w)[idx] = v;
-            else if (prec == NCW_PREC_F16) reinterpret_cast<_Float16*>(dst_w)[idx] = (_Float16)v;
-            else reinterpret_cast<__bf16*>(dst_w)[idx] = (__bf16)v;
+            else if (prec == NCW_PREC_F16) {
+                const _Float16 hi = (_Float16)v;  // residual: the low half of a split (hi + lo) matrix
+                reinterpret_cast<_Float16*>(dst_w)[idx] = D.residual ? (_Float16)(v - (float)hi) : hi;
+            } else {
+                const __bf16 hi = (__bf16)v;
+                reinterpret_cast<__bf16*>(dst_w)[idx] = D.residual ? (__bf16)(v - (float)hi) : hi;
+            }
         }
     }
     if (D.dst_b != nullptr && D.bias != nullptr && lane == 0) {
@@ -209,7 +214,7 @@ extern "C" int ncw_stash_to_rows(int prec, const void* stash, int64_t n, int F, 
     return 0;
 }
 
-extern "C" int ncw_abi_version(void) { return 9; }
+extern "C" int ncw_abi_version(void) { return 10; }
 
 extern "C" int ncw_device_info(char* buf, int buflen) {
     int cnt = 0;

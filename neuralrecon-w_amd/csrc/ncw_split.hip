@@ -1,0 +1,381 @@
+// Split-precision SDF VALUE path, W = 256, fp16 build only: sdf_inferS, sdf_fwdS.
+//
+// NeuS turns the SDF into opacity through sigmoid(sdf * inv_s), inv_s = exp(10 * variance) (models/neuconw.py:173-179,
+// rendering/renderer.py:624-632; the sampler uses fixed 512 / 1024, renderer.py:527-533).  inv_s is 20 at initialisation and
+// several hundred where NeuS trains, so the 3-9e-4 absolute SDF error of one fp16 rounding per operand is 0.1-0.4 in the
+// sigmoid's argument there: measured 2e-2 on the rendered colours at inv_s = 403 against 1.5e-4 for the exact-fp32 mode.
+// Every layer contributes equally (scripts/diag/emul16.py: splitting only the last layers, or only weights, or only
+// activations, does not help), so the whole value chain gamma -> 8 Softplus layers -> sdf row runs here with BOTH operands
+// as fp16 hi + lo pairs:   W h  ~=  W_hi h_hi + W_lo h_hi + W_hi h_lo   (three MFMAs, f32 accumulate; the dropped
+// W_lo h_lo term is 2^-22 relative) -- fp32-like SDF values on the fp16 matrix pipe, which these kernels leave 75 % idle
+// anyway.  The feature rows, the adjoint sweep (normals) and the whole backward stay plain fp16: their errors are not
+// multiplied by inv_s.
+//
+// Structure: the weights-stationary layout of ncw_sdf8.hip (8 waves own the 8 output blocks of a layer; the 128 points'
+// activations live in LDS as B fragments, here [tile][k-unit][hi | lo][64 lanes] = 128 KiB, ONE buffer rewritten in place:
+// every wave keeps its block's 4 tile accumulators until all waves have finished reading the layer input).  A layer's
+// weight slice is 2 x 64 registers (hi + lo), so it is streamed in two K-halves through two static register sets
+// (A: units 0..7, B: units 8..15), each half prefetched while the other is in use.
+#include "ncw_mlp.h"
+
+#ifdef NCW_HALF_F16
+
+namespace {
+
+constexpr int SS_WAVES = 8, SS_TILES = 4;
+constexpr int SS_ACT = SS_TILES * 16 * 2 * 1024;  // [tile][16 units][hi | lo][64 lanes x 16 B]
+constexpr int SS_GAM = SS_TILES * 3 * 2 * 1024;   // gamma: [tile][3 units][hi | lo][64 lanes x 16 B]
+constexpr int SB_ACT = SS_TILES * 16 * 1024;      // the adjoint sweep's plain buffers (ncw_sdf8.hip layout), aliased
+
+typedef __attribute__((address_space(3))) bf16x8 ss_lfrag;
+
+NCW_DEV bf16x8 ss_gload(const void* w, size_t unit, int lane) {
+    typedef const __attribute__((address_space(1))) bf16x8* gp;
+    return ((gp)w)[unit * 64 + lane];
+}
+
+// units [u0, u0 + NU) of output block ob of a packed matrix (hi) and of its residual matrix (lo)
+template <int NU>
+NCW_DEV void ss_load_half(bf16x8 (&h)[NU], bf16x8 (&l)[NU], const void* w, const void* wlo, int rb_stride, int ob, int u0, int lane) {
+#pragma unroll
+    for (int q = 0; q < NU; ++q) {
+        h[q] = ss_gload(w, (size_t)(u0 + q) * rb_stride + ob, lane);
+        l[q] = ss_gload(wlo, (size_t)(u0 + q) * rb_stride + ob, lane);
+    }
+}
+
+// fp16 hi + lo images of accumulator registers 8t..8t+7 (one k-unit of the next layer)
+NCW_DEV void ss_split8(const f32x16& v, int t, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[8 * t + e];
+        const ncw_h16 h = (ncw_h16)x;
+        hi[e] = h;
+        lo[e] = (ncw_h16)(x - (float)h);
+    }
+}
+
+// acc[t] += W[ob, units u0 .. u0 + NU) . in[t, the same units], three MFMAs per unit; tiles in pairs so that consecutive
+// MFMAs alternate between two accumulators
+template <int NU>
+NCW_DEV void ss_mma(f32x16 (&acc)[SS_TILES], const bf16x8 (&wh)[NU], const bf16x8 (&wl)[NU], const ss_lfrag* in, int upt, int u0) {
+#pragma unroll
+    for (int tp = 0; tp < SS_TILES; tp += 2) {
+#pragma unroll
+        for (int q = 0; q < NU; ++q) {
+            const ss_lfrag* p0 = in + ((tp * upt + u0 + q) * 2) * 64;
+            const ss_lfrag* p1 = in + (((tp + 1) * upt + u0 + q) * 2) * 64;
+            const bf16x8 bh0 = p0[0], bl0 = p0[64], bh1 = p1[0], bl1 = p1[64];
+            acc[tp] = NCW_MFMA_H(wh[q], bh0, acc[tp], 0, 0, 0);
+            acc[tp + 1] = NCW_MFMA_H(wh[q], bh1, acc[tp + 1], 0, 0, 0);
+            acc[tp] = NCW_MFMA_H(wl[q], bh0, acc[tp], 0, 0, 0);
+            acc[tp + 1] = NCW_MFMA_H(wl[q], bh1, acc[tp + 1], 0, 0, 0);
+            acc[tp] = NCW_MFMA_H(wh[q], bl0, acc[tp], 0, 0, 0);
+            acc[tp + 1] = NCW_MFMA_H(wh[q], bl1, acc[tp + 1], 0, 0, 0);
+        }
+    }
+}
+
+NCW_DEV f32x16 ss_bias(const float* bp, int ob, int lane) {
+    CVec<1> b1;
+    load_bias(b1, bp + ob * 32, lane);
+    return b1.v[0];
+}
+
+NCW_DEV void ss_load_sprime(f32x16& sv, const ncw_h16* __restrict__ st_h, size_t tile, int RB, int rb, int lane) {
+    stash_load_block(sv, st_h, tile, RB, rb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = 1.f - __builtin_amdgcn_exp2f(sv[r] * -144.26950408889634f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The value chain: gamma (exact sin / cos) -> layers 0 .. L-2 (Softplus, f32 epilogue, hi + lo split) -> sdf row.
+// Leaves h_{L-1} (hi | lo) of the 128 points in abuf.  STASH: also writes the activation stash of ncw_sdf_fwd
+// (gamma, h_1 .. h_{L-1}: the fp16 roundings, i.e. the hi parts -- what the plain kernel stashes).
+// ------------------------------------------------------------------------------------------------
+template <bool STASH>
+NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t n, int64_t tile0, ss_lfrag* abuf, ss_lfrag* gbuf,
+                            int lane, int wave, float* __restrict__ sdf, const NcwSdfStash& st) {
+    typedef ncw_h16 SE;
+    const int L = net.n_layers;
+    if (wave < SS_TILES) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        if (p >= n) p = n - 1;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+        CVec<2> gam;
+        freq_encode<2, 3, 6, false>(gam, xs, lane);  // sinf / cosf: the hardware v_sin / v_cos are not fp32-accurate
+        if (STASH) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            bf16x8 hi, lo;
+            ss_split8(gam.v[q >> 1], q & 1, hi, lo);
+            gbuf[((wave * 3 + q) * 2 + 0) * 64 + lane] = hi;
+            gbuf[((wave * 3 + q) * 2 + 1) * 64 + lane] = lo;
+        }
+    }
+    bf16x8 Ah[8], Al[8], Bh[8], Bl[8];  // the two K-halves of the current layer's slice (hi, lo)
+    f32x16 acc[SS_TILES];
+    const ss_lfrag* const ain = abuf + lane;
+    const ss_lfrag* const gin = gbuf + lane;
+    // hidden-layer epilogue: Softplus, stash, hi / lo fragments of this wave's block into abuf (in place)
+    auto epilogue = [&](int l_out) {
+        __syncthreads();  // every wave has finished reading the layer input
+#pragma unroll
+        for (int t = 0; t < SS_TILES; ++t) {
+            f32x16 yv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[t][r], y, s); yv[r] = y; }
+            if (STASH) stash_store_block((SE*)st.h[l_out], (size_t)(tile0 + t), 8, wave, yv, lane);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                bf16x8 hi, lo;
+                ss_split8(yv, tt, hi, lo);
+                abuf[((t * 16 + 2 * wave + tt) * 2 + 0) * 64 + lane] = hi;
+                abuf[((t * 16 + 2 * wave + tt) * 2 + 1) * 64 + lane] = lo;
+            }
+        }
+        __syncthreads();  // the layer output is complete
+    };
+    // ---- layer 0: K = 39, the 3 gamma units ------------------------------------------------------------------
+    {
+        bf16x8 w0h[3], w0l[3];
+        ss_load_half<3>(w0h, w0l, net.w[0], net.w_lo[0], 8, wave, 0, lane);
+        if (L - 1 > 1) ss_load_half<8>(Ah, Al, net.w[1], net.w_lo[1], 8, wave, 0, lane);
+        const f32x16 bias = ss_bias(net.b[0], wave, lane);
+#pragma unroll
+        for (int t = 0; t < SS_TILES; ++t) acc[t] = bias;
+        __syncthreads();  // gamma visible
+        ss_mma<3>(acc, w0h, w0l, gin, 3, 0);
+        epilogue(1);
+    }
+    // ---- hidden layers 1 .. L-2 ------------------------------------------------------------------------------
+    for (int l = 1; l < L - 1; ++l) {
+        const f32x16 bias = ss_bias(net.b[l], wave, lane);
+#pragma unroll
+        for (int t = 0; t < SS_TILES; ++t) acc[t] = bias;
+        ss_load_half<8>(Bh, Bl, net.w[l], net.w_lo[l], 8, wave, 8, lane);  // second half: lands during the first
+        ss_mma<8>(acc, Ah, Al, ain, 16, 0);
+        if (l + 1 < L - 1) ss_load_half<8>(Ah, Al, net.w[l + 1], net.w_lo[l + 1], 8, wave, 0, lane);  // next layer, first half
+        ss_mma<8>(acc, Bh, Bl, ain, 16, 8);
+        if (l == net.skip_layer) {  // the gamma columns: units 16..18 (once per launch: loaded just in time)
+            bf16x8 wgh[3], wgl[3];
+            ss_load_half<3>(wgh, wgl, net.w[l], net.w_lo[l], 8, wave, 16, lane);
+            ss_mma<3>(acc, wgh, wgl, gin, 3, 0);
+        }
+        epilogue(l + 1);
+    }
+    // ---- sdf row (1 output block), tile t by wave t ------------------------------------------------------------
+    if (wave < SS_TILES) {
+        CVec<1> o;
+        load_bias(o, net.b[L - 1], lane);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bf16x8 wh[8], wl[8];
+            ss_load_half<8>(wh, wl, net.w[L - 1], net.w_lo[L - 1], 1, 0, 8 * half, lane);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const ss_lfrag* p = ain + ((wave * 16 + 8 * half + q) * 2) * 64;
+                const bf16x8 bh = p[0], bl = p[64];
+                o.v[0] = NCW_MFMA_H(wh[q], bh, o.v[0], 0, 0, 0);
+                o.v[0] = NCW_MFMA_H(wl[q], bh, o.v[0], 0, 0, 0);
+                o.v[0] = NCW_MFMA_H(wh[q], bl, o.v[0], 0, 0, 0);
+            }
+        }
+        const int64_t p = (tile0 + wave) * 32 + (lane & 31);
+        if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+    }
+}
+
+__global__ __launch_bounds__(64 * SS_WAVES) void sdf_inferS_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                  float* __restrict__ sdf) {
+    __shared__ __attribute__((aligned(16))) char lds[SS_ACT + SS_GAM];
+    ss_lfrag* const abuf = (ss_lfrag*)(ncw_lchar*)lds;
+    ss_lfrag* const gbuf = abuf + SS_ACT / 16;
+    const int lane = ncw_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    NcwSdfStash none = {};
+    ss_value_chain<false>(net, src, n, (int64_t)blockIdx.x * SS_TILES, abuf, gbuf, lane, wave, sdf, none);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sdf_fwd: the split value chain (with the activation stash), then -- plain fp16, exactly the arithmetic of
+// sdf_fwdB_kernel (ncw_sdf8.hip) -- the feature rows, the analytic adjoint sweep with the t_l stash and grad = J_gamma^T g_gamma.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) bf16x8 sb_lfrag;
+
+template <int NU>
+NCW_DEV void sb_load_slice(bf16x8* a, const void* w, int rb_stride, int ob, int u0, int lane) {
+#pragma unroll
+    for (int q = 0; q < NU; ++q) a[q] = ss_gload(w, (size_t)(u0 + q) * rb_stride + ob, lane);
+}
+
+NCW_DEV void sb_store_units(sb_lfrag* buf, int t, int ob, const f32x16& v, int lane) {
+    Act<PrecBF16, 1> o;
+    to_act_block<1>(o, 0, v);
+    buf[(t * 16 + 2 * ob) * 64 + lane] = o.f[0];
+    buf[(t * 16 + 2 * ob + 1) * 64 + lane] = o.f[1];
+}
+
+__global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                float* __restrict__ sdf, float* __restrict__ grad,
+                                                                NcwSdfStash st) {
+    typedef ncw_h16 SE;
+    __shared__ __attribute__((aligned(16))) char lds[SS_ACT + SS_GAM];
+    ss_lfrag* const sbuf = (ss_lfrag*)(ncw_lchar*)lds;
+    ss_lfrag* const gbuf = sbuf + SS_ACT / 16;
+    const int lane = ncw_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int L = net.n_layers;
+    const int64_t tile0 = (int64_t)blockIdx.x * SS_TILES;
+    const int jb = wave & 1, jt = wave >> 1;  // this wave's gamma job of the adjoint sweep: block jb of tile jt
+    ss_value_chain<true>(net, src, n, tile0, sbuf, gbuf, lane, wave, sdf, st);
+    // ---- feature rows (plain fp16: the colour network reads them from the fp16 stash): W_feat . h_hi ----------------
+    bf16x8 wa[16], wb[16];
+    {
+        sb_load_slice<16>(wa, net.w_feat, 8, wave, 0, lane);
+        const bf16x8 wt1 = ss_gload(net.wt[L - 1], (size_t)wave, lane);  // W_{L-1}^T: unit 0, block = wave
+        if (L - 2 >= 1) sb_load_slice<16>(wb, net.wt[L - 2], (L - 2 == net.skip_layer) ? 10 : 8, wave, 0, lane);
+        const f32x16 bias = ss_bias(net.b_feat, wave, lane);
+        const ss_lfrag* const ain = sbuf + lane;
+#pragma unroll
+        for (int tp = 0; tp < SS_TILES; tp += 2) {
+            f32x16 acc0 = bias, acc1 = bias;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = NCW_MFMA_H(wa[q], ain[((tp * 16 + q) * 2) * 64], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wa[q], ain[(((tp + 1) * 16 + q) * 2) * 64], acc1, 0, 0, 0);
+            }
+            stash_store_block((SE*)st.feat, (size_t)(tile0 + tp), 8, wave, acc0, lane);
+            stash_store_block((SE*)st.feat, (size_t)(tile0 + tp + 1), 8, wave, acc1, lane);
+        }
+        // ---- adjoint start: a_{L-2} = W_{L-1}^T e_0 (the same for every point); t_{L-2} = a * phi'(z_{L-2}) ----------
+        bf16x8 e0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) e0f[e] = (ncw_h16)0.f;
+        e0f[0] = (ncw_h16)(lane < 32 ? 1.f : 0.f);
+        f32x16 a0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0[r] = 0.f;
+        a0 = NCW_MFMA_H(wt1, e0f, a0, 0, 0, 0);
+        __syncthreads();  // every wave is done with the split buffer (feature rows, sdf row): the plain buffers alias it
+        sb_lfrag* out = (sb_lfrag*)sbuf;  // abuf0
+#pragma unroll
+        for (int t = 0; t < SS_TILES; ++t) {
+            f32x16 sv;
+            ss_load_sprime(sv, (const SE*)st.h[L - 1], (size_t)(tile0 + t), 8, wave, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] *= a0[r];
+            stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 8, wave, sv, lane);
+            sb_store_units(out, t, wave, sv, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+    }
+    sb_lfrag* const abuf0 = (sb_lfrag*)sbuf;
+    sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
+    int cur = 0;  // t_{L-2} lives in abuf0
+    // ---- adjoint layers l = L-2 .. 1: t_{l-1} = (W_l^T t_l) * phi'(z_{l-1});  wa = slice of wt[l] ---------------
+    f32x16 gg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gg[r] = 0.f;
+    for (int l = L - 2; l >= 1; --l) {
+        const bool skip = (l == net.skip_layer);
+        if (!skip && l - 1 >= 1) sb_load_slice<16>(wb, net.wt[l - 1], (l - 1 == net.skip_layer) ? 10 : 8, wave, 0, lane);
+        __syncthreads();  // t_l complete in abuf[cur]
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SS_TILES; tp += 2) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16& acc = j ? acc1 : acc0;
+                f32x16 sv;
+                ss_load_sprime(sv, (const SE*)st.h[l], (size_t)(tile0 + tp + j), 8, wave, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[r] *= acc[r];
+                stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + tp + j), 8, wave, sv, lane);
+                sb_store_units(out, tp + j, wave, sv, lane);
+            }
+        }
+        if (skip) {  // the gamma columns of the transposed skip layer: out-blocks 8, 9 (one (block, tile) job per wave)
+            sb_load_slice<16>(wb, net.wt[l], 10, 8 + jb, 0, lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) gg = NCW_MFMA_H(wb[q], in[(jt * 16 + q) * 64 + lane], gg, 0, 0, 0);
+            if (l - 1 >= 1) sb_load_slice<16>(wb, net.wt[l - 1], (l - 1 == net.skip_layer) ? 10 : 8, wave, 0, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
+        cur ^= 1;
+    }
+    // ---- adjoint layer 0: g_gamma += W_0^T t_0 (2 out-blocks), then grad = J_gamma^T g_gamma -----------------------
+    sb_load_slice<16>(wb, net.wt[0], 2, jb, 0, lane);
+    __syncthreads();
+    {
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) gg = NCW_MFMA_H(wb[q], in[(jt * 16 + q) * 64 + lane], gg, 0, 0, 0);
+    }
+    int64_t p = (tile0 + jt) * 32 + (lane & 31), ray;
+    const bool valid = p < n;
+    if (!valid) p = n - 1;
+    float xs[3];
+    load_point(src, p, xs, ray);
+    xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f0 = 32 * jb + ncw_feat_of(r, 0);
+        if (f0 >= 39) continue;  // (block 1 holds features 32..38 only)
+        int comp;
+        const float dv = freq_feature_deriv<3, 6, true>(xs, f0 + 4 * h, comp);
+        const float c = gg[r] * dv;
+        nx += comp == 0 ? c : 0.f;
+        ny += comp == 1 ? c : 0.f;
+        nz += comp == 2 ? c : 0.f;
+    }
+    nx = half_pair_sum(nx); ny = half_pair_sum(ny); nz = half_pair_sum(nz);
+    // combine the two blocks of a tile (waves 2 jt and 2 jt + 1) through LDS (the gamma region is free now)
+    typedef __attribute__((address_space(3))) float lfloat;
+    lfloat* part = (lfloat*)gbuf;
+    if (jb == 1 && lane < 32) {
+        part[(jt * 32 + lane) * 3 + 0] = nx; part[(jt * 32 + lane) * 3 + 1] = ny; part[(jt * 32 + lane) * 3 + 2] = nz;
+    }
+    __syncthreads();
+    if (jb == 0 && lane < 32 && valid) {
+        grad[p * 3 + 0] = nx + part[(jt * 32 + lane) * 3 + 0];
+        grad[p * 3 + 1] = ny + part[(jt * 32 + lane) * 3 + 1];
+        grad[p * 3 + 2] = nz + part[(jt * 32 + lane) * 3 + 2];
+    }
+}
+
+}  // namespace
+
+int ncw_sdf_inferS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(sdf_inferS_kernel, dim3((unsigned)((tiles + SS_TILES - 1) / SS_TILES)), dim3(64 * SS_WAVES), 0, st, *net,
+                       src, n, sdf);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+int ncw_sdf_fwdS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
+                            const NcwSdfStash& stash, hipStream_t st) {
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(sdf_fwdS_kernel, dim3((unsigned)((tiles + SS_TILES - 1) / SS_TILES)), dim3(64 * SS_WAVES), 0, st, *net, src,
+                       n, sdf, grad, stash);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+#endif  // NCW_HALF_F16

@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const NcwWgradDesc* __restri
     const int nqj = (D.rby + 3) >> 2;
     const int qi = quad / nqj, qj = quad - qi * nqj;
     const int nbi = min(4, D.rbx - 4 * qi), nbj = min(4, D.rby - 4 * qj);
+    // a product sized on the device (dead-background elimination, NcwPoints mode 4): its K-slices divide the tiles that
+    // exist; slices past the end contribute zero slabs (ordered mode) / nothing (atomics)
+    if (D.n_points_dev != nullptr) ntiles = min(ntiles, ((int64_t)D.n_points_dev[0] + 31) / 32);
     const int64_t tpk = (ntiles + ksplit - 1) / ksplit;
     const int64_t t_begin = (int64_t)ks * tpk, t_end = min(t_begin + tpk, ntiles);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

@@ -91,12 +91,10 @@ class NeRF(_PackedNet):
         return plan
 
     def supports_selection(self, prec):
-        """Point selections (NcwPoints mode 4, dead-background elimination) exist in the W = 256 16-bit kernels only."""
-        import os
-
-        if os.environ.get("NCW_NERF_FWD8", "1") == "0" or os.environ.get("NCW_NERF_BWD8", "1") == "0":
-            return False  # the weights-through-LDS kernels were asked for: they take whole launches only
-        return prec != L.PREC_F32 and self.W == 256 and 1 <= self.n_head <= 4
+        """Point selections (NcwPoints mode 4, dead-background elimination): every background kernel takes them (the
+        W = 256 16-bit weights-stationary kernels, and the generic weights-through-LDS kernels of the fp32 parity mode /
+        other widths / the reproducible d_a_rows path)."""
+        return True
 
     def fwd_stash(self, pts, n, prec, a, x4=None, select=None):
         """select = (z, O): pts are the R x (S + O) mode-2 samples of z_feed, z [R, S] the primary samples; evaluate only the

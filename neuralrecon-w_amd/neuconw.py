@@ -147,9 +147,21 @@ class SDFNetwork(nn.Module):
     def n_lin(self):
         return self.num_layers - 1
 
+    def split_value(self, prec):
+        """Split-precision VALUE path (NcwSdfNet.w_lo): fp16 mode at W = 256 evaluates sdf with hi + lo pairs of fp16
+        weights and activations (three MFMAs per product) -- fp32-like SDF values, which sigmoid(sdf * inv_s) needs once
+        inv_s is in the hundreds.  NEUCONW_SDF_SPLIT=0 (or `self.sdf_split = False`) switches it off."""
+        import os
+
+        on = self.__dict__.get("sdf_split")
+        if on is None:
+            on = os.environ.get("NEUCONW_SDF_SPLIT", "1") not in ("0", "")
+        return bool(on) and prec == L.PREC_F16 and self.d_hidden == 256 and self.n_lin >= 3
+
     def plan(self, prec):
         dev = self.lin0.bias.device
-        key = (prec, str(dev))
+        split = self.split_value(prec)
+        key = (prec, str(dev), split)
         p = self._plans.get(key)
         if p is not None:
             return p
@@ -158,7 +170,7 @@ class SDFNetwork(nn.Module):
         skip = self.skip_in[0] if self.skip_in else -1
         plan = PackPlan(dev, prec)
         net = L.NcwSdfNet()
-        slots = {}
+        slots, lo = {}, {}
         for l in range(Lm):
             v, g, b = _wvb(getattr(self, "lin%d" % l))
             n_out, n_in = v.shape
@@ -176,6 +188,9 @@ class SDFNetwork(nn.Module):
                 plan.add_pack(v, g, None, mt, None, segs, transpose=True, scale=scale)
                 plan.add_unpack(v, g, b, dn, segs, scale=scale)
                 slots[l] = (m, bs, mt, dn)
+                if split:
+                    lo[l] = plan.new_matrix(RB, rb_in)
+                    plan.add_pack(v, g, None, lo[l], None, segs, scale=scale, residual=True)
             else:  # last Linear: row 0 = sdf, rows 1..W = feature vector (neuconw.py:279)
                 m, bs = plan.new_matrix(1, RB), plan.new_bias(1)
                 mt = plan.new_matrix(RB, 1)
@@ -190,7 +205,12 @@ class SDFNetwork(nn.Module):
                 plan.add_unpack(v, g, b, dn, segs, row0=0, nrows=1)
                 plan.add_unpack(v, g, b, dnf, segs, row0=1, nrows=W)
                 slots[l] = (m, bs, mt, dn, mf, bf, mft, dnf)
+                if split:
+                    lo[l] = plan.new_matrix(1, RB)
+                    plan.add_pack(v, g, None, lo[l], None, segs, row0=0, nrows=1, residual=True)
         plan.finalize()
+        for l, m_lo in lo.items():
+            net.w_lo[l] = plan.mat_ptr(m_lo)
         for l in range(Lm):
             s = slots[l]
             net.w[l], net.b[l], net.wt[l] = plan.mat_ptr(s[0]), plan.bias_ptr(s[1]), plan.mat_ptr(s[2])

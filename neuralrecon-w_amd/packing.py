@@ -59,11 +59,13 @@ class PackPlan:
 
     # ---- descriptors ----------------------------------------------------------------------
     def add_pack(self, weight, g, bias, mat, bias_slot, segs, row0=0, nrows=None, drow0=0, transpose=False,
-                 scale=1.0):
-        """weight: [out, in] parameter (weight_v when g is given).  segs: [(col0, ncols, dcol0)]."""
+                 scale=1.0, residual=False):
+        """weight: [out, in] parameter (weight_v when g is given).  segs: [(col0, ncols, dcol0)].
+        residual: store h16(w - h16(w)) -- the low half of a split (hi + lo) 16-bit matrix."""
         nrows = weight.shape[0] - row0 if nrows is None else nrows
         self._pack.append(dict(weight=weight, g=g, bias=bias, mat=mat, bias_slot=bias_slot, segs=list(segs),
-                               row0=row0, nrows=nrows, drow0=drow0, transpose=bool(transpose), scale=float(scale)))
+                               row0=row0, nrows=nrows, drow0=drow0, transpose=bool(transpose), scale=float(scale),
+                               residual=bool(residual)))
 
     def add_unpack(self, weight, g, bias, dense, segs, row0=0, nrows=None, drow0=0, scale=1.0):
         nrows = weight.shape[0] - row0 if nrows is None else nrows
@@ -128,6 +130,7 @@ class PackPlan:
             d.transpose = 1 if p["transpose"] else 0
             d.prec = self.prec
             d.scale = p["scale"]
+            d.residual = 1 if p.get("residual") else 0
             d.nseg = len(p["segs"])
             assert d.nseg <= L.MAX_SEGS
             for i, (c0, nc, dc0) in enumerate(p["segs"]):

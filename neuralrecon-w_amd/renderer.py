@@ -52,9 +52,8 @@ class _RenderFn(torch.autograd.Function):
             # multiplied by 1 - inside_sphere = 0, forward and backward) and at the n_outside samples; the reference
             # evaluates the NeRF on all S + O samples all the same.  Identical outputs and gradients; bg_dense=True
             # evaluates everything like the reference.  (Columns are paired with primary samples by index, as there.)
-            ordered_ = rdr.reproducible if rdr.reproducible is not None else (prec == L.PREC_F32)
             select = None
-            if rdr.trim_sphere and not rdr.bg_dense and not ordered_ and nerf.supports_selection(prec):
+            if rdr.trim_sphere and not rdr.bg_dense and nerf.supports_selection(prec):
                 select = (z, M - S)
             density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select)
             density, bg_rgb = density.view(R, M), bg_rgb.view(R, M, 3)
@@ -118,7 +117,10 @@ class _RenderFn(torch.autograd.Function):
         if ctx.use_bg:
             M = comp.S + comp.O
             if ordered:
-                rows_bg = torch.empty(R * M, n_a, device=dev, dtype=torch.float32)
+                # with the elimination only the selected samples write their row (at the ray sample's slot): the others
+                # are the exact zeros the dense evaluation would have produced (their cotangents are zero)
+                rows_bg = (torch.zeros if nctx.get("sel_count") is not None else torch.empty)(R * M, n_a, device=dev,
+                                                                                             dtype=torch.float32)
                 nerf.bwd_stash(nctx, g["d_density"].view(R * M), g["d_bg_rgb"].view(R * M, 3), None, d_a_rows=rows_bg)
                 L.check(lib.ncw_ray_sum_rows(L.ptr(rows_bg), R, M, n_a, L.ptr(d_a), 1, L.stream_ptr(dev)),
                         "ncw_ray_sum_rows")
@@ -308,7 +310,8 @@ class NeuconWRenderer:
                              "512 is overridden by every shipped scene yaml (8 + 16)."
                              % (self.n_samples + self.n_importance + (self.boundary_samples or 0) + self.n_outside))
         # bg_dense=True: evaluate the background NeRF on every sample like the reference does, instead of only where the
-        # compositor can use it (dead-background elimination, _RenderFn.forward); NEUCONW_BG_DENSE=1 sets the default
+        # compositor can use it (dead-background elimination, _RenderFn.forward: every precision, incl. the reproducible
+        # fp32 parity mode); NEUCONW_BG_DENSE=1 sets the default
         self.bg_dense = os.environ.get("NEUCONW_BG_DENSE", "0") not in ("0", "")
         # loss scale of the fp16 mode (prec = PREC_F16; unused otherwise): a power of two kept on the device, see
         # _RenderFn.backward.  `grad_scale` (property) reads / sets it; trainer.FlatAdam adapts it (halves after a step

@@ -102,7 +102,6 @@ class WgradBatch:
                 d.rbx, d.rby, d.ld = rbx, rby, ld
                 d.ksplit, d.n_points = (ksp, ni) if tile is not None else (0, 0)
                 if ndev:
-                    assert tile is not None, "device-sized products need the 16-bit tiled launch"
                     d.n_points_dev = ndev
                 descs.append(d)
                 prefix.append(prefix[-1] + ((rbx + xb - 1) // xb) * ((rby + yb - 1) // yb) * ksp)

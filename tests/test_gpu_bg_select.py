@@ -1,7 +1,8 @@
 """GPU: dead-background elimination (ncw_bg_select + NcwPoints mode 4 + NcwWgradDesc.n_points_dev).  With trim_sphere the
 compositor multiplies the background NeRF's output of a primary sample inside the unit sphere by 1 - inside_sphere = 0
-(/root/reference rendering/renderer.py:637,693-708), forward and backward, so the 16-bit modes evaluate the NeRF only
-where it can matter.  Nothing observable may change: rendered outputs bitwise, parameter gradients to summation order."""
+(/root/reference rendering/renderer.py:637,693-708), forward and backward, so every mode (16-bit and the fp32 parity mode)
+evaluates the NeRF only where it can matter.  Nothing observable may change: rendered outputs bitwise, parameter gradients
+to summation order (the weight-gradient K-slices cover different point sets)."""
 import pytest
 import torch
 
@@ -50,11 +51,13 @@ def test_selection_list_matches_torch():
     assert 0.05 < float(inside.float().mean()) < 0.95  # the case exercises both branches
 
 
-@pytest.mark.parametrize("prec_name", ["f16", "bf16"])
+@pytest.mark.parametrize("prec_name", ["f16", "bf16", "f32"])
 def test_elimination_changes_nothing(prec_name):
+    """f32: the generic weights-through-LDS NeRF kernels in mode 4, per-point appearance-code rows at the ray sample's slot,
+    order-fixed split-K over the tiles that exist (the parity mode stays bitwise run-to-run reproducible: test_gpu_repro.py)."""
     import neuralrecon_w_amd as nw
 
-    prec = {"f16": nw.PREC_F16, "bf16": nw.PREC_BF16}[prec_name]
+    prec = {"f16": nw.PREC_F16, "bf16": nw.PREC_BF16, "f32": nw.PREC_F32}[prec_name]
     res = {}
     for dense in (True, False):
         emb, neuconw, nerf, rdr = build_system(W=256, n_a=48, n_vocab=64, nerf_w=256, color_hidden=256, head=128, seed=5,
@@ -77,10 +80,14 @@ def test_elimination_changes_nothing(prec_name):
     worst = max(rel_err(ge[k], gd[k]) for k in gd)
     print("%s: inside fraction %.2f, worst parameter-gradient difference dense vs eliminated %.2e" % (prec_name, frac, worst))
     assert set(gd) == set(ge) and worst < 2e-5, worst  # f32 atomics of the weight-gradient slices: summation order only
+    if prec_name == "f32":  # nothing of the SDF / colour networks changes at all; only the background sums re-associate
+        for k in gd:
+            if not k.startswith("nerf.") and not k.startswith("embedding"):
+                assert torch.equal(gd[k], ge[k]), k
 
 
 def test_selection_is_refused_elsewhere():
-    """mode-4 points reach only the W = 256 16-bit background kernels: every other entry point refuses them loudly"""
+    """mode-4 points reach the background kernels only: the SDF entry points refuse them loudly"""
     import neuralrecon_w_amd as nw
     from neuralrecon_w_amd import lib as L
     from neuralrecon_w_amd.neuconw import points_struct
@@ -98,8 +105,27 @@ def test_selection_is_refused_elsewhere():
     out = torch.empty(64, device="cuda")
     rc = L.get_lib().ncw_sdf_infer_points(plan.net, nw.PREC_BF16, pts4, 64, L.ptr(out), L.stream_ptr(out.device))
     assert rc == -2  # NCW_E_UNSUPPORTED
-    emb, neuconw, nerf, rdr = build_system(seed=1, prec=nw.PREC_F32)  # W = 64 background net, fp32
-    assert not nerf.supports_selection(nw.PREC_F32) and not nerf.supports_selection(nw.PREC_F16)
+
+
+def test_elimination_in_the_small_generic_kernels():
+    """W = 64 background net (generic kernels in every precision), fp32 and fp16: dense vs eliminated."""
+    import neuralrecon_w_amd as nw
+
+    for prec in (nw.PREC_F32, nw.PREC_F16):
+        res = {}
+        for dense in (True, False):
+            emb, neuconw, nerf, rdr = build_system(seed=2, prec=prec)
+            rdr.bg_dense = dense
+            rays, ts, label, rgbs = _rays_crossing_the_sphere(70, 9)
+            out = rdr.render(rays.cuda(), ts.cuda(), label.cuda(), perturb_overwrite=0, background_rgb=torch.zeros(1, 3).cuda(),
+                             cos_anneal_ratio=0.3)
+            loss_from_outputs(out, rgbs.cuda()).backward()
+            res[dense] = (out, {k: p.grad.detach().clone() for k, p in named_params(emb, neuconw, nerf).items() if p.grad is not None})
+        (od, gd), (oe, ge) = res[True], res[False]
+        for k in ("color", "depth", "weights", "color_bg"):
+            assert torch.equal(od[k], oe[k]), (prec, k)
+        worst = max(rel_err(ge[k], gd[k]) for k in gd)
+        assert worst < 2e-5, (prec, worst)
 
 
 def test_elimination_under_graph_capture():
