@@ -7,8 +7,10 @@ A "step" = NeuconWRenderer.render (sampler + background NeRF + SDF/colour nets +
 + NeuconWLoss + backward (incl. the second-order SDF terms and every weight gradient) + the
 gradient all-reduce + grad-norm clip + Adam step, on a synthetic batch of BASELINE.json's
 configs[1]: 1024 rays/GPU x (64 coarse + 64 fine) samples, SDF 8x256, colour 4x256, background
-NeRF 8x256, 4 outside samples, fp16 MFMA operands with f32 accumulation and a 2^10 loss scale (--prec f16, the default:
-as fast as bf16 and 10-20x closer to the oracle, tests/test_gpu_fullsize.py; --prec bf16 | f32 select the others).  Rays
+NeRF 8x256, 4 outside samples, fp16 MFMA operands with f32 accumulation, a dynamic loss scale, and the SDF VALUE chain in
+split precision (fp16 hi + lo pairs, three MFMAs per product: fp32-like SDF values -- csrc/ncw_split.hip) (--prec f16, the
+default: rendered outputs within 1e-4 of the oracle at initialisation AND at trained sharpness, `parity`; --prec bf16 | f32
+select the others, `plain_f16_mode` times the step without the split).  Rays
 shard across ranks (weak scaling); value = total ray-samples of all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with the driver contract keys plus
@@ -445,7 +447,7 @@ def main():
     rays, ts, label, rgbs = synth_batch(R, 1000 + rank, dev)
     n_boundary = 0
 
-    def make_step(prec_, bg_dense=True):
+    def make_step(prec_, bg_dense=True, sdf_split=None):
         """models + TrainStep in precision prec_ -> step(i).  bg_dense=True: the background NeRF on every one of the
         S + O samples of a ray like the reference evaluates it (the timed `value`); False = the product default, which
         skips the samples whose result the compositor multiplies by 0 (reported as `bg_elimination`).  LR rule of train.py:21-25: 1e-4 * world*batch / 4096; Adam
@@ -453,6 +455,8 @@ def main():
         all-reduce + clip + Adam (trainer.py)."""
         emb_, neuconw_, nerf_, rdr_ = build_models(dev, prec_)
         rdr_.bg_dense = bg_dense
+        if sdf_split is not None:  # None = the product default (fp16: split-precision SDF value path, csrc/ncw_split.hip)
+            neuconw_.sdf_net.sdf_split = sdf_split
         if args.config == "voxel":  # configs[2]: coarse octree -> ray near/far; fine octree -> +-SAMPLE_RANGE window + boundary samples
             from neuralrecon_w_amd import voxel
 
@@ -577,7 +581,7 @@ def main():
 
     # ---- the fp32 parity mode (the <= 1e-4 mode, tests/test_gpu_render.py) timed in the same process ---------------
     parity = None
-    alt = elim = None
+    alt = elim = plain = None
     if not args.no_parity_mode and world == 1 and args.prec in ("bf16", "f16") and not args.graph:
         del train, step
         torch.cuda.empty_cache()
@@ -594,6 +598,22 @@ def main():
         alt = {"dtype": alt_name, "value": R * S / d_a, "unit": "ray-samples/s", "ms_per_step": d_a * 1e3, "steps": args.steps}
         del train_a, step_a
         torch.cuda.empty_cache()
+        if args.prec == "f16" and W_SDF == 256:  # what the split-precision SDF value path costs: the same step without it
+            step_p, train_p, _ = make_step(prec, sdf_split=False)
+            for i in range(5):
+                step_p(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                step_p(5 + i)
+            torch.cuda.synchronize()
+            d_p = (time.perf_counter() - t1) / args.steps
+            plain = {"dtype": "f16", "value": R * S / d_p, "unit": "ray-samples/s", "ms_per_step": d_p * 1e3, "steps": args.steps,
+                     "note": "NEUCONW_SDF_SPLIT=0: one fp16 rounding per operand in the SDF value chain too (round 2's "
+                             "kernels); rendered outputs 5e-4 of the oracle at inv_s 20 and 2e-2 at inv_s 403 on these rays, "
+                             "against 4e-5 / 9e-5 for the timed split path"}
+            del train_p, step_p
+            torch.cuda.empty_cache()
         # the product default: dead-background elimination (renderer.py _RenderFn.forward) -- identical outputs and
         # gradients (tests/test_gpu_bg_select.py), the NeRF evaluated only where the compositor can use it
         step_e, train_e, (_, _, _, rdr_e) = make_step(prec, bg_dense=False)
@@ -625,7 +645,19 @@ def main():
             step32(2 + i)
         torch.cuda.synchronize()
         d32 = (time.perf_counter() - t1) / k32
+        del train32, step32
+        torch.cuda.empty_cache()
+        step32e, train32e, _ = make_step(nw.PREC_F32, bg_dense=False)  # the fp32 mode as the product runs it
+        for i in range(2):
+            step32e(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(k32):
+            step32e(2 + i)
+        torch.cuda.synchronize()
+        d32e = (time.perf_counter() - t1) / k32
         parity = {"dtype": "f32", "value": R * S / d32, "unit": "ray-samples/s", "ms_per_step": d32 * 1e3, "steps": k32,
+                  "bg_elimination_ms_per_step": d32e * 1e3,
                   "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak): outputs within 1e-4 of the reference, "
                           "bitwise run-to-run reproducible; step_frac_of_f32_mfma_peak = %.3f"
                           % (roofline["step_algorithmic_tflop"] / d32 / 157.3 if roofline else float("nan"))}
@@ -674,7 +706,8 @@ def main():
                        "world_size": world, "ranks": ranks,
                        "submission": "hip-graph replay" if args.graph else "eager",
                        "final_loss": float(loss.detach())},
-            "roofline": roofline, "parity": parity_obj, "parity_mode": parity, "alt_mode": alt, "bg_elimination": elim,
+            "roofline": roofline, "parity": parity_obj, "parity_mode": parity, "alt_mode": alt, "plain_f16_mode": plain,
+            "bg_elimination": elim,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

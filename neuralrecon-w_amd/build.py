@@ -31,7 +31,8 @@ if "NCW_MLP_FLAGS" in os.environ:  # A/B builds (scripts/): e.g. NCW_MLP_FLAGS="
 # The fp16 mode (NCW_PREC_F16) is the SAME source compiled a second time with the 16-bit type switched (ncw_common.h:
 # ncw_h16 = _Float16, the f16 MFMA, entry points suffixed _f16, kernels in their own namespace); the bf16 objects'
 # entry points forward prec == NCW_PREC_F16 to them.
-F16_FILES = ["ncw_sdf.hip", "ncw_sdf8.hip", "ncw_sdf16.hip", "ncw_pp.hip", "ncw_color.hip", "ncw_nerf.hip", "ncw_wgrad.hip"]
+F16_FILES = ["ncw_sdf.hip", "ncw_sdf8.hip", "ncw_sdf16.hip", "ncw_pp.hip", "ncw_color.hip", "ncw_nerf.hip", "ncw_wgrad.hip",
+             "ncw_split.hip"]  # ncw_split.hip: fp16 only (its bf16 object is empty)
 
 
 def _sources():

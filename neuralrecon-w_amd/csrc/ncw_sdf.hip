@@ -419,6 +419,19 @@ static bool sdf16_on(const NcwSdfNet* net, int prec) {
     return on > 0 && net->rb == 16 && prec == NCW_PREC_BF16 && net->n_layers >= 3;
 }
 
+// fp16 build, W = 256: the split-precision value path of ncw_split.hip whenever the net carries residual matrices (w_lo)
+#ifdef NCW_HALF_F16
+int ncw_sdf_inferS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);
+int ncw_sdf_fwdS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
+                            const NcwSdfStash& stash, hipStream_t st);
+static bool sdf_split_on(const NcwSdfNet* net, int prec) {
+    if (!(net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3 && net->n_layers <= NCW_MAX_LAYERS)) return false;
+    for (int l = 0; l < net->n_layers; ++l)
+        if (net->w_lo[l] == nullptr) return false;
+    return true;
+}
+#endif
+
 static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, int64_t n, float* sdf, void* stream) {
     if (!sdf_net_ok(net) || n < 0 || (prec != NCW_PREC_F32 && prec != NCW_PREC_BF16)) return NCW_E_BADARG;
     if (src.mode == 4) return NCW_E_UNSUPPORTED;  // point selections: background NeRF kernels only
@@ -428,6 +441,9 @@ static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, i
     // 2 = the weights-stationary burst kernel of ncw_sdf8.hip (0.198 ms),
     // 0 = the weights-through-LDS kernel below (0.26 ms).
     static const int variant8 = getenv("NCW_SDF_INFER8") ? atoi(getenv("NCW_SDF_INFER8")) : 3;
+#ifdef NCW_HALF_F16
+    if (sdf_split_on(net, prec)) return ncw_sdf_inferS_launch_f16(net, src, n, sdf, st);
+#endif
     if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_infer16_launch)(net, src, n, sdf, st);
     if (variant8 == 3 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3 && net->n_layers <= 12)
         return NCW_FN(ncw_sdf_inferC_launch)(net, src, n, sdf, st);
@@ -480,6 +496,9 @@ extern "C" int NCW_FN(ncw_sdf_fwd)(const NcwSdfNet* net, int prec, const NcwPoin
     // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (0.57 vs 0.67 ms per 131,072 points);
     // NCW_SDF_FWD8=0 selects the weights-through-LDS kernel below
     static const int fwd8 = getenv("NCW_SDF_FWD8") ? atoi(getenv("NCW_SDF_FWD8")) : 1;
+#ifdef NCW_HALF_F16
+    if (sdf_split_on(net, prec)) return ncw_sdf_fwdS_launch_f16(net, *pts, n, sdf, grad, *stash, st);
+#endif
     if (fwd8 > 0 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
         return NCW_FN(ncw_sdf_fwd8_launch)(net, *pts, n, sdf, grad, *stash, st);
     if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_fwd16_launch)(net, *pts, n, sdf, grad, *stash, st);

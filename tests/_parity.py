@@ -31,7 +31,7 @@ def perturb_weights(neuconw, g_jit=0.1, v_jit=0.0, seed=11):
 _ORACLE_CACHE = {}
 
 
-def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=True, cos_anneal=0.3):
+def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=True, cos_anneal=0.3, sdf_split=None):
     """-> dict(errs={color, depth, weights_sum, gradient_error}, loss, loss_ref, grad_worst, inv_s).
     Gradient errors are scaled by the largest gradient of their network (the fp32 reference's own gradients of ~1e-7
     tensors carry ~1e-1 relative noise: tests/test_gpu_fullsize.py)."""
@@ -40,6 +40,8 @@ def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=Tru
     emb, neuconw, nerf, rdr = build_system(W=W, n_a=48, n_vocab=100, nerf_w=256, color_hidden=256, head=128, seed=seed,
                                            prec=prec, n_samples=ns, n_importance=ni)
     perturb_weights(neuconw, 0.1, v_jit)
+    if sdf_split is not None:  # None = the product default (split-precision SDF value path in the fp16 mode at W = 256)
+        neuconw.sdf_net.sdf_split = bool(sdf_split)
     with torch.no_grad():
         neuconw.deviation_network.variance.fill_(float(variance))
     rays, ts, label, rgbs = synth_rays(R, 77, 100)

@@ -25,13 +25,16 @@ def _jitter(neuconw):
 # test, recorded in DESIGN.md 4):
 #   bf16: outputs 2.6e-3 / gradients 8.7e-2 of the network's largest gradient at 16+16 samples, outputs 6.7e-3 /
 #         gradients 4.3e-2 at 64+64; loss 3.5e-5 / 4.8e-4
-#   fp16: outputs 2.4e-4 / gradients 1.8e-2 at 16+16, outputs 4.2e-4 / gradients 1.3e-3 at 64+64; loss 8e-6 / 2e-6
-#   W = 512 at 8+16 samples (the shipped yaml's shape) is the ill-conditioned case -- 24 samples per ray, one moved
+#   fp16 (W = 256: split-precision SDF value path, csrc/ncw_split.hip): colour / depth / weights_sum 5.5e-5, eikonal term
+#         2.3e-4 / 2.7e-4, gradients 3.7e-3 / 1.25e-3 at 16+16 / 64+64; loss 2e-6 / 1.1e-5.  (Plain fp16 value path,
+#         NEUCONW_SDF_SPLIT=0: 2.4e-4 / 4.2e-4 on the outputs, see test_plain_fp16_value_path.)
+#   W = 512 at 8+16 samples (the shipped yaml's shape; plain fp16) is the ill-conditioned case -- 24 samples per ray, one moved
 #   sample shows: fp32 itself is at 1.5e-4 there; bf16 1.5e-2 / 4.7e-2, fp16 3.4e-3 (gradient_error 7.6e-3) / 1.3e-2,
 #   loss 2e-3 / 2e-4.  The kernels themselves are as accurate at W = 512 as at 256 (scripts/diag/sdf_fwd_prec.py:
 #   sdf_fwd's sdf / normals / features vs the fp32 mode, bf16 3.9e-3 / 1.1e-2 / 4.6e-3, fp16 3.7e-4 / 1.3e-3 / 7.0e-4).
-BF16_TOL = {(16, 16): (1e-2, 0.175), (64, 64): (1.4e-2, 0.09), (8, 16): (3e-2, 0.1)}
-F16_TOL = {(16, 16): (6e-4, 0.04), (64, 64): (1e-3, 4e-3), (8, 16): (1.5e-2, 0.03)}
+# (tol colour/depth/weights_sum, tol parameter gradients, tol eikonal term)
+BF16_TOL = {(16, 16): (1e-2, 0.175, 1e-2), (64, 64): (1.4e-2, 0.09, 1.4e-2), (8, 16): (3e-2, 0.1, 3e-2)}
+F16_TOL = {(16, 16): (1.2e-4, 8e-3, 5e-4), (64, 64): (1.2e-4, 3e-3, 6e-4), (8, 16): (1.5e-2, 0.03, 1.6e-2)}
 LOSS_TOL = {"f32": 1e-4, "bf16": 1.4e-3, "f16": 5e-5}
 
 
@@ -65,15 +68,15 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
     names = list(sd)
     gref = dict(zip(names, torch.autograd.grad(lref, [sd[k] for k in names], allow_unused=True)))
     if prec_name == "f32":
-        tol_out, tol_grad = 2e-4, 2e-3
-    elif prec_name == "f16":  # fp16 operands + loss scale 1024 (renderer.grad_scale)
-        tol_out, tol_grad = F16_TOL[(ns, ni)]
+        tol_out, tol_grad, tol_eik = 2e-4, 2e-3, 2e-4
+    elif prec_name == "f16":  # fp16 operands (split-precision SDF value path at W = 256) + dynamic loss scale
+        tol_out, tol_grad, tol_eik = F16_TOL[(ns, ni)]
     else:  # bf16 throughput mode
-        tol_out, tol_grad = BF16_TOL[(ns, ni)]
+        tol_out, tol_grad, tol_eik = BF16_TOL[(ns, ni)]
     errs = {k: rel_err(out[k].detach().cpu(), ref[k]) for k in ("color", "depth", "weights_sum", "gradient_error")}
     print("W=%d %d+%d %s outputs:" % (W, ns, ni, prec_name), {k: "%.2e" % v for k, v in errs.items()})
     for k, e in errs.items():
-        assert e < tol_out, (k, e)
+        assert e < (tol_eik if k == "gradient_error" else tol_out), (k, e)
     assert abs(float(loss.detach()) - float(lref.detach())) < LOSS_TOL[prec_name] * (40 if W == 512 and prec_name != "f32" else 1)
     params = named_params(emb, neuconw, nerf)
 
@@ -97,23 +100,24 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
 
 # ---- trained operating points ---------------------------------------------------------------------------------------
 # inv_s = exp(10 variance) multiplies the SDF inside sigmoid(sdf * inv_s) (models/neuconw.py:173-179, rendering/renderer.py:
-# 624-632): 20 at initialisation, hundreds where NeuS trains.  An SDF error of 5e-4 (fp16) is 0.2 in the sigmoid's argument
-# at inv_s 403.  MEASURED on MI355X (scripts/diag/trained_point_parity.py, W = 256, 64 + 64 samples, R = 16; worst of colour /
-# depth / weights_sum / eikonal term; parameter gradients relative to the largest gradient of their network), tolerances
-# = 2x these:
-#   (variance, v_jit)   f32: out / grad        f16: out / grad        bf16: out / grad
-#   (0.5, 0)  inv_s 148  2.0e-5 / 1.0e-3        2.8e-4 / 6.3e-3        1.5e-2 / 3.7e-1
-#   (0.6, 0)  inv_s 403  6.1e-4 / 1.7e-3        7.3e-3 / 1.9e-2        5.7e-2 / 4.7e-2
-#   (0.7, 0)  inv_s 1097 1.5e-4 / 2.0e-2        1.6e-3 / 2.1e-1        1.9e-3 / 1.6e-1
-#   (0.6, 0.05) (weight_v jittered 5 %: a non-sphere SDF)  1.1e-6 / 3.0e-4   1.1e-3 / 3.9e-3   1.1e-2 / 2.4e-1
-# Even the exact-fp32 kernels sit at 1e-4 .. 6e-4 of the fp64 oracle once inv_s is in the hundreds (so does the fp32 CPU
-# oracle on other rays: the discrete sampler amplifies 1e-7 SDF differences); the 16-bit modes are 10x (fp16) / 100x (bf16)
-# above that.  DESIGN.md 4 has the full table.
+# 624-632): 20 at initialisation, hundreds where NeuS trains.  An SDF error of 5e-4 (one fp16 rounding per operand) is 0.2 in
+# the sigmoid's argument at inv_s 403.  MEASURED on MI355X (scripts/diag/trained_point_parity.py, W = 256, 64 + 64 samples,
+# R = 16; worst of colour / depth / weights_sum, [eikonal term]; parameter gradients relative to the largest gradient of
+# their network), tolerances = 2x these:
+#   (variance, v_jit)    f32: out / grad     f16 (split SDF value path): out [eik] / grad    f16 plain: out   bf16: out / grad
+#   (0.5, 0)  inv_s 148  2.0e-5 / 1.0e-3     2.3e-5 [1.3e-4] / 1.3e-3                        2.8e-4           1.5e-2 / 3.7e-1
+#   (0.6, 0)  inv_s 403  6.1e-4 / 1.7e-3     5.5e-5 [1.3e-4] / 1.0e-3                        7.3e-3           5.7e-2 / 4.7e-2
+#   (0.7, 0)  inv_s 1097 1.5e-4 / 2.0e-2     3.4e-5 [1.3e-4] / 2.8e-3                        1.6e-3           1.9e-3 / 1.6e-1
+#   (0.6, 0.05) (weight_v jittered 5 %: a non-sphere SDF)  1.1e-6 / 3.0e-4   2.3e-5 [6.7e-5] / 1.0e-3   1.6e-4   1.1e-2 / 2.4e-1
+# The exact-fp32 kernels themselves sit at 1e-4 .. 6e-4 of the fp64 oracle once inv_s is in the hundreds (the discrete
+# sampler amplifies 1e-7 SDF differences on single rays); the fp16 mode with the split value path stays <= 5.5e-5 at every
+# operating point, the plain fp16 value path is 10-100x and bf16 100-1000x above that.  DESIGN.md 4 has the full table.
+# (tol colour/depth/weights_sum, tol parameter gradients, tol eikonal term)
 TRAINED_TOL = {
-    (0.5, 0.0): {"f32": (1e-4, 2e-3), "f16": (6e-4, 1.3e-2), "bf16": (3e-2, 0.75)},
-    (0.6, 0.0): {"f32": (1.3e-3, 3.5e-3), "f16": (1.5e-2, 4e-2), "bf16": (0.12, 0.1)},
-    (0.7, 0.0): {"f32": (3e-4, 4e-2), "f16": (3.2e-3, 0.42), "bf16": (4e-3, 0.32)},
-    (0.6, 0.05): {"f32": (1e-4, 2e-3), "f16": (2.2e-3, 8e-3), "bf16": (2.2e-2, 0.5)},
+    (0.5, 0.0): {"f32": (1e-4, 2e-3, 1e-4), "f16": (1.2e-4, 2.6e-3, 3e-4), "bf16": (3e-2, 0.75, 4e-3)},
+    (0.6, 0.0): {"f32": (1.3e-3, 3.5e-3, 1e-4), "f16": (1.2e-4, 2.1e-3, 3e-4), "bf16": (0.12, 0.1, 4e-3)},
+    (0.7, 0.0): {"f32": (3e-4, 4e-2, 1e-4), "f16": (1.2e-4, 5.7e-3, 3e-4), "bf16": (4e-3, 0.32, 4e-3)},
+    (0.6, 0.05): {"f32": (1e-4, 2e-3, 1e-4), "f16": (1.2e-4, 2.1e-3, 2e-4), "bf16": (3e-3, 0.5, 2.2e-2)},
 }
 
 
@@ -125,12 +129,28 @@ def test_train_step_vs_oracle_at_trained_operating_points(variance, v_jit, prec_
 
     prec = {"f32": nw.PREC_F32, "bf16": nw.PREC_BF16, "f16": nw.PREC_F16}[prec_name]
     r = run_case(256, 64, 64, prec, 16, variance=variance, v_jit=v_jit)
-    tol_out, tol_grad = TRAINED_TOL[(variance, v_jit)][prec_name]
+    tol_out, tol_grad, tol_eik = TRAINED_TOL[(variance, v_jit)][prec_name]
     print("variance %.1f (inv_s %d) v_jit %.2f %s:" % (variance, round(r["inv_s"]), v_jit, prec_name),
           {k: "%.2e" % v for k, v in r["errs"].items()}, "grads %.2e" % r["grad_worst"])
     for k, e in r["errs"].items():
-        assert e < tol_out, (k, e)
+        assert e < (tol_eik if k == "gradient_error" else tol_out), (k, e)
     assert r["grad_worst"] < tol_grad, r["grad_worst"]
+
+
+def test_plain_fp16_value_path():
+    """NEUCONW_SDF_SPLIT=0 / sdf_net.sdf_split = False: one fp16 rounding per operand in the SDF value chain too (the
+    round-2 kernels: sdf_inferC, sdf_fwdB).  Measured: outputs 4.2e-4 at inv_s 20, 7.3e-3 at inv_s 403 (R = 16)."""
+    import neuralrecon_w_amd as nw
+    from tests._parity import run_case
+
+    for variance, tol_out, tol_grad in ((0.3, 1e-3, 4e-3), (0.6, 1.5e-2, 4e-2)):
+        r = run_case(256, 64, 64, nw.PREC_F16, 16, variance=variance, sdf_split=False)
+        print("plain fp16, variance %.1f:" % variance, {k: "%.2e" % v for k, v in r["errs"].items()}, "grads %.2e" % r["grad_worst"])
+        assert max(r["errs"].values()) < tol_out and r["grad_worst"] < tol_grad, r
+        # the split path is the one that must be an order of magnitude better where it matters
+        s = run_case(256, 64, 64, nw.PREC_F16, 16, variance=variance)
+        if variance > 0.5:
+            assert max(s["errs"][k] for k in ("color", "depth", "weights_sum")) * 10 < max(r["errs"][k] for k in ("color", "depth", "weights_sum"))
 
 
 def test_properties_at_full_baseline_shape():
