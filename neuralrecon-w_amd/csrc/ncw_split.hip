@@ -12,10 +12,15 @@
 // multiplied by inv_s.
 //
 // Structure: the weights-stationary layout of ncw_sdf8.hip (8 waves own the 8 output blocks of a layer; the 128 points'
-// activations live in LDS as B fragments, here [tile][k-unit][hi | lo][64 lanes] = 128 KiB, ONE buffer rewritten in place:
-// every wave keeps its block's 4 tile accumulators until all waves have finished reading the layer input).  A layer's
-// weight slice is 2 x 64 registers (hi + lo), so it is streamed in two K-halves through two static register sets
-// (A: units 0..7, B: units 8..15), each half prefetched while the other is in use.
+// activations live in LDS as B fragments, here [tile][k-unit][hi | lo][64 lanes] = 128 KiB, ONE buffer rewritten in place).
+//   * burst chain (ss_value_chain: sdf_fwd, and sdf_infer of nets with more than 8 Softplus layers): every wave keeps its
+//     block's 4 tile accumulators until all waves have finished reading the layer input; the layer's weight slice (2 x 64
+//     registers, hi + lo) is streamed in two K-halves through two static register sets, each prefetched while the other
+//     is in use; two barriers per layer;
+//   * pipelined chain (s2_value_chain: sdf_infer): one tile per stage, the epilogue of the previous stage between the
+//     MFMAs of the current one, one LDS-only barrier per stage, the whole slice resident (see there).
+#include <stdlib.h>
+
 #include "ncw_mlp.h"
 
 #ifdef NCW_HALF_F16
@@ -186,6 +191,231 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         const int64_t p = (tile0 + wave) * 32 + (lane & 31);
         if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Version 2 of the value chain: the fine-interleaved pipeline of ncw_pp.hip with split operands, one TILE
+// per pipeline stage.  Segment (l, t) issues the 48 MFMAs of tile t of layer l (16 k-units x {hi.hi, lo.hi, hi.lo}) with
+// the epilogue of the PREVIOUS segment's finished accumulator (Softplus, hi / lo split, LDS + stash stores) between them,
+// three MFMAs and one accumulator register per step; ONE LDS-only barrier per segment.  A tile's activation region
+// ([16 units][hi | lo], 32 KiB) is rewritten IN PLACE: within a segment it is either read (its MFMAs) or written (its
+// epilogue), never both.  The layer's weight slice (16 units hi + 16 units lo = 128 registers) stays resident for the four
+// tiles and is reloaded in place during the layer's last segment; two 16-register accumulators alternate.
+// ------------------------------------------------------------------------------------------------
+constexpr int S2_TILE = 16 * 2 * 1024;     // one tile region
+constexpr int S2_BIAS = 8 * 1024;          // bias staging: up to 8 Softplus layers x 256 f32 (128 + 24 + 8 KiB = all of the LDS)
+typedef __attribute__((address_space(3))) f32x4 ss_lf4;
+
+NCW_DEV void s2_barrier() {  // LDS stores of this phase complete; vector-memory traffic stays in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+NCW_DEV f32x16 s2_bias(const ss_lf4* bb, int lane) {
+    const ss_lf4* p = bb + (lane >> 5) * 4;
+    f32x16 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = p[g];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[4 * g + c] = t[c];
+    }
+    return v;
+}
+
+// extra k-units (gamma: NU = 3) of one tile: xin = gbuf + tile * NU * 2 * 64 + lane
+template <int NU>
+NCW_DEV void s2_mma_x(f32x16& a, const bf16x8* wh, const bf16x8* wl, const ss_lfrag* xin) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const bf16x8 bh = xin[(u * 2) * 64], bl = xin[(u * 2 + 1) * 64];
+        a = NCW_MFMA_H(wh[u], bh, a, 0, 0, 0);
+        a = NCW_MFMA_H(wl[u], bh, a, 0, 0, 0);
+        a = NCW_MFMA_H(wh[u], bl, a, 0, 0, 0);
+    }
+}
+
+// One segment: m += W[ob] . h of one tile (in = tile region + lane; m holds the bias on entry), epi(u) after the three MFMAs
+// of unit u.  PREFETCH: unit u of the NEXT layer goes into the registers unit u has just left.
+template <bool PREFETCH, class EPI>
+NCW_DEV void s2_segment(f32x16& m, bf16x8 (&wh)[16], bf16x8 (&wl)[16], const ss_lfrag* in, const void* wn, const void* wn_lo, int ob,
+                        int lane, EPI&& epi) {
+    // two independent accumulator chains (a dependent MFMA waits for its predecessor's result): m takes the hi.hi terms, c the
+    // two cross terms -- which also keeps the small terms from being absorbed one by one into a large partial sum
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    bf16x8 b[2][2];  // ring of two k-units: {hi, lo}, one unit ahead of its use
+    b[0][0] = in[0]; b[0][1] = in[64];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        if (u + 1 < 16) {
+            b[(u + 1) & 1][0] = in[((u + 1) * 2) * 64];
+            b[(u + 1) & 1][1] = in[((u + 1) * 2 + 1) * 64];
+        }
+        m = NCW_MFMA_H(wh[u], b[u & 1][0], m, 0, 0, 0);
+        c = NCW_MFMA_H(wl[u], b[u & 1][0], c, 0, 0, 0);
+        c = NCW_MFMA_H(wh[u], b[u & 1][1], c, 0, 0, 0);
+        if (PREFETCH) {
+            wh[u] = ss_gload(wn, (size_t)u * 8 + ob, lane);
+            wl[u] = ss_gload(wn_lo, (size_t)u * 8 + ob, lane);
+        }
+        epi(u);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m[r] += c[r];
+}
+
+// Epilogue step u (0..15) of a finished tile accumulator: register u goes through Softplus and is split into fp16 hi + lo;
+// every fourth step one 8-byte stash piece (4 consecutive features), every eighth step one k-unit (hi fragment + lo fragment)
+// of the next layer's input, in place.
+template <bool STASH>
+NCW_DEV void s2_epi_step(int u, const f32x16& e, bf16x8& fh, bf16x8& fl, ss_lfrag* out, int ob, int lane, ncw_h16* __restrict__ st_h,
+                         size_t tile) {
+    float y, sgm;
+    softplus100<true>(e[u], y, sgm);
+    const ncw_h16 hh = (ncw_h16)y;
+    fh[u & 7] = hh;
+    fl[u & 7] = (ncw_h16)(y - (float)hh);
+    if (STASH && (u & 3) == 3) {  // registers 4g .. 4g+3, g = u >> 2: one [tile][block][g][lane][4] piece of the stash
+        bf16x4 t;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = fh[(u & 7) - 3 + c];
+        reinterpret_cast<bf16x4*>(st_h)[((tile * 8 + ob) * 4 + (u >> 2)) * 64 + lane] = t;
+    }
+    if ((u & 7) == 7) {
+        const int unit = 2 * ob + (u >> 3);
+        out[(unit * 2 + 0) * 64 + lane] = fh;
+        out[(unit * 2 + 1) * 64 + lane] = fl;
+    }
+}
+
+template <bool STASH>
+NCW_DEV void s2_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t n, int64_t tile0, ss_lfrag* abuf, ss_lfrag* gbuf,
+                            ss_lf4* bbuf, int lane, int wave, float* __restrict__ sdf, const NcwSdfStash& st) {
+    typedef ncw_h16 SE;
+    const int L = net.n_layers, NL = L - 1;
+    const int ob = wave;
+    for (int i = threadIdx.x; i < NL * 64; i += 64 * SS_WAVES) bbuf[i] = reinterpret_cast<const f32x4*>(net.b[i >> 6])[i & 63];
+    if (wave < SS_TILES) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        if (p >= n) p = n - 1;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+        CVec<2> gam;
+        freq_encode<2, 3, 6, false>(gam, xs, lane);  // sinf / cosf: the hardware v_sin / v_cos are not fp32-accurate
+        if (STASH) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            bf16x8 hi, lo;
+            ss_split8(gam.v[q >> 1], q & 1, hi, lo);
+            gbuf[((wave * 3 + q) * 2 + 0) * 64 + lane] = hi;
+            gbuf[((wave * 3 + q) * 2 + 1) * 64 + lane] = lo;
+        }
+    }
+    bf16x8 wh[16], wl[16];
+    f32x16 x, y;  // tiles 0, 2 accumulate into x, tiles 1, 3 into y
+    bf16x8 fh, fl;
+    auto region = [&](int t) { return abuf + t * (S2_TILE / 16); };
+    auto gin = [&](int t) { return gbuf + t * 3 * 2 * 64 + lane; };
+    auto bias_of = [&](int l) { return s2_bias(bbuf + (l * 8 + ob) * 8, lane); };
+    // ---- layer 0 (K = 39: the 3 gamma units) for the four tiles, then E(0, t = 0..2); E(0, 3) rides on segment (1, 0) --------
+    {
+        ss_load_half<3>(reinterpret_cast<bf16x8(&)[3]>(wh[0]), reinterpret_cast<bf16x8(&)[3]>(wl[0]), net.w[0], net.w_lo[0], 8, ob, 0, lane);
+        s2_barrier();  // gamma + biases visible
+        x = bias_of(0);
+        y = x;
+        s2_mma_x<3>(x, wh, wl, gin(0));
+        s2_mma_x<3>(y, wh, wl, gin(1));
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, x, fh, fl, region(0), ob, lane, (SE*)st.h[1], (size_t)tile0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, y, fh, fl, region(1), ob, lane, (SE*)st.h[1], (size_t)(tile0 + 1));
+        x = bias_of(0);
+        y = x;
+        s2_mma_x<3>(x, wh, wl, gin(2));
+        s2_mma_x<3>(y, wh, wl, gin(3));
+        // the first hidden layer's slice (its latency hides behind the epilogue)
+        if (NL > 1) ss_load_half<16>(wh, wl, net.w[1], net.w_lo[1], 8, ob, 0, lane);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, x, fh, fl, region(2), ob, lane, (SE*)st.h[1], (size_t)(tile0 + 2));
+        s2_barrier();
+    }
+    // ---- hidden layer l >= 1, tile t: [M(l, t) | E(previous segment)] bar ---------------------------------------------------
+    for (int l = 1; l < NL; ++l) {
+        const bool more = l + 1 < NL, skip = (l == net.skip_layer);
+        bf16x8 gh[3], gl[3];
+        if (skip) ss_load_half<3>(gh, gl, net.w[l], net.w_lo[l], 8, ob, 16, lane);  // the gamma columns: units 16..18
+        {   // t = 0 -> x;  E(l-1, 3) <- y
+            x = bias_of(l);
+            auto epi = [&](int u) { s2_epi_step<STASH>(u, y, fh, fl, region(3), ob, lane, (SE*)st.h[l], (size_t)(tile0 + 3)); };
+            s2_segment<false>(x, wh, wl, region(0) + lane, nullptr, nullptr, ob, lane, epi);
+            if (skip) s2_mma_x<3>(x, gh, gl, gin(0));
+            s2_barrier();
+        }
+        {   // t = 1 -> y;  E(l, 0) <- x
+            y = bias_of(l);
+            auto epi = [&](int u) { s2_epi_step<STASH>(u, x, fh, fl, region(0), ob, lane, (SE*)st.h[l + 1], (size_t)tile0); };
+            s2_segment<false>(y, wh, wl, region(1) + lane, nullptr, nullptr, ob, lane, epi);
+            if (skip) s2_mma_x<3>(y, gh, gl, gin(1));
+            s2_barrier();
+        }
+        {   // t = 2 -> x;  E(l, 1) <- y
+            x = bias_of(l);
+            auto epi = [&](int u) { s2_epi_step<STASH>(u, y, fh, fl, region(1), ob, lane, (SE*)st.h[l + 1], (size_t)(tile0 + 1)); };
+            s2_segment<false>(x, wh, wl, region(2) + lane, nullptr, nullptr, ob, lane, epi);
+            if (skip) s2_mma_x<3>(x, gh, gl, gin(2));
+            s2_barrier();
+        }
+        {   // t = 3 -> y;  E(l, 2) <- x; the layer's last use of its weight slice -> the next layer's takes its registers
+            y = bias_of(l);
+            auto epi = [&](int u) { s2_epi_step<STASH>(u, x, fh, fl, region(2), ob, lane, (SE*)st.h[l + 1], (size_t)(tile0 + 2)); };
+            if (more) s2_segment<true>(y, wh, wl, region(3) + lane, net.w[l + 1], net.w_lo[l + 1], ob, lane, epi);
+            else s2_segment<false>(y, wh, wl, region(3) + lane, nullptr, nullptr, ob, lane, epi);
+            if (skip) s2_mma_x<3>(y, gh, gl, gin(3));
+            s2_barrier();
+        }
+    }
+    // ---- drain: E(NL-1, 3) --------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, y, fh, fl, region(3), ob, lane, (SE*)st.h[NL], (size_t)(tile0 + 3));
+    s2_barrier();
+    // ---- sdf row (1 output block), tile t by wave t -------------------------------------------------------------------
+    if (wave < SS_TILES) {
+        CVec<1> o;
+        load_bias(o, net.b[L - 1], lane);
+        const ss_lfrag* in = region(wave) + lane;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bf16x8 vh[8], vl[8];
+            ss_load_half<8>(vh, vl, net.w[L - 1], net.w_lo[L - 1], 1, 0, 8 * half, lane);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const ss_lfrag* p = in + ((8 * half + q) * 2) * 64;
+                const bf16x8 bh = p[0], bl = p[64];
+                o.v[0] = NCW_MFMA_H(vh[q], bh, o.v[0], 0, 0, 0);
+                o.v[0] = NCW_MFMA_H(vl[q], bh, o.v[0], 0, 0, 0);
+                o.v[0] = NCW_MFMA_H(vh[q], bl, o.v[0], 0, 0, 0);
+            }
+        }
+        const int64_t p = (tile0 + wave) * 32 + (lane & 31);
+        if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+    }
+}
+
+__global__ __launch_bounds__(64 * SS_WAVES) void sdf_inferS2_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                   float* __restrict__ sdf) {
+    __shared__ __attribute__((aligned(16))) char lds[SS_ACT + SS_GAM + S2_BIAS];
+    ss_lfrag* const abuf = (ss_lfrag*)(ncw_lchar*)lds;
+    ss_lfrag* const gbuf = abuf + SS_ACT / 16;
+    ss_lf4* const bbuf = (ss_lf4*)(gbuf + SS_GAM / 16);
+    const int lane = ncw_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    NcwSdfStash none = {};
+    s2_value_chain<false>(net, src, n, (int64_t)blockIdx.x * SS_TILES, abuf, gbuf, bbuf, lane, wave, sdf, none);
 }
 
 __global__ __launch_bounds__(64 * SS_WAVES) void sdf_inferS_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
@@ -361,10 +591,16 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, 
 
 }  // namespace
 
+// Measured per 131,072 points on MI355X (scripts/diag/split_check.py; plain fp16 kernels: 0.160 / 0.558 ms):
+//   sdf_infer: pipelined value chain 0.351-0.361 ms, burst 0.399-0.412 ms -> pipelined (burst for nets with more than 8
+//              Softplus layers: the bias staging of the pipelined kernel fills the LDS);
+//   sdf_fwd:   burst 0.770-0.776 ms, pipelined 0.800-0.839 ms (its stash stores sit in the MFMA stream and share vmcnt with
+//              the weight prefetch) -> burst.
 int ncw_sdf_inferS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
-    hipLaunchKernelGGL(sdf_inferS_kernel, dim3((unsigned)((tiles + SS_TILES - 1) / SS_TILES)), dim3(64 * SS_WAVES), 0, st, *net,
-                       src, n, sdf);
+    const dim3 grid((unsigned)((tiles + SS_TILES - 1) / SS_TILES));
+    if (net->n_layers - 1 <= 8) hipLaunchKernelGGL(sdf_inferS2_kernel, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf);
+    else hipLaunchKernelGGL(sdf_inferS_kernel, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf);
     NCW_CHECK_LAUNCH();
     return 0;
 }
@@ -372,8 +608,8 @@ int ncw_sdf_inferS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_
 int ncw_sdf_fwdS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
                             const NcwSdfStash& stash, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
-    hipLaunchKernelGGL(sdf_fwdS_kernel, dim3((unsigned)((tiles + SS_TILES - 1) / SS_TILES)), dim3(64 * SS_WAVES), 0, st, *net, src,
-                       n, sdf, grad, stash);
+    const dim3 grid((unsigned)((tiles + SS_TILES - 1) / SS_TILES));
+    hipLaunchKernelGGL(sdf_fwdS_kernel, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }
