@@ -517,19 +517,24 @@ int ncw_ray_tail_bwd(const float* weights_sum, const int64_t* label, const int* 
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Iso-surface extraction, replaces skimage.measure.marching_cubes(sdf, level, mask=...) of
- * utils/visualization.py:114 with marching tetrahedra on the same grid (skimage's Lewiner tables are not in the
- * reference tree: triangulation parity unpinned; the vertex rule -- one linear zero crossing per sign-changing
- * grid edge -- is the same).  sdf: [Dx,Dy,Dz] f32 (x slowest).  mask: uint8 [Dx,Dy,Dz] or NULL; the cube with
- * minimum corner (i,j,k) is processed iff mask[i+1,j+1,k+1] (utils/visualization.py:103-112 builds the mask that way).
- *   ncw_mt_count: counts[(Dx-1)(Dy-1)(Dz-1)] int32 triangles per cube (cube index x slowest)
- *   ncw_mt_emit : offsets = EXCLUSIVE prefix sum of counts (int64); writes tri_pos [T,3,3] f32 in grid-index
+ * Iso-surface extraction: replaces `skimage.measure.marching_cubes(sdf, level, mask=...)` of
+ * utils/visualization.py:114 by MARCHING CUBES on the same grid: one vertex per sign-changing grid edge at its linear
+ * zero crossing (the vertex rule of every marching-cubes variant), triangles per cube from the 256-entry case tables
+ * generated by neuralrecon-w_amd/mc_tables.py (tri [256][16] int8 edge triples, -1 padded; ntri [256]; edges [12][2]
+ * corner pairs; corner k = offset (k&1, k>>1&1, k>>2&1), configuration bit k = value < level).  skimage's triangulation of
+ * the ambiguous configurations is not reproducible without skimage: the vertex set and the geometry are what is pinned.
+ * sdf: [Dx,Dy,Dz] f32 (x slowest).  mask: uint8 [Dx,Dy,Dz] or NULL; the cube with minimum corner (i,j,k) is processed
+ * iff mask[i+1,j+1,k+1] (utils/visualization.py:103-112 builds the mask that way).
+ *   ncw_mc_count: counts[(Dx-1)(Dy-1)(Dz-1)] int32 triangles per cube (cube index x slowest)
+ *   ncw_mc_emit : offsets = EXCLUSIVE prefix sum of counts (int64); writes tri_pos [T,3,3] f32 in grid-index
  *                 coordinates and tri_key [T,3] int64 vertex ids (lo_point * Dx*Dy*Dz + hi_point: weld by key).
  *                 Faces are wound so that normals point towards increasing values.
  * ---------------------------------------------------------------------------------------- */
-int ncw_mt_count(const float* sdf, const uint8_t* mask, int Dx, int Dy, int Dz, float level, int32_t* counts, void* stream);
-int ncw_mt_emit(const float* sdf, const uint8_t* mask, int Dx, int Dy, int Dz, float level, const int64_t* offsets,
-                float* tri_pos, int64_t* tri_key, void* stream);
+int ncw_mc_count(const float* sdf, const uint8_t* mask, int Dx, int Dy, int Dz, float level, const int32_t* ntri,
+                 int32_t* counts, void* stream);
+int ncw_mc_emit(const float* sdf, const uint8_t* mask, int Dx, int Dy, int Dz, float level, const int8_t* tri,
+                const int32_t* ntri, const int32_t* edges, const int64_t* offsets, float* tri_pos, int64_t* tri_key,
+                void* stream);
 
 #ifdef __cplusplus
 }

@@ -194,9 +194,6 @@ NCW_DEV void ring_issue(ncw_lchar* lds_slot, const void* gsrc, int bytes) {
     const int lane = threadIdx.x & 63;
     const int pieces = (bytes + 1023) >> 10;
     const char* g0 = reinterpret_cast<const char*>(gsrc) + lane * 16;
-#ifdef NCW_EXP_NODMA  // timing experiment only: results are garbage
-    return;
-#endif
     for (int pc = wave; pc < pieces; pc += nw) {
         if (pc * 1024 + lane * 16 < bytes)
             __builtin_amdgcn_global_load_lds((ncw_gvoid*)(g0 + (size_t)pc * 1024), (ncw_lvoid*)(lds_slot + pc * 1024), 16,
@@ -296,9 +293,7 @@ NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename
     typedef typename std::conditional<P::id == NCW_PREC_F32, float, bf16x8>::type Frag;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-#ifndef NCW_EXP_NOBAR  // timing experiment only
         __syncthreads();
-#endif
         if (c + 1 < NCH) {
             const int nu = (c + 2) * CU <= NU ? CU : NU - (c + 1) * CU;
             ring_issue(ring.slot(ring.cur ^ 1), reinterpret_cast<const char*>(wp) + (size_t)(c + 1) * CU * UB, nu * UB);
@@ -404,34 +399,17 @@ NCW_DEV void load_bias(CVec<RB>& acc, const float* __restrict__ bp, int lane) {
 // sigma(100 z) (exactly 1 above the threshold).  FAST selects hardware exp2/log2.
 template <bool FAST>
 NCW_DEV void softplus100(float z, float& y, float& s) {
-#ifdef NCW_EXP_NOSP  // timing experiment only: no transcendental epilogue
-    y = __builtin_fmaxf(z, 0.f);
-    s = 0.5f;
-    return;
-#endif
     if (FAST) {
         // 16-bit kernels: y = max(z, 0) + log2(1 + 2^-|t|) ln2 / 100, t = 100 z log2(e), on the hardware exp2 / log2
         // (4 plain VALU + 2 transcendentals); s = 1 - exp(-100 y) (== sigmoid(100 z)), dead code wherever Softplus' is
         // recomputed from the stashed h.
-        // -DNCW_POLY_SOFTPLUS replaces the correction term by a degree-4 polynomial on [0, 0.06], constant beyond (7 plain
-        // VALU, max abs error 3.3e-5).  It was the default for a while: sdf_infer 7 % faster, the whole step 0.5 %.  But its
-        // constant tail (2.5e-5 instead of -> 0) puts a FLOOR of 2.5e-3 under the recomputed sigmoid of every switched-off
-        // unit, which is what bounded the accuracy of the 16-bit modes: with the exact form the fp16 mode's rendered
-        // outputs moved from 3e-3 to 1-2.4e-4 of the fp64 oracle and its parameter gradients from 6.9e-2 to 1.8e-2
-        // (tests/test_gpu_fullsize.py), bf16's outputs from 4.9e-3 to 2.3e-3.
-#ifndef NCW_POLY_SOFTPLUS
+        // (Round 2 tried a degree-4 polynomial for the correction term -- 7 plain VALU, sdf_infer 7 % faster, the step 0.5 % --
+        // and dropped it: its constant tail put a floor of 2.5e-3 under the sigmoid recomputed from the stashed h, which
+        // bounded the accuracy of the 16-bit modes.  DESIGN.md 3.1.)
         const float t = z * 144.26950408889634f;  // 100 z log2(e)
         const float w = __builtin_amdgcn_exp2f(-__builtin_fabsf(t));
         const float l = __builtin_amdgcn_logf(1.f + w);  // log2(1 + w)
         y = __builtin_fmaf(l, 0.6931471805599453f * 0.01f, __builtin_fmaxf(z, 0.f));
-#else
-        const float a = __builtin_fminf(__builtin_fabsf(z), 0.06f);
-        float r = __builtin_fmaf(1067.48234f, a, -204.559567f);
-        r = __builtin_fmaf(r, a, 15.0247592f);
-        r = __builtin_fmaf(r, a, -0.510720189f);
-        r = __builtin_fmaf(r, a, 0.00693755643f);
-        y = __builtin_fmaxf(z, 0.f) + r;
-#endif
         s = 1.f - __builtin_amdgcn_exp2f(y * -144.26950408889634f);
     } else {
         const float bz = 100.f * z;
@@ -529,9 +507,6 @@ NCW_DEV void freq_encode(CVec<RB>& out, const float (&x)[D], int lane) {
 // ---------------------------------------------------------------------------------------------
 template <int RB>
 NCW_DEV void stash_store(float* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
-#ifdef NCW_EXP_NOSTASH  // timing experiment only
-    return;
-#endif
     f32x4* p = reinterpret_cast<f32x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -545,9 +520,6 @@ NCW_DEV void stash_store(float* __restrict__ base, size_t tile, const CVec<RB>& 
 }
 template <int RB>
 NCW_DEV void stash_store(ncw_h16* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
-#ifdef NCW_EXP_NOSTASH  // timing experiment only
-    return;
-#endif
     bf16x4* p = reinterpret_cast<bf16x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)

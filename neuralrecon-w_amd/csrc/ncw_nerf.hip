@@ -1,7 +1,5 @@
 // Fused background-NeRF kernels: models/nerf.py:86-183 evaluated on the inverted-sphere
 // reparametrisation of renderer.py:176-186, forward and backward, one launch each.
-#include <stdlib.h>
-
 #include "ncw_mlp.h"
 
 int NCW_FN(ncw_nerf_fwd8_launch)(const NcwNerfNet* net, const NcwPoints& src, const float* x4, int64_t n, const float* a, float* density,
@@ -270,10 +268,9 @@ extern "C" int NCW_FN(ncw_nerf_fwd)(const NcwNerfNet* net, int prec, const NcwPo
     if (pts->mode == 4 && (!pts->idx || !pts->count || x4)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (0.33 vs 0.40 ms per 135,168 points);
-    // NCW_NERF_FWD8=0 selects the weights-through-LDS kernel below
-    static const int fwd8 = getenv("NCW_NERF_FWD8") ? atoi(getenv("NCW_NERF_FWD8")) : 1;
-    if (fwd8 > 0 && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 && net->n_head <= 4)
+    // W = 256, 16-bit: the weights-stationary kernel of ncw_sdf8.hip (0.33 vs 0.40 ms per 135,168 points for the
+    // weights-through-LDS kernel below, which serves fp32 and the other widths)
+    if (net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 && net->n_head <= 4)
         return NCW_FN(ncw_nerf_fwd8_launch)(net, *pts, x4, n, a, density, rgb, *stash, st);
     NCW_NERF_DISPATCH(nerf_fwd_kernel, *net, *pts, x4, n, a, density, rgb, *stash);
     return 0;
@@ -286,10 +283,9 @@ extern "C" int NCW_FN(ncw_nerf_bwd)(const NcwNerfNet* net, int prec, const NcwPo
     if (pts->mode == 4 && (!pts->idx || !pts->count)) return NCW_E_BADARG;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (0.44 vs 0.49 ms per 135,168 points);
-    // NCW_NERF_BWD8=0 selects the weights-through-LDS kernel below
-    static const int bwd8 = getenv("NCW_NERF_BWD8") ? atoi(getenv("NCW_NERF_BWD8")) : 1;
-    if (bwd8 > 0 && d_a_rows == nullptr && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 &&
+    // W = 256, 16-bit: the weights-stationary kernel of ncw_sdf8.hip (0.44 vs 0.49 ms per 135,168 points); the
+    // weights-through-LDS kernel below serves fp32, the other widths and the order-fixed d_a_rows path
+    if (d_a_rows == nullptr && net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 &&
         net->n_head <= 4)
         return NCW_FN(ncw_nerf_bwd8_launch)(net, *pts, n, d_density, d_rgb, d_a, *stash, st);
     NCW_NERF_DISPATCH(nerf_bwd_kernel, *net, *pts, n, d_density, d_rgb, d_a, d_a_rows, *stash);

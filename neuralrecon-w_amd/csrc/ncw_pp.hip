@@ -36,22 +36,10 @@ constexpr int PP_BIAS = 12 * 1024;            // bias staging: up to 12 layers x
 typedef __attribute__((address_space(3))) bf16x8 pp_lfrag;
 typedef __attribute__((address_space(3))) f32x4 pp_lf4;
 
-// One k-unit (1 KiB: 64 lanes x 16 B) of a packed matrix, global -> registers.  The unit's address is wave-uniform
-// (kernel argument + readfirstlane'd block index), so it goes into an SGPR pair and the load takes the saddr form
-// `global_load_dwordx4 v, v_lane_offset, s[base:base+1]`: no per-load 64-bit VGPR address arithmetic (a VMEM
-// instruction costs ~60 issue cycles beside MFMAs as it is).
+// One k-unit (1 KiB: 64 lanes x 16 B) of a packed matrix, global -> registers
 NCW_DEV bf16x8 pp_load_unit(const void* w, int unit_index, int lane) {
-    typedef const __attribute__((address_space(1))) char* gcp;
     typedef const __attribute__((address_space(1))) bf16x8* gp;
-#ifdef PP_SADDR
-    const unsigned long long b = (unsigned long long)w + (unsigned long long)unit_index * 1024ull;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    gcp base = (gcp)(((unsigned long long)hi << 32) | lo);
-    return *(gp)(base + (unsigned)(lane * 16));
-#else
-    (void)sizeof(gcp);
     return ((gp)w)[(size_t)unit_index * 64 + lane];
-#endif
 }
 
 template <int NU>
@@ -62,10 +50,6 @@ NCW_DEV void pp_load_slice(bf16x8* a, const void* w, int rb_stride, int ob, int 
 
 // LDS-only barrier: LDS stores of this phase are complete, vector-memory traffic stays in flight
 NCW_DEV void pp_barrier() {
-#ifdef PP_EXP_NOBAR  // timing experiment only: results are garbage
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    return;
-#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -101,19 +85,15 @@ NCW_DEV void pp_prio(int p) {
 }
 
 NCW_DEV float pp_softplus(float z) {
-#ifdef PP_EXP_NOSP  // timing experiment only
-    return __builtin_fmaxf(z, 0.f);
-#else
     float y, s;
     softplus100<true>(z, y, s);  // hardware exp2 / log2 form of ncw_common.h
     return y;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
-// NB = output blocks per wave: 1 -> 8 waves per workgroup (two per SIMD, <= 256 registers each), 2 -> 4 waves (one per
-// SIMD, 512 registers): wave w owns blocks w, w + NW, ... .  With NB = 2 every B fragment read from LDS feeds two MFMAs,
-// half as many waves meet at the barriers, and no second wave competes for the SIMD's issue port.
+// NB = output blocks per wave: 1 -> 8 waves per workgroup (two per SIMD, <= 256 registers each): the shipped form.  (NB = 2 --
+// four 512-register waves, every B fragment feeding two MFMAs -- measured 0.188 vs 0.165 ms in round 2: half of a
+// 512-register file is AGPRs, the accumulators land there and every epilogue value costs a v_accvgpr_read.)
 // ------------------------------------------------------------------------------------------------
 template <int NB> struct PPAcc { f32x16 v[NB][2]; };  // [block of the wave][tile of the group]
 
@@ -122,67 +102,27 @@ template <int NB> struct PPAcc { f32x16 v[NB][2]; };  // [block of the wave][til
 // placed after each 2 NB MFMAs.  The B fragments go through a register ring (one k-unit of both tiles per slot,
 // PP_RING - 1 slots ahead of their use); with PREFETCH (the layer's LAST segment) unit u of the NEXT layer is fetched
 // global -> registers into the registers unit u of this layer has just left.
-#ifndef PP_RING
 #define PP_RING 4
-#endif
-#ifdef PP_EXP_TRACE2  // timing experiment: cycle stamps INSIDE the segments of one workgroup (slots of 8 per segment)
-__device__ float* pp_trace_buf;
-__device__ unsigned long long pp_trace_t0;
-#define PP_STEP_STAMP(u) do { if ((u) % 4 == 0 && blockIdx.x == 0 && (threadIdx.x & 63) == 0) { \
-        const int w_ = threadIdx.x >> 6; int& c_ = pp_trace_cnt[0]; \
-        if (c_ < 62) pp_trace_buf[w_ * 512 + c_ * 8 + (u) / 4] = (float)(__builtin_readcyclecounter() - pp_trace_t0); } } while (0)
-#else
-#define PP_STEP_STAMP(u) do {} while (0)
-#endif
 template <bool PREFETCH, int NB, class EPI>
 NCW_DEV void pp_segment(PPAcc<NB>& m, const f32x16 (&c_init)[NB], bf16x8 (&w)[NB][16], const pp_lfrag* in,
-                        const void* wnext, int nstride, int ob0, int ob_step, int lane, EPI&& epi, int* pp_trace_cnt = nullptr) {
+                        const void* wnext, int nstride, int ob0, int ob_step, int lane, EPI&& epi) {
     constexpr int RD = PP_RING - 1;
-    (void)pp_trace_cnt;
     bf16x8 b[PP_RING][2];
-#ifndef PP_EXP_NOLDSR
 #pragma unroll
     for (int c = 0; c < RD; ++c) { b[c][0] = in[c * 64]; b[c][1] = in[(16 + c) * 64]; }
-#endif
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        PP_STEP_STAMP(u);
-#ifndef PP_EXP_NOLDSR
         if (u + RD < 16)
-#else
-        if (false)
-#endif
         { b[(u + RD) % PP_RING][0] = in[(u + RD) * 64]; b[(u + RD) % PP_RING][1] = in[(16 + u + RD) * 64]; }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-#if defined(PP_EXP_NOMFMA) && defined(PP_EXP_NOLDSR)
-            if (u == 0) { m.v[nb][0] = c_init[nb]; m.v[nb][1] = c_init[nb]; }
-            m.v[nb][0][u] += (float)w[nb][u][0];
-            m.v[nb][1][u] += (float)w[nb][u][1];
-#elif defined(PP_EXP_NOMFMA)
-            if (u == 0) { m.v[nb][0] = c_init[nb]; m.v[nb][1] = c_init[nb]; }
-            m.v[nb][0][u] += (float)w[nb][u][0] * (float)b[u % PP_RING][0][0];
-            m.v[nb][1][u] += (float)w[nb][u][1] * (float)b[u % PP_RING][1][1];
-#elif defined(PP_EXP_NOLDSR)
-            m.v[nb][0] = NCW_MFMA_H(w[nb][u], w[nb][(u + 1) & 15], u == 0 ? c_init[nb] : m.v[nb][0], 0, 0, 0);
-            m.v[nb][1] = NCW_MFMA_H(w[nb][u], w[nb][(u + 2) & 15], u == 0 ? c_init[nb] : m.v[nb][1], 0, 0, 0);
-#else
             m.v[nb][0] = NCW_MFMA_H(w[nb][u], b[u % PP_RING][0], u == 0 ? c_init[nb] : m.v[nb][0], 0, 0, 0);
             m.v[nb][1] = NCW_MFMA_H(w[nb][u], b[u % PP_RING][1], u == 0 ? c_init[nb] : m.v[nb][1], 0, 0, 0);
-#endif
-#ifndef PP_EXP_NOW
             if (PREFETCH) w[nb][u] = pp_load_unit(wnext, u * nstride + ob0 + nb * ob_step, lane);
-#endif
         }
         epi(u);
-#ifndef PP_NO_SCHEDBAR
         __builtin_amdgcn_sched_barrier(0);
-#endif
     }
-    PP_STEP_STAMP(16);
-#ifdef PP_EXP_TRACE2
-    if (pp_trace_cnt) ++pp_trace_cnt[0];
-#endif
 }
 
 // extra k-units (gamma) from the x buffer: xin = xbuf + (first tile of the group) * XU * 64 + lane
@@ -228,9 +168,6 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
     const int ob = wave;  // this wave's blocks: ob + nb * NW
     const int L = net.n_layers, NL = L - 1;
     const int64_t tile0 = (int64_t)blockIdx.x * PP_TILES;
-#ifdef PP_EXP_TIMELINE  // timing experiment: absolute start / end stamps and hardware id of every workgroup
-    const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
-#endif
     // ---- biases of the Softplus layers -> LDS (256 f32 per layer) ---------------------------------------------------
     for (int i = threadIdx.x; i < NL * 64; i += 64 * NW) {
         const int l = i >> 6;
@@ -261,31 +198,13 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
     // the group finished one segment earlier -- goes through the epilogue: no register copies
     PPAcc<NB> x, y;
     bf16x8 frag[NB];
-    int tcnt[1] = {0};
-    (void)tcnt;
-#ifdef PP_EXP_TRACE2
-    if (blockIdx.x == 0 && threadIdx.x == 0) { pp_trace_buf = sdf; pp_trace_t0 = __builtin_readcyclecounter(); }
-    __syncthreads();
-#endif
     f32x16 bias[NB];
     auto read_bias = [&](int l) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) bias[nb] = pp_bias(bbuf + (l * 8 + ob + nb * NW) * 8, lane);
     };
-#ifdef PP_EXP_TRACE  // timing experiment: per-segment cycle stamps of one workgroup into the output buffer
-    const unsigned long long t0 = __builtin_readcyclecounter();
-#define PP_STAMP(slot) do { if (blockIdx.x == PP_EXP_TRACE && lane == 0) sdf[wave * 128 + (slot)] = (float)(__builtin_readcyclecounter() - t0); } while (0)
-#else
-#define PP_STAMP(slot) do {} while (0)
-#endif
-    int stamp = 0;
-    (void)stamp;
-#define PP_SEG_END() do { PP_STAMP(64 + stamp); pp_barrier(); ++stamp; PP_STAMP(stamp); } while (0)
-#ifdef PP_STATIC_PRIO  // experiment: the second-dispatched half loses every arbitration (MI355X_MICROARCH.md): boost it once
-    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(PP_STATIC_PRIO);
-#endif
+#define PP_SEG_END() pp_barrier()
     pp_barrier();
-    PP_STAMP(0);
     auto softplus_f = [](float z, int, int, int) { return pp_softplus(z); };
     // ---- layer 0 (K = 39: the 3 gamma units): [M(0,g0)] [M(0,g1) | E(0,g0)] ---------------------------------------------
     {
@@ -312,10 +231,8 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
             const pp_lfrag* in = abuf + (0 * 2 + ((l - 1) & 1)) * (PP_GRP / 16) + lane;
             pp_lfrag* out = abuf + (1 * 2 + ((l - 1) & 1)) * (PP_GRP / 16);  // E(l-1, g1)
             auto epi = [&](int u) { pp_epi_step<NB>(u, y, frag, out, ob, NW, lane, softplus_f); };
-            pp_segment<false, NB>(x, bias, wa, in, nullptr, 8, ob, NW, lane, epi, tcnt);
-#ifndef PP_EXP_NOSKIP
+            pp_segment<false, NB>(x, bias, wa, in, nullptr, 8, ob, NW, lane, epi);
             if (l == net.skip_layer) pp_mma_x<3, NB>(x, wx, gbuf + lane);
-#endif
             read_bias(l);
             PP_SEG_END();
         }
@@ -323,16 +240,14 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
             const pp_lfrag* in = abuf + (1 * 2 + ((l - 1) & 1)) * (PP_GRP / 16) + lane;
             pp_lfrag* out = abuf + (0 * 2 + (l & 1)) * (PP_GRP / 16);        // E(l, g0)
             auto epi = [&](int u) { pp_epi_step<NB>(u, x, frag, out, ob, NW, lane, softplus_f); };
-            if (more) pp_segment<true, NB>(y, bias, wa, in, net.w[l + 1], 8, ob, NW, lane, epi, tcnt);
-            else pp_segment<false, NB>(y, bias, wa, in, nullptr, 8, ob, NW, lane, epi, tcnt);
-#ifndef PP_EXP_NOSKIP
+            if (more) pp_segment<true, NB>(y, bias, wa, in, net.w[l + 1], 8, ob, NW, lane, epi);
+            else pp_segment<false, NB>(y, bias, wa, in, nullptr, 8, ob, NW, lane, epi);
             if (l == net.skip_layer) pp_mma_x<3, NB>(y, wx, gbuf + 2 * 3 * 64 + lane);
             // the skip layer's gamma columns (units 16..18) for the NEXT layer (W_0's units are no longer needed)
             if (more && l + 1 == net.skip_layer) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) pp_load_slice<3>(wx[nb], net.w[l + 1], 8, ob + nb * NW, 16, lane);
             }
-#endif
             read_bias(more ? l + 1 : l);
             PP_SEG_END();
         }
@@ -354,38 +269,16 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
 #pragma unroll
         for (int u = 0; u < 16; ++u) o.v[0] = NCW_MFMA_H(w1[u], in[u * 64], o.v[0], 0, 0, 0);
         const int64_t p = (tile0 + t) * 32 + (lane & 31);
-#if !defined(PP_EXP_TRACE) && !defined(PP_EXP_TIMELINE) && !defined(PP_EXP_TRACE2)
         if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
-#else
-        if (o.v[0][0] == 123.456f) sdf[p] = 0.f;
-#endif
     }
-    PP_STAMP(127);
-#ifdef PP_EXP_TIMELINE
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long tl1 = __builtin_amdgcn_s_memrealtime();
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned* o = reinterpret_cast<unsigned*>(sdf) + (size_t)blockIdx.x * 4;
-        o[0] = (unsigned)tl0; o[1] = (unsigned)tl1; o[2] = hwid; o[3] = xcc;
-    }
-#endif
 }
 
 }  // namespace
 
 int NCW_FN(ncw_sdf_inferC_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
-    // NCW_PP_NB: output blocks per wave.  1 (default) = eight waves, two per SIMD; 2 = four 512-register waves: every LDS
-    // fragment feeds two MFMAs and nobody competes for the issue port, but half of a 512-register wave's file is
-    // AGPRs, the accumulators land there and every epilogue value costs an extra v_accvgpr_read: 0.188 vs 0.165 ms
-    static const int nb = getenv("NCW_PP_NB") ? atoi(getenv("NCW_PP_NB")) : 1;
     const dim3 grid((unsigned)((tiles + PP_TILES - 1) / PP_TILES));
-    if (nb == 1) hipLaunchKernelGGL(sdf_inferC_kernel<1>, grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
-    else hipLaunchKernelGGL(sdf_inferC_kernel<2>, grid, dim3(64 * PP_WAVES / 2), 0, st, *net, src, n, sdf);
+    hipLaunchKernelGGL(sdf_inferC_kernel<1>, grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
     NCW_CHECK_LAUNCH();
     return 0;
 }

@@ -401,22 +401,19 @@ static bool sdf_net_ok(const NcwSdfNet* net) {
         } else return NCW_E_UNSUPPORTED;                                                                \
     } while (0)
 
-int NCW_FN(ncw_sdf_infer8_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant);  // ncw_sdf8.hip
-
 int NCW_FN(ncw_sdf_fwd8_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
                         hipStream_t st);  // ncw_sdf8.hip
 
 int NCW_FN(ncw_sdf_inferC_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);  // ncw_pp.hip
 
-// W = 512, 16-bit: weights streamed from L2, activations in LDS (ncw_sdf16.hip); NCW_SDF16=0 selects the generic kernels below
+// W = 512, 16-bit: weights streamed from L2, activations in LDS (ncw_sdf16.hip)
 int NCW_FN(ncw_sdf_infer16_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);
 int NCW_FN(ncw_sdf_fwd16_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
                                  const NcwSdfStash& stash, hipStream_t st);
 int NCW_FN(ncw_sdf_bwd16_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, const float* d_sdf, const float* d_grad,
                                  const NcwSdfStash& stash, hipStream_t st);
 static bool sdf16_on(const NcwSdfNet* net, int prec) {
-    static const int on = getenv("NCW_SDF16") ? atoi(getenv("NCW_SDF16")) : 1;
-    return on > 0 && net->rb == 16 && prec == NCW_PREC_BF16 && net->n_layers >= 3;
+    return net->rb == 16 && prec == NCW_PREC_BF16 && net->n_layers >= 3;
 }
 
 // fp16 build, W = 256: the split-precision value path of ncw_split.hip whenever the net carries residual matrices (w_lo)
@@ -437,18 +434,14 @@ static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, i
     if (src.mode == 4) return NCW_E_UNSUPPORTED;  // point selections: background NeRF kernels only
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    // W = 256, 16-bit: variant 3 = the fine-interleaved kernel of ncw_pp.hip (default: 0.165-0.175 ms per 131,072 points),
-    // 2 = the weights-stationary burst kernel of ncw_sdf8.hip (0.198 ms),
-    // 0 = the weights-through-LDS kernel below (0.26 ms).
-    static const int variant8 = getenv("NCW_SDF_INFER8") ? atoi(getenv("NCW_SDF_INFER8")) : 3;
 #ifdef NCW_HALF_F16
     if (sdf_split_on(net, prec)) return ncw_sdf_inferS_launch_f16(net, src, n, sdf, st);
 #endif
     if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_infer16_launch)(net, src, n, sdf, st);
-    if (variant8 == 3 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3 && net->n_layers <= 12)
+    // W = 256, 16-bit: the fine-interleaved kernel of ncw_pp.hip (0.165 ms per 131,072 points; round 2's burst kernel 0.198,
+    // the weights-through-LDS kernel below -- fp32 and the other widths -- 0.26)
+    if (net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3 && net->n_layers <= 12)
         return NCW_FN(ncw_sdf_inferC_launch)(net, src, n, sdf, st);
-    if (variant8 > 0 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
-        return NCW_FN(ncw_sdf_infer8_launch)(net, src, n, sdf, st, variant8 == 3 ? 2 : variant8);
     NCW_SDF_DISPATCH(sdf_infer_kernel, *net, src, n, sdf);
     return 0;
 }
@@ -493,13 +486,12 @@ extern "C" int NCW_FN(ncw_sdf_fwd)(const NcwSdfNet* net, int prec, const NcwPoin
     if (pts->mode == 4) return NCW_E_UNSUPPORTED;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    // W = 256 bf16: the weights-stationary kernel of ncw_sdf8.hip (0.57 vs 0.67 ms per 131,072 points);
-    // NCW_SDF_FWD8=0 selects the weights-through-LDS kernel below
-    static const int fwd8 = getenv("NCW_SDF_FWD8") ? atoi(getenv("NCW_SDF_FWD8")) : 1;
 #ifdef NCW_HALF_F16
     if (sdf_split_on(net, prec)) return ncw_sdf_fwdS_launch_f16(net, *pts, n, sdf, grad, *stash, st);
 #endif
-    if (fwd8 > 0 && net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
+    // W = 256, 16-bit: the weights-stationary kernel of ncw_sdf8.hip (0.57 vs 0.67 ms per 131,072 points for the
+    // weights-through-LDS kernel below, which serves fp32 and the other widths)
+    if (net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
         return NCW_FN(ncw_sdf_fwd8_launch)(net, *pts, n, sdf, grad, *stash, st);
     if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_fwd16_launch)(net, *pts, n, sdf, grad, *stash, st);
     NCW_SDF_DISPATCH(sdf_fwd_kernel, *net, *pts, n, sdf, grad, *stash);

@@ -1,12 +1,13 @@
-// Weights-stationary fused MLP kernels, W = 256 bf16: sdf_inferB, sdf_fwdB, nerf_fwdB, nerf_bwdB.
+// Weights-stationary fused MLP kernels, W = 256, 16-bit: sdf_fwdB, nerf_fwdB, nerf_bwdB.
 // (The 8-wave / half-layer pilot of round 1 and the sdf_bwd / color_fwd ports that did not beat the
-// two-workgroups-per-CU kernels were removed in round 2; numbers in DESIGN.md.)
+// two-workgroups-per-CU kernels were removed in round 2, the burst inference kernel sdf_inferB -- superseded by
+// ncw_pp.hip's fine-interleaved sdf_inferC -- in round 3; numbers in DESIGN.md.)
 #include "ncw_mlp.h"
 
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// Variant 2 (default; NCW_SDF_INFER8=2): WEIGHTS STATIONARY IN REGISTERS, ACTIVATIONS THROUGH LDS.
+// The structure: WEIGHTS STATIONARY IN REGISTERS, ACTIVATIONS THROUGH LDS.
 // A workgroup of 8 waves owns 128 points (4 tiles of 32).  Wave w owns OUTPUT BLOCK w of every hidden layer:
 // its slice of the layer's packed matrix (16 k-units x 1 KiB = 64 registers per lane) is loaded global -> registers,
 // the NEXT layer's slice while the current one is being used (the loads have a whole layer to land), and is reused
@@ -38,121 +39,8 @@ NCW_DEV void sb_load_slice(bf16x8* a, const void* w, int rb_stride, int ob, int 
     for (int q = 0; q < NU; ++q) a[q] = g[((size_t)(u0 + q) * rb_stride + ob) * 64];
 }
 
-__global__ __launch_bounds__(64 * SB_WAVES) void sdf_inferB_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
-                                                                  float* __restrict__ sdf) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_GAM];
-    sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
-    sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
-    sb_lfrag* const gbuf = abuf0 + 2 * SB_ACT / 16;
-    const int lane = ncw_lane();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int L = net.n_layers;
-    const int64_t tile0 = (int64_t)blockIdx.x * SB_TILES;
-    // ---- gamma of the 4 tiles (waves 0..3), straight into LDS as k-units 0..2 --------------------------------
-    if (wave < SB_TILES) {
-        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
-        if (p >= n) p = n - 1;
-        float xs[3];
-        load_point(src, p, xs, ray);
-        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
-        CVec<2> gam;
-        freq_encode<2, 3, 6, true>(gam, xs, lane);
-        Act<PrecBF16, 2> ga;
-        to_act(ga, gam);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) gbuf[(wave * 3 + q) * 64 + lane] = ga.f[q];
-    }
-    // ---- layer 0 slice (3 units) and the prefetch of layer 1 ----------------------------------------------
-    bf16x8 wa[16], wb[16], wg[3];      // current slice, next slice, gamma part of the skip layer
-    {
-        bf16x8 w0[3];
-        sb_load_slice<3>(w0, net.w[0], 8, wave, 0, lane);
-        if (L - 1 > 1) sb_load_slice<16>(wa, net.w[1], 8, wave, 0, lane);
-        f32x16 bias;
-        {
-            CVec<1> b1;
-            load_bias(b1, net.b[0] + wave * 32, lane);
-            bias = b1.v[0];
-        }
-        __syncthreads();  // gamma visible
-#pragma unroll
-        for (int t = 0; t < SB_TILES; ++t) {
-            f32x16 acc = bias;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) acc = NCW_MFMA_H(w0[q], gbuf[(t * 3 + q) * 64 + lane], acc, 0, 0, 0);
-            Act<PrecBF16, 1> o;
-            f32x16 yv;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[r], y, s); yv[r] = y; }
-            to_act_block<1>(o, 0, yv);
-            abuf0[(t * 16 + 2 * wave) * 64 + lane] = o.f[0];
-            abuf0[(t * 16 + 2 * wave + 1) * 64 + lane] = o.f[1];
-        }
-    }
-    int cur = 0;
-    // ---- hidden layers 1 .. L-2 ---------------------------------------------------------------------------
-    for (int l = 1; l < L - 1; ++l) {
-        const bool skip = (l == net.skip_layer);
-        if (skip) sb_load_slice<3>(wg, net.w[l], 8, wave, 16, lane);       // units 16..18 = gamma columns
-        if (l + 1 < L - 1) sb_load_slice<16>(wb, net.w[l + 1], 8, wave, 0, lane);  // prefetch the next layer's slice
-        f32x16 bias;
-        {
-            CVec<1> b1;
-            load_bias(b1, net.b[l] + wave * 32, lane);
-            bias = b1.v[0];
-        }
-        __syncthreads();  // layer l-1 outputs of all waves are in abuf[cur]; abuf[cur^1] is free
-        const sb_lfrag* in = cur ? abuf1 : abuf0;
-        sb_lfrag* out = cur ? abuf0 : abuf1;
-#pragma unroll
-        for (int tp = 0; tp < SB_TILES; tp += 2) {  // two tiles at a time: two independent accumulator chains
-            f32x16 acc0 = bias, acc1 = bias;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                acc0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
-            }
-            if (skip) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    acc0 = NCW_MFMA_H(wg[q], gbuf[(tp * 3 + q) * 64 + lane], acc0, 0, 0, 0);
-                    acc1 = NCW_MFMA_H(wg[q], gbuf[((tp + 1) * 3 + q) * 64 + lane], acc1, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x16& acc = j ? acc1 : acc0;
-                Act<PrecBF16, 1> o;
-                f32x16 yv;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[r], y, s); yv[r] = y; }
-                to_act_block<1>(o, 0, yv);
-                out[((tp + j) * 16 + 2 * wave) * 64 + lane] = o.f[0];
-                out[((tp + j) * 16 + 2 * wave + 1) * 64 + lane] = o.f[1];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) wa[q] = wb[q];
-        cur ^= 1;
-    }
-    // ---- sdf row: wave t < 4 takes tile t ------------------------------------------------------------------
-    __syncthreads();
-    if (wave < SB_TILES) {
-        bf16x8 w1[16];
-        sb_load_slice<16>(w1, net.w[L - 1], 1, 0, 0, lane);
-        CVec<1> o;
-        load_bias(o, net.b[L - 1], lane);
-        const sb_lfrag* in = cur ? abuf1 : abuf0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) o.v[0] = NCW_MFMA_H(w1[q], in[(wave * 16 + q) * 64 + lane], o.v[0], 0, 0, 0);
-        const int64_t p = (tile0 + wave) * 32 + (lane & 31);
-        if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------
-// sdf_fwd in the weights-stationary structure (NCW_SDF_FWD8): forward chain with the activation stash, feature
+// sdf_fwd in the weights-stationary structure: forward chain with the activation stash, feature
 // layer, sdf row, then the analytic adjoint pass a_{l-1} = W_l^T (a_l * phi'(z_l)) with the t_l stash and
 // grad = J_gamma^T g_gamma -- the same arithmetic as sdf_fwd_kernel (ncw_sdf.hip), W = 256 bf16.
 // The two gamma output blocks of the transposed skip layer and of W_0^T are 2 blocks x 4 tiles = 8 jobs:
@@ -395,7 +283,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
 
 // ------------------------------------------------------------------------------------------------
 // nerf_fwd (models/nerf.py:86-183 on the inverted-sphere points of renderer.py:176-186) in the weights-stationary
-// structure, W = 256 bf16 (NCW_NERF_FWD8): trunk with the gamma(p) skip, density, feature layer, appearance head,
+// structure, W = 256, 16-bit: trunk with the gamma(p) skip, density, feature layer, appearance head,
 // raw rgb -- the same arithmetic and stash as nerf_fwd_kernel (ncw_nerf.hip).  The 128-wide head layers are
 // 4 output blocks x 4 tiles: wave w takes block (w & 3) for the tile pair (w >> 2).
 // xbuf ([4 tiles][6 units]) holds gamma(p) during the trunk and AUX1 = [gamma(dir) | appearance code] for the head.
@@ -616,7 +504,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
 
 
 // ------------------------------------------------------------------------------------------------
-// nerf_bwd in the weights-stationary structure (NCW_NERF_BWD8), W = 256 bf16: the data-gradient chain of
+// nerf_bwd in the weights-stationary structure, W = 256, 16-bit: the data-gradient chain of
 // nerf_bwd_kernel (ncw_nerf.hip) -- rgb head reversed, appearance head, feature / density, trunk -- emitting the
 // z-bar stashes the weight-gradient GEMMs read and the per-ray appearance-code gradient d_a.
 // ------------------------------------------------------------------------------------------------
@@ -828,15 +716,6 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
 
 
 }  // namespace
-
-int NCW_FN(ncw_sdf_infer8_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st, int variant) {
-    const int64_t tiles = (n + 31) / 32;
-    (void)variant;
-    hipLaunchKernelGGL(sdf_inferB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st,
-                       *net, src, n, sdf);
-    NCW_CHECK_LAUNCH();
-    return 0;
-}
 
 int NCW_FN(ncw_sdf_fwd8_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
                         hipStream_t st) {

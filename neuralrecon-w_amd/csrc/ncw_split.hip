@@ -19,8 +19,6 @@
 //     is in use; two barriers per layer;
 //   * pipelined chain (s2_value_chain: sdf_infer): one tile per stage, the epilogue of the previous stage between the
 //     MFMAs of the current one, one LDS-only barrier per stage, the whole slice resident (see there).
-#include <stdlib.h>
-
 #include "ncw_mlp.h"
 
 #ifdef NCW_HALF_F16
@@ -203,6 +201,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
 // tiles and is reloaded in place during the layer's last segment; two 16-register accumulators alternate.
 // ------------------------------------------------------------------------------------------------
 constexpr int S2_TILE = 16 * 2 * 1024;     // one tile region
+
 constexpr int S2_BIAS = 8 * 1024;          // bias staging: up to 8 Softplus layers x 256 f32 (128 + 24 + 8 KiB = all of the LDS)
 typedef __attribute__((address_space(3))) f32x4 ss_lf4;
 
@@ -238,6 +237,7 @@ NCW_DEV void s2_mma_x(f32x16& a, const bf16x8* wh, const bf16x8* wl, const ss_lf
 
 // One segment: m += W[ob] . h of one tile (in = tile region + lane; m holds the bias on entry), epi(u) after the three MFMAs
 // of unit u.  PREFETCH: unit u of the NEXT layer goes into the registers unit u has just left.
+constexpr int S2_RING = 3;  // depths 2 / 3 / 4 measured the same (0.38 ms per 131k points on one box): not LDS latency
 template <bool PREFETCH, class EPI>
 NCW_DEV void s2_segment(f32x16& m, bf16x8 (&wh)[16], bf16x8 (&wl)[16], const ss_lfrag* in, const void* wn, const void* wn_lo, int ob,
                         int lane, EPI&& epi) {
@@ -246,17 +246,19 @@ NCW_DEV void s2_segment(f32x16& m, bf16x8 (&wh)[16], bf16x8 (&wl)[16], const ss_
     f32x16 c;
 #pragma unroll
     for (int r = 0; r < 16; ++r) c[r] = 0.f;
-    bf16x8 b[2][2];  // ring of two k-units: {hi, lo}, one unit ahead of its use
-    b[0][0] = in[0]; b[0][1] = in[64];
+    constexpr int RD = S2_RING - 1;  // the B fragments {hi, lo} of a k-unit are read RD units ahead of their use
+    bf16x8 b[S2_RING][2];
+#pragma unroll
+    for (int q = 0; q < RD; ++q) { b[q][0] = in[(q * 2) * 64]; b[q][1] = in[(q * 2 + 1) * 64]; }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        if (u + 1 < 16) {
-            b[(u + 1) & 1][0] = in[((u + 1) * 2) * 64];
-            b[(u + 1) & 1][1] = in[((u + 1) * 2 + 1) * 64];
+        if (u + RD < 16) {
+            b[(u + RD) % S2_RING][0] = in[((u + RD) * 2) * 64];
+            b[(u + RD) % S2_RING][1] = in[((u + RD) * 2 + 1) * 64];
         }
-        m = NCW_MFMA_H(wh[u], b[u & 1][0], m, 0, 0, 0);
-        c = NCW_MFMA_H(wl[u], b[u & 1][0], c, 0, 0, 0);
-        c = NCW_MFMA_H(wh[u], b[u & 1][1], c, 0, 0, 0);
+        m = NCW_MFMA_H(wh[u], b[u % S2_RING][0], m, 0, 0, 0);
+        c = NCW_MFMA_H(wl[u], b[u % S2_RING][0], c, 0, 0, 0);
+        c = NCW_MFMA_H(wh[u], b[u % S2_RING][1], c, 0, 0, 0);
         if (PREFETCH) {
             wh[u] = ss_gload(wn, (size_t)u * 8 + ob, lane);
             wl[u] = ss_gload(wn_lo, (size_t)u * 8 + ob, lane);
@@ -599,8 +601,9 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, 
 int ncw_sdf_inferS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
     const dim3 grid((unsigned)((tiles + SS_TILES - 1) / SS_TILES));
-    if (net->n_layers - 1 <= 8) hipLaunchKernelGGL(sdf_inferS2_kernel, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf);
-    else hipLaunchKernelGGL(sdf_inferS_kernel, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf);
+    if (net->n_layers - 1 <= 8) {
+        hipLaunchKernelGGL(sdf_inferS2_kernel, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf);
+    } else hipLaunchKernelGGL(sdf_inferS_kernel, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf);
     NCW_CHECK_LAUNCH();
     return 0;
 }

@@ -2,11 +2,12 @@
 
 Reference: utils/visualization.py:37-159 `extract_mesh` (rank-0 CPU `skimage.measure.marching_cubes`, vertex
 colours through `renderer.rgb`, trimesh export) driven by tools/extract_mesh.py:104-168.  Here the SDF grid never
-leaves the GPU: `grid.sdf_grid` -> `isosurface` (marching tetrahedra, csrc/ncw_mesh.hip) -> vertex welding with
-torch.unique -> optional colour pass -> binary PLY.  skimage's triangulation (Lewiner) is not reproducible
-without skimage, which is neither in the reference tree nor installable: **triangulation parity is unpinned**;
-what is kept is the vertex rule (linear zero crossing on every sign-changing grid edge), the `mask` semantics
-and the coordinate chain `verts * voxel_size + vol_origin`, `* scene_radius + scene_origin` (:116-117).
+leaves the GPU: `grid.sdf_grid` -> `isosurface` (marching cubes, csrc/ncw_mesh.hip + the generated case tables of
+mc_tables.py) -> vertex welding with torch.unique -> optional colour pass -> binary PLY.  The VERTEX SET is the reference's
+(one linear zero crossing per sign-changing grid edge of the enabled cubes: tests/test_gpu_mesh.py checks it edge by
+edge); skimage's triangulation of the ambiguous cube configurations (Lewiner) is not reproducible without skimage, which
+is neither in the reference tree nor installable: **triangulation parity is unpinned** there.  Also kept: the `mask`
+semantics and the coordinate chain `verts * voxel_size + vol_origin`, `* scene_radius + scene_origin` (:116-117).
 Normals / winding point towards increasing SDF (outwards).
 """
 import struct
@@ -16,6 +17,21 @@ import torch
 
 from . import grid as _grid
 from . import lib as L
+
+
+_TABLES = {}
+
+
+def _mc_tables(dev):
+    """The generated marching-cubes case tables (mc_tables.py) on `dev`."""
+    t = _TABLES.get(str(dev))
+    if t is None:
+        from . import mc_tables
+
+        tri, ntri, edges = mc_tables.tables()
+        t = _TABLES[str(dev)] = (torch.from_numpy(tri).to(dev).contiguous(), torch.from_numpy(ntri).to(dev).contiguous(),
+                                 torch.from_numpy(edges).to(dev).contiguous())
+    return t
 
 
 @torch.no_grad()
@@ -30,9 +46,10 @@ def isosurface(sdf, level=0.0, mask=None):
     m8 = None if mask is None else mask.to(device=dev, dtype=torch.uint8).contiguous()
     ncubes = (Dx - 1) * (Dy - 1) * (Dz - 1)
     counts = torch.empty(ncubes, dtype=torch.int32, device=dev)
+    tri, ntri, edges = _mc_tables(dev)
     lib = L.get_lib()
-    L.check(lib.ncw_mt_count(L.ptr(sdf), L.ptr(m8), Dx, Dy, Dz, float(level), L.ptr(counts), L.stream_ptr(dev)),
-            "ncw_mt_count")
+    L.check(lib.ncw_mc_count(L.ptr(sdf), L.ptr(m8), Dx, Dy, Dz, float(level), L.ptr(ntri), L.ptr(counts), L.stream_ptr(dev)),
+            "ncw_mc_count")
     incl = torch.cumsum(counts, 0, dtype=torch.int64)
     T = int(incl[-1])  # one device->host read: the mesh size
     if T == 0:
@@ -40,8 +57,8 @@ def isosurface(sdf, level=0.0, mask=None):
     offsets = (incl - counts).contiguous()
     pos = torch.empty(T, 3, 3, device=dev, dtype=torch.float32)
     key = torch.empty(T, 3, device=dev, dtype=torch.int64)
-    L.check(lib.ncw_mt_emit(L.ptr(sdf), L.ptr(m8), Dx, Dy, Dz, float(level), L.ptr(offsets), L.ptr(pos), L.ptr(key),
-                            L.stream_ptr(dev)), "ncw_mt_emit")
+    L.check(lib.ncw_mc_emit(L.ptr(sdf), L.ptr(m8), Dx, Dy, Dz, float(level), L.ptr(tri), L.ptr(ntri), L.ptr(edges),
+                            L.ptr(offsets), L.ptr(pos), L.ptr(key), L.stream_ptr(dev)), "ncw_mc_emit")
     uniq, inv = torch.unique(key.reshape(-1), return_inverse=True)  # weld: one vertex per grid edge
     verts = torch.empty(uniq.shape[0], 3, device=dev, dtype=torch.float32)
     verts[inv] = pos.reshape(-1, 3)  # all copies of a vertex are bit-identical (interpolated lo -> hi)

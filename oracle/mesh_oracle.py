@@ -1,63 +1,116 @@
 """TEST INFRASTRUCTURE ONLY -- never imported by the product path.
 
-CPU (numpy) restatement of the iso-surface extractor of neuralrecon-w_amd/csrc/ncw_mesh.hip: marching tetrahedra
-on a regular grid, used in place of `skimage.measure.marching_cubes` at utils/visualization.py:114.
-PARITY UNPINNED: skimage (Lewiner) is neither under /root/reference nor installable, so the triangulation of the
-reference cannot be reproduced; this oracle pins the GPU kernel to an independent implementation of the SAME
-algorithm (plain Python loops over cubes and tetrahedra: small grids only) and the tests add
-geometry-level properties (vertices on the surface, watertightness, enclosed volume, orientation).
+CPU (numpy, plain Python loops: small grids only) restatement of the iso-surface extractor that stands in for
+`skimage.measure.marching_cubes(sdf, level, mask=...)` at utils/visualization.py:114: MARCHING CUBES.
+
+What the reference's call guarantees independently of skimage's internals -- and what `edge_vertices` restates exactly --
+is the VERTEX SET: one vertex on every sign-changing grid edge of an enabled cube, at the linear zero crossing.
+PARITY UNPINNED for the triangulation of the ambiguous cube configurations: skimage (Lewiner's variant: interior tests, a
+cell-centre vertex in a few sub-cases) is neither under /root/reference nor installable here.  `marching_cubes` below
+triangulates each cube by tracing the iso-polygons over the cube's faces straight from the corner values -- no case table
+-- with the same face rule as the product's generated tables (on an ambiguous face the two `inside` corners, value <
+level, are kept apart); the GPU kernel is compared with it triangle by triangle, and the tests add geometry-level
+properties (watertightness, orientation, enclosed volume, vertices on the surface).
 """
 import numpy as np
 
-TETS = [(0, 1, 3, 7), (0, 3, 2, 7), (0, 2, 6, 7), (0, 6, 4, 7), (0, 4, 5, 7), (0, 5, 1, 7)]  # corner bit0=x,1=y,2=z
+
+def _pid(shape, x, y, z):
+    return (x * shape[1] + y) * shape[2] + z
 
 
-def marching_tetrahedra(sdf, level=0.0, mask=None):
-    """sdf [Dx,Dy,Dz] float32 -> (triangles as a list of 3-tuples of vertex keys (lo_id, hi_id), dict key -> xyz)."""
+def edge_vertices(sdf, level=0.0, mask=None):
+    """{(lo_id, hi_id): xyz float32} for every sign-changing grid edge that belongs to at least one enabled cube
+    (cube (i,j,k) is enabled iff mask is None or mask[i+1,j+1,k+1]); the vertex is interpolated from the lower point id to
+    the higher one in float32, like the kernel."""
     sdf = np.asarray(sdf, dtype=np.float32)
     Dx, Dy, Dz = sdf.shape
-    pid = lambda x, y, z: (x * Dy + y) * Dz + z  # noqa: E731
-    verts, tris = {}, []
     f32 = np.float32
-
-    def vertex(ca, cb, base):
-        (ia, pa, va), (ib, pb, vb) = ca, cb
-        if ia > ib:
-            (ia, pa, va), (ib, pb, vb) = (ib, pb, vb), (ia, pa, va)
-        t = (f32(level) - va) / (vb - va)
-        p = tuple(f32(pa[d]) + t * (f32(pb[d]) - f32(pa[d])) for d in range(3))
-        verts[(ia, ib)] = p
-        return (ia, ib)
-
+    out = {}
     for x in range(Dx - 1):
         for y in range(Dy - 1):
             for z in range(Dz - 1):
                 if mask is not None and not mask[x + 1, y + 1, z + 1]:
                     continue
-                corner = []
-                for k in range(8):
-                    p = (x + (k & 1), y + ((k >> 1) & 1), z + ((k >> 2) & 1))
-                    corner.append((pid(*p), p, sdf[p]))
-                for tet in TETS:
-                    ins = [c for c in tet if corner[c][2] < level]
-                    out = [c for c in tet if not corner[c][2] < level]
-                    if len(ins) in (0, 4):
-                        continue
-                    off = lambda c: np.array([c & 1, (c >> 1) & 1, (c >> 2) & 1], dtype=np.float32)  # noqa: E731
-                    g = sum(off(c) for c in out) / len(out) - sum(off(c) for c in ins) / len(ins)
-                    C = corner
-                    if len(ins) == 1:
-                        cand = [[vertex(C[ins[0]], C[o], None) for o in out]]
-                    elif len(ins) == 3:
-                        cand = [[vertex(C[out[0]], C[i], None) for i in ins]]
-                    else:
-                        ac, ad = vertex(C[ins[0]], C[out[0]], None), vertex(C[ins[0]], C[out[1]], None)
-                        bd, bc = vertex(C[ins[1]], C[out[1]], None), vertex(C[ins[1]], C[out[0]], None)
-                        cand = [[ac, ad, bd], [ac, bd, bc]]
-                    for a, b, c in cand:
-                        pa, pb, pc = (np.array(verts[k], dtype=np.float32) for k in (a, b, c))
-                        n = np.cross(pb - pa, pc - pa)
-                        if float(np.dot(n, g)) < 0:
-                            b, c = c, b
-                        tris.append((a, b, c))
+                pts = [(x + (k & 1), y + ((k >> 1) & 1), z + ((k >> 2) & 1)) for k in range(8)]
+                for a in range(8):
+                    for b in range(a + 1, 8):
+                        if bin(a ^ b).count("1") != 1:
+                            continue
+                        pa, pb = pts[a], pts[b]
+                        va, vb = sdf[pa], sdf[pb]
+                        if (va < level) == (vb < level):
+                            continue
+                        ia, ib = _pid(sdf.shape, *pa), _pid(sdf.shape, *pb)
+                        if ia > ib:
+                            ia, ib, pa, pb, va, vb = ib, ia, pb, pa, vb, va
+                        t = (f32(level) - va) / (vb - va)
+                        out[(ia, ib)] = tuple(f32(pa[d]) + t * (f32(pb[d]) - f32(pa[d])) for d in range(3))
+    return out
+
+
+def _cube_polygons(val, level):
+    """Iso-polygons of one cube from its 8 corner values (corner k at offset (k&1, k>>1&1, k>>2&1)): lists of cut edges
+    (a, b) with a inside (value < level), b outside, in cyclic order, wound with the normal towards increasing values."""
+    ins = [v < level for v in val]
+    off = [np.array([k & 1, (k >> 1) & 1, (k >> 2) & 1], dtype=np.float64) for k in range(8)]
+    nbr = {}
+
+    def cut(a, b):  # canonical name of the cut edge between adjacent corners a, b
+        return (a, b) if ins[a] else (b, a)
+
+    def join(e, f):
+        nbr.setdefault(e, []).append(f)
+        nbr.setdefault(f, []).append(e)
+
+    for axis in range(3):
+        u, v = [d for d in range(3) if d != axis]
+        for side in (0, 1):
+            ring = [side << axis | (cu << u) | (cv << v) for cu, cv in ((0, 0), (1, 0), (1, 1), (0, 1))]
+            crossing = [i for i in range(4) if ins[ring[i]] != ins[ring[(i + 1) % 4]]]
+            if len(crossing) == 2:
+                i, j = crossing
+                join(cut(ring[i], ring[(i + 1) % 4]), cut(ring[j], ring[(j + 1) % 4]))
+            elif len(crossing) == 4:  # diagonal corners share a sign: cut off each inside corner on its own
+                for i in range(4):
+                    if ins[ring[i]]:
+                        join(cut(ring[i], ring[i - 1]), cut(ring[i], ring[(i + 1) % 4]))
+    polys, done = [], set()
+    for start in sorted(nbr):
+        if start in done:
+            continue
+        loop, prev, cur = [start], None, start
+        done.add(start)
+        while True:
+            a, b = nbr[cur]
+            nxt = b if a == prev else a
+            if nxt == start:
+                break
+            loop.append(nxt)
+            done.add(nxt)
+            prev, cur = cur, nxt
+        mid = [(off[a] + off[b]) / 2 for a, b in loop]
+        n = sum(np.cross(mid[i], mid[(i + 1) % len(mid)]) for i in range(len(mid)))
+        g = sum(off[b] - off[a] for a, b in loop)
+        polys.append(loop if float(np.dot(n, g)) >= 0 else loop[::-1])
+    return polys
+
+
+def marching_cubes(sdf, level=0.0, mask=None):
+    """sdf [Dx,Dy,Dz] float32 -> (triangles as a list of 3-tuples of vertex keys (lo_id, hi_id), dict key -> xyz)."""
+    sdf = np.asarray(sdf, dtype=np.float32)
+    Dx, Dy, Dz = sdf.shape
+    verts = edge_vertices(sdf, level, mask)
+    tris = []
+    for x in range(Dx - 1):
+        for y in range(Dy - 1):
+            for z in range(Dz - 1):
+                if mask is not None and not mask[x + 1, y + 1, z + 1]:
+                    continue
+                pts = [(x + (k & 1), y + ((k >> 1) & 1), z + ((k >> 2) & 1)) for k in range(8)]
+                ids = [_pid(sdf.shape, *p) for p in pts]
+                for loop in _cube_polygons([sdf[p] for p in pts], np.float32(level)):
+                    keys = [(min(ids[a], ids[b]), max(ids[a], ids[b])) for a, b in loop]
+                    for i in range(1, len(keys) - 1):
+                        tris.append((keys[0], keys[i], keys[i + 1]))
     return tris, verts

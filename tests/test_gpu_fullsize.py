@@ -203,19 +203,3 @@ def test_sync_free_depth_loss_is_the_same_loss():
     assert abs(float(a["sfm_depth_loss"].mean()) - float(b["sfm_depth_loss"].mean())) < 1e-7
     la, lb = loss_from_outputs(a, rgbs.cuda()), loss_from_outputs(b, rgbs.cuda())
     assert abs(float(la) - float(lb)) < 1e-6
-
-
-def test_weights_through_lds_kernels_at_the_bench_width_in_a_subprocess():
-    """At W = 256 bf16 the forward kernels default to the weights-stationary structure (csrc/ncw_sdf8.hip); the
-    weights-through-LDS kernels (the only ones for f32 / other widths) must stay correct at that shape: the bf16
-    train-step comparison of this file is re-run with NCW_SDF_FWD8=0 NCW_NERF_FWD8=0 NCW_NERF_BWD8=0 NCW_SDF_INFER8=0."""
-    import os
-    import subprocess
-    import sys
-
-    if os.environ.get("NCW_NERF_FWD8") is not None:
-        pytest.skip("already inside a variant run")
-    env = dict(os.environ, NCW_SDF_FWD8="0", NCW_NERF_FWD8="0", NCW_NERF_BWD8="0", NCW_SDF_INFER8="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "bf16"],
-                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,5 +1,6 @@
-"""GPU: iso-surface extraction -- ncw_mt_count / ncw_mt_emit through mesh.isosurface against the
-CPU restatement (same triangles, bit-identical vertices), geometry properties at a larger size, the colour pass
+"""GPU: iso-surface extraction -- marching cubes, ncw_mc_count / ncw_mc_emit through mesh.isosurface:
+the vertex set against the reference's vertex rule (every sign-changing grid edge of an enabled cube, at its linear zero
+crossing, bit-identical), the triangles against the CPU restatement, geometry properties at a larger size, the colour pass
 and the PLY writer."""
 import os
 
@@ -21,14 +22,14 @@ def _field(D, seed):
 @pytest.mark.parametrize("D,use_mask", [(9, False), (12, True)])
 def test_matches_restatement(D, use_mask):
     from neuralrecon_w_amd import mesh
-    from oracle.mesh_oracle import marching_tetrahedra
+    from oracle.mesh_oracle import edge_vertices, marching_cubes
 
     f = _field(D, D)
     f[3, 3, 3] = 0.0  # a value exactly on the level
     mask = None
     if use_mask:
         mask = np.random.default_rng(1).random(f.shape) < 0.7
-    tris, verts = marching_tetrahedra(f, 0.0, mask)
+    tris, verts = marching_cubes(f, 0.0, mask)
     v, fc = mesh.isosurface(torch.from_numpy(f).cuda(), 0.0, None if mask is None else torch.from_numpy(mask).cuda())
     v, fc = v.cpu().numpy(), fc.cpu().numpy()
     # same triangles (as unordered vertex triples with bit-identical coordinates); triangles with coincident
@@ -47,6 +48,28 @@ def test_matches_restatement(D, use_mask):
         if k is not None:
             got[k] = got.get(k, 0) + 1
     assert len(got) > 50 and got == ref
+    # the analytic vertex-set check (utils/visualization.py:114-119): exactly one vertex per sign-changing edge of the enabled
+    # cubes, at the float32 linear interpolation lo -> hi
+    want_v = {tuple(float(c) for c in p) for k, p in edge_vertices(f, 0.0, mask).items()
+              if f.reshape(-1)[k[0]] != 0.0 and f.reshape(-1)[k[1]] != 0.0}
+    got_v = {tuple(float(c) for c in p) for p in v}
+    assert want_v <= got_v and len(got_v) <= len(edge_vertices(f, 0.0, mask))
+
+
+def test_vertex_set_on_noise():
+    """White-noise grid (every ambiguous configuration occurs): welded vertices == the sign-changing grid edges, one each,
+    bit-identical positions; every face references existing vertices; the surface is closed away from the grid boundary."""
+    from neuralrecon_w_amd import mesh
+    from oracle.mesh_oracle import edge_vertices
+
+    f = np.random.default_rng(9).standard_normal((11, 9, 10)).astype(np.float32)
+    v, fc = mesh.isosurface(torch.from_numpy(f).cuda())
+    want = edge_vertices(f)
+    got = {tuple(float(c) for c in p) for p in v.cpu().numpy()}
+    assert len(got) == v.shape[0] == len(want) and got == {tuple(float(c) for c in p) for p in want.values()}
+    e = torch.cat([fc[:, [0, 1]], fc[:, [1, 2]], fc[:, [2, 0]]])
+    key = e[:, 0] * v.shape[0] + e[:, 1]
+    assert key.unique().numel() == key.numel()  # consistently oriented: no directed edge twice
 
 
 def test_sphere_properties_and_ply(tmp_path):

@@ -99,21 +99,3 @@ def test_sdf_infer_edge_sizes():
         if n:
             full = net.sdf(torch.cat([x, torch.rand(77, 3).cuda()]), prec=nw.PREC_F32)[:n]
             assert torch.equal(out, full)  # a point's result does not depend on its tile mates
-
-
-@pytest.mark.parametrize("variant,nb", [("0", "1"), ("2", "1"), ("3", "2")])
-def test_other_infer_kernels_match_in_a_subprocess(variant, nb):
-    """W = 256 bf16 inference defaults to the fine-interleaved kernel (csrc/ncw_pp.hip, variant 3, eight waves); the
-    weights-through-LDS kernel (NCW_SDF_INFER8=0), the weights-stationary burst kernel (=2) and the four-wave form of
-    the default (NCW_PP_NB=2) must give the same answers: the tests of this file are re-run in a subprocess with the
-    switches set (they are read once per process)."""
-    import os
-    import subprocess
-    import sys
-
-    if os.environ.get("NCW_SDF_INFER8") is not None:
-        pytest.skip("already inside a variant run")
-    env = dict(os.environ, NCW_SDF_INFER8=variant, NCW_PP_NB=nb)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "not subprocess"],
-                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

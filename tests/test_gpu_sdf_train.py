@@ -83,23 +83,6 @@ def test_sdf_train_f16(W, n_layers, skip):
     assert worst < (0.03 if W == 64 else 8e-3)
 
 
-def test_weights_through_lds_forward_kernel_in_a_subprocess():
-    """W = 256 16-bit defaults to the weights-stationary sdf_fwd (csrc/ncw_sdf8.hip) and W = 512 16-bit to the
-    weights-from-L2 kernels (csrc/ncw_sdf16.hip); the weights-through-LDS kernels (NCW_SDF_FWD8=0 / NCW_SDF16=0, the only
-    ones for f32 and other widths) must stay correct at those shapes too: the tests of this
-    file are re-run in a subprocess with the switch set (it is read once per process)."""
-    import os
-    import subprocess
-    import sys
-
-    if os.environ.get("NCW_SDF_FWD8") is not None:
-        pytest.skip("already inside a variant run")
-    env = dict(os.environ, NCW_SDF_FWD8="0", NCW_SDF16="0")  # NCW_SDF16=0: the generic kernels at W = 512 as well
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "not subprocess"],
-                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_w512_four_tile_kernels_in_a_subprocess():
     """csrc/ncw_sdf16.hip picks T = 4 tiles per workgroup only for launches of >= 768 tiles (24,576 points); the W = 512
     cases of this file and of test_gpu_sdf.py are small, so they are re-run with NCW_SDF16_T=4 (read once per process)."""
