@@ -520,12 +520,23 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_bwd16_kernel(NcwSdfNet net
     }
 }
 
-// T = 4 (128 points per workgroup: half the weight traffic per point) once that still gives every CU a workgroup,
-// T = 2 below that (the sampler's small launches, small batches)
+// Tiles per workgroup.  A workgroup costs about (12 + 10.7 T) k cycles per layer (the weight stream from L2 is paid once per
+// workgroup whatever T is, the MFMAs per tile: fitted from T = 2 vs 4) and the launch runs
+// ceil(workgroups / 256 CUs) rounds: T is chosen to minimise rounds x cost.  At the reference's batch (2048 rays x 24
+// samples = 1536 tiles, scripts/train.sh:16-19) T = 3 gives 512 workgroups = exactly two rounds (T = 4: 384 = 1.5 rounds,
+// i.e. two), at 1024 rays 256 workgroups = one round; long launches (the grid sweep) take T = 4.
+// NCW_SDF16_T = 2 | 3 | 4 forces a value (tests: the small cases never reach T = 3 / 4 on their own).
 int s16_tiles_per_wg(int64_t tiles) {
     static const int forced = getenv("NCW_SDF16_T") ? atoi(getenv("NCW_SDF16_T")) : 0;
-    if (forced == 2 || forced == 4) return forced;
-    return tiles >= 4 * 192 ? 4 : 2;
+    if (forced >= 2 && forced <= 4) return forced;
+    int best = 2;
+    double best_cost = 1e30;
+    for (int T = 2; T <= 4; ++T) {
+        const int64_t wgs = (tiles + T - 1) / T;
+        const double cost = (double)((wgs + 255) / 256) * (12.0 + 10.7 * T);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = T; }
+    }
+    return best;
 }
 
 }  // namespace
@@ -533,8 +544,11 @@ int s16_tiles_per_wg(int64_t tiles) {
 #define S16_LAUNCH(KERNEL, ...)                                                                                              \
     do {                                                                                                                     \
         const int64_t tiles = (n + 31) / 32;                                                                                 \
-        if (s16_tiles_per_wg(tiles) == 4)                                                                                    \
+        const int T = s16_tiles_per_wg(tiles);                                                                               \
+        if (T == 4)                                                                                                          \
             hipLaunchKernelGGL(KERNEL<4>, dim3((unsigned)((tiles + 3) / 4)), dim3(64 * S16_WAVES), 0, st, __VA_ARGS__);      \
+        else if (T == 3)                                                                                                     \
+            hipLaunchKernelGGL(KERNEL<3>, dim3((unsigned)((tiles + 2) / 3)), dim3(64 * S16_WAVES), 0, st, __VA_ARGS__);      \
         else                                                                                                                 \
             hipLaunchKernelGGL(KERNEL<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(64 * S16_WAVES), 0, st, __VA_ARGS__);      \
         NCW_CHECK_LAUNCH();                                                                                                  \

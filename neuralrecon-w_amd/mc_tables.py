@@ -9,8 +9,10 @@ tables here resolve every ambiguous FACE the same way from the face's own corner
 level -- are kept apart), so neighbouring cubes agree on every shared face and the mesh is watertight by construction.
 
 Conventions: corner k has offset (k & 1, (k >> 1) & 1, (k >> 2) & 1) = (+x, +y, +z); configuration bit k is set iff corner k
-is inside (value < level); edge e joins EDGES[e] = (a, b), a < b; triangles are wound so that the normal points towards
-increasing values (outwards for a signed distance).
+is inside (value < level); edge e joins EDGES[e] = (a, b), a < b (edges sorted by that pair); triangles are wound so that the
+normal points towards increasing values (outwards for a signed distance); a polygon of more than three cut edges is a fan
+around its cut edge with the smallest corner pair.  (Like every table-driven marching cubes, a fan diagonal may lie inside
+an ambiguous face when both arcs of that face belong to one polygon: rare doubled edges on noise, none on smooth fields.)
 """
 import numpy as np
 
@@ -20,6 +22,7 @@ _EDGE_ID = {e: i for i, e in enumerate(EDGES)}
 
 
 def _faces():
+    """[(ring of 4 corners in cyclic order, outward normal)] of the 6 cube faces."""
     out = []
     for d in range(3):
         u, v = [x for x in range(3) if x != d]
@@ -29,7 +32,9 @@ def _faces():
                 c = [0, 0, 0]
                 c[d], c[u], c[v] = s, cu, cv
                 ring.append(c[0] | (c[1] << 1) | (c[2] << 2))
-            out.append(ring)
+            n = np.zeros(3)
+            n[d] = 1.0 if s else -1.0
+            out.append((ring, n))
     return out
 
 
@@ -40,54 +45,60 @@ def _edge(a, b):
     return _EDGE_ID[(min(a, b), max(a, b))]
 
 
+def _pos(k):
+    return np.array(CORNERS[k], dtype=float)
+
+
+def _mid(e):
+    return (_pos(EDGES[e][0]) + _pos(EDGES[e][1])) / 2
+
+
 def case_triangles(cfg):
-    """-> list of (e0, e1, e2) for configuration cfg (bit k: corner k inside)."""
+    """-> list of (e0, e1, e2) for configuration cfg (bit k: corner k inside).
+
+    The iso-polygons are traced over the cube's faces as DIRECTED arcs: on a face with outward normal n, the segment
+    between two cut edges separates an inside side from an outside side (s = in-face direction inside -> outside); with
+    the surface normal towards the outside (increasing values) and the polygon's interior inside the cube, the boundary
+    runs along s x n.  Every cut edge then has exactly one outgoing and one incoming arc, and the loops come out
+    consistently oriented across neighbouring cubes (a shared face sees the opposite n, hence the opposite direction)."""
     inside = [(cfg >> k) & 1 for k in range(8)]
-    links = {}
+    succ = {}
 
-    def link(e, f):
-        links.setdefault(e, []).append(f)
-        links.setdefault(f, []).append(e)
+    def arc(e, f, s_dir, n):
+        if float(np.dot(_mid(f) - _mid(e), np.cross(s_dir, n))) > 0:
+            assert e not in succ
+            succ[e] = f
+        else:
+            assert f not in succ
+            succ[f] = e
 
-    for ring in FACES:
+    for ring, n in FACES:
         cut = [_edge(ring[i], ring[(i + 1) % 4]) for i in range(4) if inside[ring[i]] != inside[ring[(i + 1) % 4]]]
         if len(cut) == 2:
-            link(cut[0], cut[1])
-        elif len(cut) == 4:  # ambiguous face: keep the two inside corners apart
+            ins = [k for k in ring if inside[k]]
+            out = [k for k in ring if not inside[k]]
+            s_dir = sum(_pos(k) for k in out) / len(out) - sum(_pos(k) for k in ins) / len(ins)
+            arc(cut[0], cut[1], s_dir, n)
+        elif len(cut) == 4:  # ambiguous face: keep the two inside corners apart (cut each one off on its own)
+            centre = sum(_pos(k) for k in ring) / 4
             for i in range(4):
                 if inside[ring[i]]:
-                    link(_edge(ring[i - 1], ring[i]), _edge(ring[i], ring[(i + 1) % 4]))
-    assert all(len(v) == 2 for v in links.values())
+                    arc(_edge(ring[i - 1], ring[i]), _edge(ring[i], ring[(i + 1) % 4]), centre - _pos(ring[i]), n)
     tris, seen = [], set()
-    mid = lambda e: (np.array(CORNERS[EDGES[e][0]], float) + np.array(CORNERS[EDGES[e][1]], float)) / 2  # noqa: E731
-    for start in sorted(links):
+    for start in sorted(succ):
         if start in seen:
             continue
-        loop, prev, cur = [start], None, start
-        seen.add(start)
-        while True:
-            nxt = [f for f in links[cur] if f != prev]
-            nxt = nxt[0] if nxt else links[cur][0]
-            if links[cur][0] == links[cur][1]:
-                nxt = links[cur][0]
-            if nxt == start:
-                break
-            loop.append(nxt)
-            seen.add(nxt)
-            prev, cur = cur, nxt
-        assert len(loop) >= 3
-        # orientation: Newell normal of the loop (edge mid-points) against the inside -> outside direction of its edges
-        P = [mid(e) for e in loop]
-        n = sum(np.cross(P[i], P[(i + 1) % len(P)]) for i in range(len(P)))
-        g = np.zeros(3)
-        for e in loop:
-            a, b = EDGES[e]
-            ca, cb = np.array(CORNERS[a], float), np.array(CORNERS[b], float)
-            g += (cb - ca) if inside[a] else (ca - cb)
-        if float(np.dot(n, g)) < 0:
-            loop = loop[::-1]
+        loop, cur = [], start
+        while cur not in seen:
+            seen.add(cur)
+            loop.append(cur)
+            cur = succ[cur]
+        assert cur == start and len(loop) >= 3
+        k = loop.index(min(loop))  # convention: the fan's apex is the loop's lowest edge index (= smallest corner pair)
+        loop = loop[k:] + loop[:k]
         for i in range(1, len(loop) - 1):
             tris.append((loop[0], loop[i], loop[i + 1]))
+    assert len(seen) == sum(1 for a, b in EDGES if inside[a] != inside[b])
     return tris
 
 

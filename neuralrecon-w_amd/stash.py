@@ -14,8 +14,9 @@ class StashArena:
         self.prec = prec
         self.n = int(n_points)
         self.tiles = (self.n + 31) // 32
-        # kernels run whole workgroups (<= 8 waves = 8 tiles): pad so surplus waves store into padding
-        self.tiles_alloc = (self.tiles + 7) // 8 * 8
+        # kernels run whole workgroups (8 waves = 8 tiles; the W = 512 kernels 2, 3 or 4 tiles): pad to a multiple of 24
+        # so that surplus waves / tiles store into padding
+        self.tiles_alloc = (self.tiles + 23) // 24 * 24
         self.esize = 4 if prec == L.PREC_F32 else 2
         self._off = []
         self._bytes = 0

@@ -51,48 +51,53 @@ def edge_vertices(sdf, level=0.0, mask=None):
 
 def _cube_polygons(val, level):
     """Iso-polygons of one cube from its 8 corner values (corner k at offset (k&1, k>>1&1, k>>2&1)): lists of cut edges
-    (a, b) with a inside (value < level), b outside, in cyclic order, wound with the normal towards increasing values."""
+    (a, b) with a inside (value < level), b outside, in cyclic order, wound with the normal towards increasing values.
+    Tracing rule (stated from the geometry, not from a table): on the face with outward normal n the arc between two cut
+    edges runs along s x n, s = in-face direction from the arc's inside side to its outside side; on a face whose diagonal
+    corners share a sign each inside corner is cut off on its own."""
     ins = [v < level for v in val]
     off = [np.array([k & 1, (k >> 1) & 1, (k >> 2) & 1], dtype=np.float64) for k in range(8)]
-    nbr = {}
+    nxt = {}
 
     def cut(a, b):  # canonical name of the cut edge between adjacent corners a, b
         return (a, b) if ins[a] else (b, a)
 
-    def join(e, f):
-        nbr.setdefault(e, []).append(f)
-        nbr.setdefault(f, []).append(e)
+    def where(e):
+        return (off[e[0]] + off[e[1]]) / 2
 
     for axis in range(3):
         u, v = [d for d in range(3) if d != axis]
         for side in (0, 1):
+            n = np.zeros(3)
+            n[axis] = 2 * side - 1
             ring = [side << axis | (cu << u) | (cv << v) for cu, cv in ((0, 0), (1, 0), (1, 1), (0, 1))]
             crossing = [i for i in range(4) if ins[ring[i]] != ins[ring[(i + 1) % 4]]]
+            arcs = []
             if len(crossing) == 2:
                 i, j = crossing
-                join(cut(ring[i], ring[(i + 1) % 4]), cut(ring[j], ring[(j + 1) % 4]))
-            elif len(crossing) == 4:  # diagonal corners share a sign: cut off each inside corner on its own
+                s = np.mean([off[k] for k in ring if not ins[k]], axis=0) - np.mean([off[k] for k in ring if ins[k]], axis=0)
+                arcs.append((cut(ring[i], ring[(i + 1) % 4]), cut(ring[j], ring[(j + 1) % 4]), s))
+            elif len(crossing) == 4:
+                c = np.mean([off[k] for k in ring], axis=0)
                 for i in range(4):
                     if ins[ring[i]]:
-                        join(cut(ring[i], ring[i - 1]), cut(ring[i], ring[(i + 1) % 4]))
+                        arcs.append((cut(ring[i], ring[i - 1]), cut(ring[i], ring[(i + 1) % 4]), c - off[ring[i]]))
+            for e, f, s in arcs:
+                if float(np.dot(where(f) - where(e), np.cross(s, n))) > 0:
+                    nxt[e] = f
+                else:
+                    nxt[f] = e
     polys, done = [], set()
-    for start in sorted(nbr):
+    for start in sorted(nxt):
         if start in done:
             continue
-        loop, prev, cur = [start], None, start
-        done.add(start)
-        while True:
-            a, b = nbr[cur]
-            nxt = b if a == prev else a
-            if nxt == start:
-                break
-            loop.append(nxt)
-            done.add(nxt)
-            prev, cur = cur, nxt
-        mid = [(off[a] + off[b]) / 2 for a, b in loop]
-        n = sum(np.cross(mid[i], mid[(i + 1) % len(mid)]) for i in range(len(mid)))
-        g = sum(off[b] - off[a] for a, b in loop)
-        polys.append(loop if float(np.dot(n, g)) >= 0 else loop[::-1])
+        loop, cur = [], start
+        while cur not in done:
+            done.add(cur)
+            loop.append(cur)
+            cur = nxt[cur]
+        k = min(range(len(loop)), key=lambda i: tuple(sorted(loop[i])))  # fan apex: the cut edge with the smallest corner pair
+        polys.append(loop[k:] + loop[:k])
     return polys
 
 

@@ -83,16 +83,18 @@ def test_sdf_train_f16(W, n_layers, skip):
     assert worst < (0.03 if W == 64 else 8e-3)
 
 
-def test_w512_four_tile_kernels_in_a_subprocess():
-    """csrc/ncw_sdf16.hip picks T = 4 tiles per workgroup only for launches of >= 768 tiles (24,576 points); the W = 512
-    cases of this file and of test_gpu_sdf.py are small, so they are re-run with NCW_SDF16_T=4 (read once per process)."""
+@pytest.mark.parametrize("T", ["3", "4"])
+def test_w512_three_and_four_tile_kernels_in_a_subprocess(T):
+    """csrc/ncw_sdf16.hip picks the tiles per workgroup T in {2, 3, 4} from the launch size (rounds x cost model); the
+    W = 512 cases of this file and of test_gpu_sdf.py are small and run T = 2, so they are re-run with NCW_SDF16_T = 3 and 4
+    (read once per process)."""
     import os
     import subprocess
     import sys
 
     if os.environ.get("NCW_SDF16_T") is not None:
         pytest.skip("already inside a variant run")
-    env = dict(os.environ, NCW_SDF16_T="4")
+    env = dict(os.environ, NCW_SDF16_T=T)
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(here, "test_gpu_sdf.py"), "-q", "-x",
                         "-k", "512 and not subprocess"], env=env, capture_output=True, text=True, cwd=os.path.dirname(here))

@@ -68,6 +68,7 @@ def test_generated_case_tables_match_the_restatement_on_all_256_configurations()
             for i in range(1, len(ks) - 1):
                 want.add(rot((ks[0], ks[i], ks[i + 1])))
         got = {rot(tuple(E[tri[cfg, 3 * t + i]] for i in range(3))) for t in range(int(ntri[cfg]))}
+        assert sorted(got) == sorted(want), cfg  # same polygons, same fan apex (the cut edge with the smallest corner pair)
         cut = {e for e in E if ((cfg >> e[0]) & 1) != ((cfg >> e[1]) & 1)}
         assert {e for t in got for e in t} == cut, cfg
         # the same surface; fans may start at a different polygon vertex, so compare as polygon edge sets instead
