@@ -598,7 +598,7 @@ def main():
         alt = {"dtype": alt_name, "value": R * S / d_a, "unit": "ray-samples/s", "ms_per_step": d_a * 1e3, "steps": args.steps}
         del train_a, step_a
         torch.cuda.empty_cache()
-        if args.prec == "f16" and W_SDF == 256:  # what the split-precision SDF value path costs: the same step without it
+        if args.prec == "f16":  # what the split-precision SDF value path costs: the same step without it
             step_p, train_p, _ = make_step(prec, sdf_split=False)
             for i in range(5):
                 step_p(i)
@@ -673,7 +673,7 @@ def main():
         # ---- measured error of the program that was timed: the GPU render + loss of the oracle leg's 256 rays (same
         # batch, same initial weights, deterministic sampling) in the TIMED dtype, against the oracle -- at the initial
         # operating point (variance 0.3, inv_s 20) and where NeuS trains (variance 0.6: inv_s = exp(6) = 403)
-        if ref32 is not None and args.config == "headline":
+        if ref32 is not None and args.config in ("headline", "shipped"):
             try:
                 parity_obj = {"dtype": args.prec, "rays": 256, "measure": "max|gpu - oracle| / max|oracle| (loss: absolute)",
                               "oracle": "fp32 torch-CPU oracle of the cpu_baseline leg (inv_s 20); fp64 oracle at inv_s 403"}

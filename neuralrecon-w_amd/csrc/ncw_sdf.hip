@@ -421,8 +421,11 @@ static bool sdf16_on(const NcwSdfNet* net, int prec) {
 int ncw_sdf_inferS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);
 int ncw_sdf_fwdS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
                             const NcwSdfStash& stash, hipStream_t st);
+int ncw_sdf_inferS16_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);  // ncw_sdf16.hip
+int ncw_sdf_fwdS16_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
+                              const NcwSdfStash& stash, hipStream_t st);
 static bool sdf_split_on(const NcwSdfNet* net, int prec) {
-    if (!(net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3 && net->n_layers <= NCW_MAX_LAYERS)) return false;
+    if (!((net->rb == 8 || net->rb == 16) && prec == NCW_PREC_BF16 && net->n_layers >= 3 && net->n_layers <= NCW_MAX_LAYERS)) return false;
     for (int l = 0; l < net->n_layers; ++l)
         if (net->w_lo[l] == nullptr) return false;
     return true;
@@ -435,7 +438,8 @@ static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, i
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
 #ifdef NCW_HALF_F16
-    if (sdf_split_on(net, prec)) return ncw_sdf_inferS_launch_f16(net, src, n, sdf, st);
+    if (sdf_split_on(net, prec))
+        return net->rb == 16 ? ncw_sdf_inferS16_launch_f16(net, src, n, sdf, st) : ncw_sdf_inferS_launch_f16(net, src, n, sdf, st);
 #endif
     if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_infer16_launch)(net, src, n, sdf, st);
     // W = 256, 16-bit: the fine-interleaved kernel of ncw_pp.hip (0.165 ms per 131,072 points; round 2's burst kernel 0.198,
@@ -487,7 +491,9 @@ extern "C" int NCW_FN(ncw_sdf_fwd)(const NcwSdfNet* net, int prec, const NcwPoin
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
 #ifdef NCW_HALF_F16
-    if (sdf_split_on(net, prec)) return ncw_sdf_fwdS_launch_f16(net, *pts, n, sdf, grad, *stash, st);
+    if (sdf_split_on(net, prec))
+        return net->rb == 16 ? ncw_sdf_fwdS16_launch_f16(net, *pts, n, sdf, grad, *stash, st)
+                             : ncw_sdf_fwdS_launch_f16(net, *pts, n, sdf, grad, *stash, st);
 #endif
     // W = 256, 16-bit: the weights-stationary kernel of ncw_sdf8.hip (0.57 vs 0.67 ms per 131,072 points for the
     // weights-through-LDS kernel below, which serves fp32 and the other widths)

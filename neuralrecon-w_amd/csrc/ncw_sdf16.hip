@@ -48,7 +48,8 @@ NCW_DEV void s16_prefetch(S16W& r, const void* w, int rb_stride, int wave, int l
 }
 
 // acc[j][t] += W[block wave + 8 j][.] . in[tile t][.] over NU k-units; r holds units 0 .. D-1 on entry and is free on exit
-template <int T, int NU>
+// (BS = 2: `in` is a split-precision buffer [tile][unit][hi | lo]; the hi fragments are read)
+template <int T, int NU, int BS = 1>
 NCW_DEV void s16_mma(f32x16 (&acc)[2][T], S16W& r, const void* w, int rb_stride, int wave, const s16_lfrag* in, int lane) {
 #pragma unroll
     for (int q = 0; q < NU; ++q) {
@@ -59,7 +60,7 @@ NCW_DEV void s16_mma(f32x16 (&acc)[2][T], S16W& r, const void* w, int rb_stride,
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const bf16x8 b = in[(t * S16_KU + q) * 64 + lane];
+            const bf16x8 b = in[((t * S16_KU + q) * BS) * 64 + lane];
             acc[0][t] = NCW_MFMA_H(a0, b, acc[0][t], 0, 0, 0);
             acc[1][t] = NCW_MFMA_H(a1, b, acc[1][t], 0, 0, 0);
         }
@@ -81,11 +82,11 @@ NCW_DEV void s16_mma_gamma(f32x16 (&acc)[2][T], const void* w, int wave, const s
 }
 
 // one output block of one tile (gamma columns of a transposed matrix, the sdf row): acc += W[block ob][.] . in[tile t][.]
-template <int NU>
+template <int NU, int BS = 1>
 NCW_DEV void s16_mma1(f32x16& acc, const void* w, int rb_stride, int ob, const s16_lfrag* in, int t, int lane) {
 #pragma unroll
     for (int q = 0; q < NU; ++q)
-        acc = NCW_MFMA_H(s16_ld(w, rb_stride, ob, q, lane), in[(t * S16_KU + q) * 64 + lane], acc, 0, 0, 0);
+        acc = NCW_MFMA_H(s16_ld(w, rb_stride, ob, q, lane), in[((t * S16_KU + q) * BS) * 64 + lane], acc, 0, 0, 0);
 }
 
 NCW_DEV void s16_store_units(s16_lfrag* buf, int t, int ob, const f32x16& v, int lane) {
@@ -204,91 +205,34 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_infer16_kernel(NcwSdfNet n
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// sdf_fwd: forward chain with the activation stash, feature layer, sdf row, then the analytic adjoint pass
-// t_{l-1} = (W_l^T t_l) * phi'(z_{l-1}) with the t_l stash and grad = J_gamma^T g_gamma (sdf_fwd_kernel, ncw_sdf.hip).
-// The gamma output blocks (16, 17) of the transposed skip layer and the two blocks of W_0^T are 2 blocks x T tiles
-// jobs: wave w < 2 T takes block (w & 1) of tile (w >> 1) and keeps that g_gamma block to the end (2 T <= 8).
-// ------------------------------------------------------------------------------------------------
-template <int T>
-__global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
-                                                                  float* __restrict__ sdf, float* __restrict__ grad,
-                                                                  NcwSdfStash st) {
+// The part of sdf_fwd after the forward chain: feature rows, (sdf row,) the analytic adjoint sweep with the t_l stash and
+// grad = J_gamma^T g_gamma.  On entry h_{L-1} of the T tiles is in abuf (BS = 1: plain fragments; BS = 2: the split chain's
+// [tile][unit][hi | lo] buffer, whose hi fragments are read) and r holds the first units of w_feat; abuf is then reused in the
+// plain layout.  SDF_ROW = false: the caller's (split-precision) chain has written sdf already.
+template <int T, int BS, bool SDF_ROW>
+NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n, float* __restrict__ sdf, float* __restrict__ grad,
+                          const NcwSdfStash& st, s16_lfrag* abuf, s16_lfrag* gbuf, S16W& r, f32x16 (&acc)[2][T], int lane, int wave,
+                          int64_t tile0) {
     typedef ncw_h16 SE;
-    static_assert(2 * T <= S16_WAVES, "one gamma job per wave");
-    S16_LDS_DECL();
+    const int L = net.n_layers;
     const int jb = wave & 1, jt = wave >> 1;
     const bool gjob = wave < 2 * T;
-    if (wave < T) {
-        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
-        if (p >= n) p = n - 1;
-        float xs[3];
-        load_point(src, p, xs, ray);
-        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
-        CVec<2> gam;
-        freq_encode<2, 3, 6, true>(gam, xs, lane);
-        stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
-        Act<PrecBF16, 2> ga;
-        to_act(ga, gam);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) gbuf[(wave * 4 + q) * 64 + lane] = ga.f[q];
-    }
-    S16W r;
-    f32x16 acc[2][T];
-    {   // layer 0
-        bf16x8 w0[2][3];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) w0[j][q] = s16_ld(net.w[0], 16, wave + 8 * j, q, lane);
-        s16_prefetch(r, L - 1 > 1 ? net.w[1] : net.w_feat, 16, wave, lane);
-        const f32x16 b0 = s16_bias(net.b[0], wave, lane), b1 = s16_bias(net.b[0], wave + 8, lane);
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x16 a = j ? b1 : b0;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) a = NCW_MFMA_H(w0[j][q], gbuf[(t * 4 + q) * 64 + lane], a, 0, 0, 0);
-                const f32x16 y = s16_softplus(a);
-                stash_store_block((SE*)st.h[1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
-                s16_store_units(abuf, t, wave + 8 * j, y, lane);
-            }
-    }
-    for (int l = 1; l < L - 1; ++l) {  // r = first units of w[l]
-        const f32x16 b0 = s16_bias(net.b[l], wave, lane), b1 = s16_bias(net.b[l], wave + 8, lane);
-        __syncthreads();
-        s16_fill<T>(acc, b0, b1);
-        s16_mma<T, S16_KU>(acc, r, net.w[l], 16, wave, abuf, lane);
-        s16_prefetch(r, l + 1 < L - 1 ? net.w[l + 1] : net.w_feat, 16, wave, lane);  // next: hidden or feature layer
-        if (l == net.skip_layer) s16_mma_gamma<T>(acc, net.w[l], wave, gbuf, lane);
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x16 y = s16_softplus(acc[j][t]);
-                stash_store_block((SE*)st.h[l + 1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
-                s16_store_units(abuf, t, wave + 8 * j, y, lane);
-            }
-    }
     // ---- feature layer (r = first units of w_feat) and sdf row; then the adjoint's first vector ------------------
     {
         const bf16x8 wt1_0 = s16_ld(net.wt[L - 1], 16, wave, 0, lane), wt1_1 = s16_ld(net.wt[L - 1], 16, wave + 8, 0, lane);
         const f32x16 b0 = s16_bias(net.b_feat, wave, lane), b1 = s16_bias(net.b_feat, wave + 8, lane);
         __syncthreads();  // h_{L-1} complete in abuf
         s16_fill<T>(acc, b0, b1);
-        s16_mma<T, S16_KU>(acc, r, net.w_feat, 16, wave, abuf, lane);
+        s16_mma<T, S16_KU, BS>(acc, r, net.w_feat, 16, wave, abuf, lane);
         if (L - 2 >= 1) s16_prefetch(r, net.wt[L - 2], (L - 2 == net.skip_layer) ? 18 : 16, wave, lane);
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int j = 0; j < 2; ++j) stash_store_block((SE*)st.feat, (size_t)(tile0 + t), 16, wave + 8 * j, acc[j][t], lane);
-        if (wave < T) {
+        if (SDF_ROW && wave < T) {
             CVec<1> o;
             load_bias(o, net.b[L - 1], lane);
-            s16_mma1<S16_KU>(o.v[0], net.w[L - 1], 1, 0, abuf, wave, lane);
+            s16_mma1<S16_KU, BS>(o.v[0], net.w[L - 1], 1, 0, abuf, wave, lane);
             const int64_t p = (tile0 + wave) * 32 + (lane & 31);
             if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
         }
@@ -369,6 +313,76 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net
         grad[p * 3 + 1] = ny + part[(jt * 32 + lane) * 3 + 1];
         grad[p * 3 + 2] = nz + part[(jt * 32 + lane) * 3 + 2];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sdf_fwd: forward chain with the activation stash, feature layer, sdf row, then the analytic adjoint pass
+// t_{l-1} = (W_l^T t_l) * phi'(z_{l-1}) with the t_l stash and grad = J_gamma^T g_gamma (sdf_fwd_kernel, ncw_sdf.hip).
+// The gamma output blocks (16, 17) of the transposed skip layer and the two blocks of W_0^T are 2 blocks x T tiles
+// jobs: wave w < 2 T takes block (w & 1) of tile (w >> 1) and keeps that g_gamma block to the end (2 T <= 8).
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                  float* __restrict__ sdf, float* __restrict__ grad,
+                                                                  NcwSdfStash st) {
+    typedef ncw_h16 SE;
+    static_assert(2 * T <= S16_WAVES, "one gamma job per wave");
+    S16_LDS_DECL();
+    if (wave < T) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        if (p >= n) p = n - 1;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+        CVec<2> gam;
+        freq_encode<2, 3, 6, true>(gam, xs, lane);
+        stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        Act<PrecBF16, 2> ga;
+        to_act(ga, gam);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gbuf[(wave * 4 + q) * 64 + lane] = ga.f[q];
+    }
+    S16W r;
+    f32x16 acc[2][T];
+    {   // layer 0
+        bf16x8 w0[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) w0[j][q] = s16_ld(net.w[0], 16, wave + 8 * j, q, lane);
+        s16_prefetch(r, L - 1 > 1 ? net.w[1] : net.w_feat, 16, wave, lane);
+        const f32x16 b0 = s16_bias(net.b[0], wave, lane), b1 = s16_bias(net.b[0], wave + 8, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 a = j ? b1 : b0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a = NCW_MFMA_H(w0[j][q], gbuf[(t * 4 + q) * 64 + lane], a, 0, 0, 0);
+                const f32x16 y = s16_softplus(a);
+                stash_store_block((SE*)st.h[1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
+                s16_store_units(abuf, t, wave + 8 * j, y, lane);
+            }
+    }
+    for (int l = 1; l < L - 1; ++l) {  // r = first units of w[l]
+        const f32x16 b0 = s16_bias(net.b[l], wave, lane), b1 = s16_bias(net.b[l], wave + 8, lane);
+        __syncthreads();
+        s16_fill<T>(acc, b0, b1);
+        s16_mma<T, S16_KU>(acc, r, net.w[l], 16, wave, abuf, lane);
+        s16_prefetch(r, l + 1 < L - 1 ? net.w[l + 1] : net.w_feat, 16, wave, lane);  // next: hidden or feature layer
+        if (l == net.skip_layer) s16_mma_gamma<T>(acc, net.w[l], wave, gbuf, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 y = s16_softplus(acc[j][t]);
+                stash_store_block((SE*)st.h[l + 1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
+                s16_store_units(abuf, t, wave + 8 * j, y, lane);
+            }
+    }
+    s16_fwd_tail<T, 1, true>(net, src, n, sdf, grad, st, abuf, gbuf, r, acc, lane, wave, tile0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -520,6 +534,189 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_bwd16_kernel(NcwSdfNet net
     }
 }
 
+#ifdef NCW_HALF_F16
+// ------------------------------------------------------------------------------------------------
+// Split-precision VALUE path at W = 512 (fp16 build; DESIGN.md 3.1b, the W = 256 counterpart is ncw_split.hip): the value
+// chain gamma -> Softplus layers -> sdf row with BOTH operands as fp16 hi + lo pairs, W h ~= W_hi h_hi + W_lo h_hi + W_hi h_lo
+// (three MFMAs, f32 accumulate), in the streamed-weights structure of this file: T = 2 tiles per workgroup (the activation
+// buffer holds hi and lo: [tile][32 units][hi | lo] = 128 KiB), wave w owns output blocks w and w + 8, per k-unit four A
+// fragments (hi, lo of both blocks) come through a register ring S16_D units ahead.  Twice the weight stream of the plain
+// kernels (hi + lo) for three times the MFMAs: 1 MiB per layer per workgroup = 16 k cycles of the CU's L2 port against 24.6 k
+// MFMA cycles.  Feature rows, adjoint sweep and backward stay plain fp16 (s16_fwd_tail reads the hi fragments).
+// ------------------------------------------------------------------------------------------------
+constexpr int S16S_T = 2;
+struct S16WS { bf16x8 f[S16_D][4]; };  // ring: {block w hi, block w lo, block w+8 hi, block w+8 lo} of units q .. q + D - 1
+
+NCW_DEV void s16s_ld_unit(bf16x8 (&f)[4], const void* w, const void* wlo, int rb_stride, int wave, int u, int lane) {
+    f[0] = s16_ld(w, rb_stride, wave, u, lane);
+    f[1] = s16_ld(wlo, rb_stride, wave, u, lane);
+    f[2] = s16_ld(w, rb_stride, wave + 8, u, lane);
+    f[3] = s16_ld(wlo, rb_stride, wave + 8, u, lane);
+}
+
+NCW_DEV void s16s_prefetch(S16WS& r, const void* w, const void* wlo, int rb_stride, int wave, int lane) {
+#pragma unroll
+    for (int d = 0; d < S16_D; ++d) s16s_ld_unit(r.f[d], w, wlo, rb_stride, wave, d, lane);
+}
+
+NCW_DEV void s16s_split8(const f32x16& v, int t, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[8 * t + e];
+        const ncw_h16 h = (ncw_h16)x;
+        hi[e] = h;
+        lo[e] = (ncw_h16)(x - (float)h);
+    }
+}
+
+// six MFMAs per (unit, tile): blocks w and w + 8, {hi.hi, lo.hi, hi.lo}; consecutive MFMAs go to different accumulators
+NCW_DEV void s16s_unit(f32x16 (&acc)[2][S16S_T], const bf16x8 (&a)[4], const s16_lfrag* in, int upt, int u, int lane) {
+    bf16x8 bh[S16S_T], bl[S16S_T];
+#pragma unroll
+    for (int t = 0; t < S16S_T; ++t) {
+        bh[t] = in[((t * upt + u) * 2) * 64 + lane];
+        bl[t] = in[((t * upt + u) * 2 + 1) * 64 + lane];
+    }
+#pragma unroll
+    for (int t = 0; t < S16S_T; ++t) { acc[0][t] = NCW_MFMA_H(a[0], bh[t], acc[0][t], 0, 0, 0); acc[1][t] = NCW_MFMA_H(a[2], bh[t], acc[1][t], 0, 0, 0); }
+#pragma unroll
+    for (int t = 0; t < S16S_T; ++t) { acc[0][t] = NCW_MFMA_H(a[1], bh[t], acc[0][t], 0, 0, 0); acc[1][t] = NCW_MFMA_H(a[3], bh[t], acc[1][t], 0, 0, 0); }
+#pragma unroll
+    for (int t = 0; t < S16S_T; ++t) { acc[0][t] = NCW_MFMA_H(a[0], bl[t], acc[0][t], 0, 0, 0); acc[1][t] = NCW_MFMA_H(a[2], bl[t], acc[1][t], 0, 0, 0); }
+}
+
+NCW_DEV void s16s_mma(f32x16 (&acc)[2][S16S_T], S16WS& r, const void* w, const void* wlo, int wave, const s16_lfrag* in, int lane) {
+#pragma unroll
+    for (int q = 0; q < S16_KU; ++q) {
+        bf16x8 a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = r.f[q % S16_D][k];
+        if (q + S16_D < S16_KU) s16s_ld_unit(r.f[q % S16_D], w, wlo, 16, wave, q + S16_D, lane);
+        s16s_unit(acc, a, in, S16_KU, q, lane);
+    }
+}
+
+// value chain: leaves h_{L-1} (hi | lo) of the 2 tiles in sbuf, the first units of w_feat are NOT prefetched (the caller's
+// plain ring does that).  STASH: gamma, h_1 .. h_{L-1} (fp16 roundings = the hi parts).
+template <bool STASH>
+NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t n, int64_t tile0, s16_lfrag* sbuf, s16_lfrag* gsbuf,
+                              int lane, int wave, float* __restrict__ sdf, const NcwSdfStash& st) {
+    typedef ncw_h16 SE;
+    constexpr int T = S16S_T;
+    const int L = net.n_layers;
+    if (wave < T) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        if (p >= n) p = n - 1;
+        float xs[3];
+        load_point(src, p, xs, ray);
+        xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+        CVec<2> gam;
+        freq_encode<2, 3, 6, false>(gam, xs, lane);  // sinf / cosf: the hardware v_sin / v_cos are not fp32-accurate
+        if (STASH) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            bf16x8 hi, lo;
+            s16s_split8(gam.v[q >> 1], q & 1, hi, lo);
+            gsbuf[((wave * 4 + q) * 2 + 0) * 64 + lane] = hi;
+            gsbuf[((wave * 4 + q) * 2 + 1) * 64 + lane] = lo;
+        }
+    }
+    S16WS r;
+    f32x16 acc[2][T];
+    auto epilogue = [&](int l_out) {  // Softplus, stash, hi / lo fragments of this wave's two blocks into sbuf (in place)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 y = s16_softplus(acc[j][t]);
+                const int ob = wave + 8 * j;
+                if (STASH) stash_store_block((SE*)st.h[l_out], (size_t)(tile0 + t), 16, ob, y, lane);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    bf16x8 hi, lo;
+                    s16s_split8(y, tt, hi, lo);
+                    sbuf[((t * S16_KU + 2 * ob + tt) * 2 + 0) * 64 + lane] = hi;
+                    sbuf[((t * S16_KU + 2 * ob + tt) * 2 + 1) * 64 + lane] = lo;
+                }
+            }
+    };
+    {   // layer 0: K = 39 (3 units of gamma)
+        bf16x8 w0[3][4];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s16s_ld_unit(w0[q], net.w[0], net.w_lo[0], 16, wave, q, lane);
+        if (L - 1 > 1) s16s_prefetch(r, net.w[1], net.w_lo[1], 16, wave, lane);
+        s16_fill<T>(acc, s16_bias(net.b[0], wave, lane), s16_bias(net.b[0], wave + 8, lane));
+        __syncthreads();  // gamma visible
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s16s_unit(acc, w0[q], gsbuf, 4, q, lane);
+        epilogue(1);
+    }
+    for (int l = 1; l < L - 1; ++l) {
+        const f32x16 b0 = s16_bias(net.b[l], wave, lane), b1 = s16_bias(net.b[l], wave + 8, lane);
+        __syncthreads();  // layer l-1 outputs of all waves are in sbuf
+        s16_fill<T>(acc, b0, b1);
+        s16s_mma(acc, r, net.w[l], net.w_lo[l], wave, sbuf, lane);
+        if (l + 1 < L - 1) s16s_prefetch(r, net.w[l + 1], net.w_lo[l + 1], 16, wave, lane);
+        if (l == net.skip_layer) {  // the gamma columns: units 32..34, loaded just in time (once per launch)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                bf16x8 g[4];
+                s16s_ld_unit(g, net.w[l], net.w_lo[l], 16, wave, S16_KU + q, lane);
+                s16s_unit(acc, g, gsbuf, 4, q, lane);
+            }
+        }
+        __syncthreads();  // every wave has read sbuf: overwrite in place
+        epilogue(l + 1);
+    }
+    __syncthreads();
+    if (wave < T) {  // sdf row (1 output block), tile = wave
+        CVec<1> o;
+        load_bias(o, net.b[L - 1], lane);
+#pragma unroll
+        for (int c = 0; c < S16_KU; c += 8) {
+            bf16x8 vh[8], vl[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { vh[q] = s16_ld(net.w[L - 1], 1, 0, c + q, lane); vl[q] = s16_ld(net.w_lo[L - 1], 1, 0, c + q, lane); }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bf16x8 bh = sbuf[((wave * S16_KU + c + q) * 2) * 64 + lane], bl = sbuf[((wave * S16_KU + c + q) * 2 + 1) * 64 + lane];
+                o.v[0] = NCW_MFMA_H(vh[q], bh, o.v[0], 0, 0, 0);
+                o.v[0] = NCW_MFMA_H(vl[q], bh, o.v[0], 0, 0, 0);
+                o.v[0] = NCW_MFMA_H(vh[q], bl, o.v[0], 0, 0, 0);
+            }
+        }
+        const int64_t p = (tile0 + wave) * 32 + (lane & 31);
+        if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+    }
+}
+
+#define S16S_LDS_DECL()                                                                                  \
+    __shared__ __attribute__((aligned(16))) char lds[S16S_T * S16_KU * 2 * 1024 + S16S_T * 4 * 2 * 1024]; \
+    s16_lfrag* const sbuf = (s16_lfrag*)(ncw_lchar*)lds;                                                 \
+    s16_lfrag* const gsbuf = sbuf + S16S_T * S16_KU * 2 * 64;                                            \
+    const int lane = ncw_lane();                                                                         \
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                           \
+    const int64_t tile0 = (int64_t)blockIdx.x * S16S_T
+
+__global__ __launch_bounds__(64 * S16_WAVES) void sdf_inferS16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                     float* __restrict__ sdf) {
+    S16S_LDS_DECL();
+    NcwSdfStash none = {};
+    s16s_value_chain<false>(net, src, n, tile0, sbuf, gsbuf, lane, wave, sdf, none);
+}
+
+__global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwdS16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                   float* __restrict__ sdf, float* __restrict__ grad, NcwSdfStash st) {
+    S16S_LDS_DECL();
+    s16s_value_chain<true>(net, src, n, tile0, sbuf, gsbuf, lane, wave, sdf, st);
+    // the plain tail: feature rows from the hi fragments (BS = 2), adjoint sweep in the plain layout over the same LDS
+    S16W r;
+    f32x16 acc[2][S16S_T];
+    s16_prefetch(r, net.w_feat, 16, wave, lane);
+    s16_fwd_tail<S16S_T, 2, false>(net, src, n, sdf, grad, st, sbuf, gsbuf, r, acc, lane, wave, tile0);
+}
+#endif  // NCW_HALF_F16
+
 // Tiles per workgroup.  A workgroup costs about (12 + 10.7 T) k cycles per layer (the weight stream from L2 is paid once per
 // workgroup whatever T is, the MFMAs per tile: fitted from T = 2 vs 4) and the launch runs
 // ceil(workgroups / 256 CUs) rounds: T is chosen to minimise rounds x cost.  At the reference's batch (2048 rays x 24
@@ -568,3 +765,23 @@ int NCW_FN(ncw_sdf_bwd16_launch)(const NcwSdfNet* net, const NcwPoints& src, int
                                  const NcwSdfStash& stash, hipStream_t st) {
     S16_LAUNCH(sdf_bwd16_kernel, *net, src, n, d_sdf, d_grad, stash);
 }
+
+#ifdef NCW_HALF_F16
+// fp16 build, W = 512, nets that carry residual matrices (NcwSdfNet.w_lo): the split-precision value path
+int ncw_sdf_inferS16_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(sdf_inferS16_kernel, dim3((unsigned)((tiles + S16S_T - 1) / S16S_T)), dim3(64 * S16_WAVES), 0, st, *net, src,
+                       n, sdf);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+int ncw_sdf_fwdS16_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
+                              const NcwSdfStash& stash, hipStream_t st) {
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(sdf_fwdS16_kernel, dim3((unsigned)((tiles + S16S_T - 1) / S16S_T)), dim3(64 * S16_WAVES), 0, st, *net, src, n,
+                       sdf, grad, stash);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+#endif

@@ -148,7 +148,7 @@ class SDFNetwork(nn.Module):
         return self.num_layers - 1
 
     def split_value(self, prec):
-        """Split-precision VALUE path (NcwSdfNet.w_lo): fp16 mode at W = 256 evaluates sdf with hi + lo pairs of fp16
+        """Split-precision VALUE path (NcwSdfNet.w_lo): fp16 mode at W = 256 / 512 evaluates sdf with hi + lo pairs of fp16
         weights and activations (three MFMAs per product) -- fp32-like SDF values, which sigmoid(sdf * inv_s) needs once
         inv_s is in the hundreds.  NEUCONW_SDF_SPLIT=0 (or `self.sdf_split = False`) switches it off."""
         import os
@@ -156,7 +156,7 @@ class SDFNetwork(nn.Module):
         on = self.__dict__.get("sdf_split")
         if on is None:
             on = os.environ.get("NEUCONW_SDF_SPLIT", "1") not in ("0", "")
-        return bool(on) and prec == L.PREC_F16 and self.d_hidden == 256 and self.n_lin >= 3
+        return bool(on) and prec == L.PREC_F16 and self.d_hidden in (256, 512) and self.n_lin >= 3
 
     def plan(self, prec):
         dev = self.lin0.bias.device

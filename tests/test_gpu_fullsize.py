@@ -28,13 +28,12 @@ def _jitter(neuconw):
 #   fp16 (W = 256: split-precision SDF value path, csrc/ncw_split.hip): colour / depth / weights_sum 5.5e-5, eikonal term
 #         2.3e-4 / 2.7e-4, gradients 3.7e-3 / 1.25e-3 at 16+16 / 64+64; loss 2e-6 / 1.1e-5.  (Plain fp16 value path,
 #         NEUCONW_SDF_SPLIT=0: 2.4e-4 / 4.2e-4 on the outputs, see test_plain_fp16_value_path.)
-#   W = 512 at 8+16 samples (the shipped yaml's shape; plain fp16) is the ill-conditioned case -- 24 samples per ray, one moved
-#   sample shows: fp32 itself is at 1.5e-4 there; bf16 1.5e-2 / 4.7e-2, fp16 3.4e-3 (gradient_error 7.6e-3) / 1.3e-2,
-#   loss 2e-3 / 2e-4.  The kernels themselves are as accurate at W = 512 as at 256 (scripts/diag/sdf_fwd_prec.py:
-#   sdf_fwd's sdf / normals / features vs the fp32 mode, bf16 3.9e-3 / 1.1e-2 / 4.6e-3, fp16 3.7e-4 / 1.3e-3 / 7.0e-4).
+#   W = 512 at 8+16 samples (the shipped yaml's shape) is the ill-conditioned case -- 24 samples per ray, one moved sample
+#   shows: fp32 itself is at 1.5e-4 there; bf16 1.5e-2 / 4.7e-2; fp16 with the split value path (ncw_sdf16.hip) 4.6e-5
+#   (eikonal 9e-6) / 1.3e-2, loss 1.1e-5 (plain fp16 value path: 3.4e-3, eikonal 7.6e-3).
 # (tol colour/depth/weights_sum, tol parameter gradients, tol eikonal term)
 BF16_TOL = {(16, 16): (1e-2, 0.175, 1e-2), (64, 64): (1.4e-2, 0.09, 1.4e-2), (8, 16): (3e-2, 0.1, 3e-2)}
-F16_TOL = {(16, 16): (1.2e-4, 8e-3, 5e-4), (64, 64): (1.2e-4, 3e-3, 6e-4), (8, 16): (1.5e-2, 0.03, 1.6e-2)}
+F16_TOL = {(16, 16): (1.2e-4, 8e-3, 5e-4), (64, 64): (1.2e-4, 3e-3, 6e-4), (8, 16): (1.5e-4, 0.03, 1e-4)}
 LOSS_TOL = {"f32": 1e-4, "bf16": 1.4e-3, "f16": 5e-5}
 
 
@@ -77,7 +76,7 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
     print("W=%d %d+%d %s outputs:" % (W, ns, ni, prec_name), {k: "%.2e" % v for k, v in errs.items()})
     for k, e in errs.items():
         assert e < (tol_eik if k == "gradient_error" else tol_out), (k, e)
-    assert abs(float(loss.detach()) - float(lref.detach())) < LOSS_TOL[prec_name] * (40 if W == 512 and prec_name != "f32" else 1)
+    assert abs(float(loss.detach()) - float(lref.detach())) < LOSS_TOL[prec_name] * (40 if W == 512 and prec_name == "bf16" else 1)
     params = named_params(emb, neuconw, nerf)
 
     def net_of(k):

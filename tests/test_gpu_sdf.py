@@ -47,18 +47,18 @@ def test_sdf_infer_vs_oracle(W, n_layers, skip, prec):
     assert err < {"f32": TOL_F32, "bf16": TOL_BF16, "f16": TOL_F16}[prec]
 
 
-@pytest.mark.parametrize("n_layers,skip", [(8, (4,)), (8, (1,)), (10, (4,)), (3, ())])
-def test_split_precision_value_path(n_layers, skip):
-    """fp16 mode at W = 256: the SDF value chain in split precision (csrc/ncw_split.hip: hi + lo fp16 pairs of weights and
-    activations, three MFMAs per product) is fp32-accurate -- sdf(), the sampler's queries and the forward sweep of sdf_fwd --
-    while the plain fp16 chain (sdf_split = False) sits at 4-9e-4.  n_layers = 10 takes the burst kernel (the pipelined one
-    stages at most 8 Softplus layers' biases), skip layer 1 / no skip layer the other branches of the pipeline."""
+@pytest.mark.parametrize("W,n_layers,skip", [(256, 8, (4,)), (256, 8, (1,)), (256, 10, (4,)), (256, 3, ()), (512, 8, (4,)), (512, 4, ())])
+def test_split_precision_value_path(W, n_layers, skip):
+    """fp16 mode at W = 256 / 512: the SDF value chain in split precision (csrc/ncw_split.hip, ncw_sdf16.hip: hi + lo fp16 pairs
+    of weights and activations, three MFMAs per product) is fp32-accurate -- sdf(), the sampler's queries and the forward
+    sweep of sdf_fwd -- while the plain fp16 chain (sdf_split = False) sits at 4-9e-4.  W = 256, n_layers = 10 takes the burst
+    kernel (the pipelined one stages at most 8 Softplus layers' biases), skip layer 1 / no skip layer the other branches."""
     import neuralrecon_w_amd as nw
     from neuralrecon_w_amd.neuconw import points_struct
     from neuralrecon_w_amd.stash import StashCache
     from oracle import neuconw_oracle as O
 
-    net = _mk(256, n_layers, skip)
+    net = _mk(W, n_layers, skip)
     g = torch.Generator().manual_seed(5)
     x = (torch.rand(4133, 3, generator=g) * 2 - 1) * 1.2  # ragged: not a multiple of 32 / 128
     sd = {"sdf_net." + k: v.detach().cpu().double() for k, v in net.state_dict().items()}
@@ -70,8 +70,8 @@ def test_split_precision_value_path(n_layers, skip):
         sdf2, grad, c = net.fwd_stash(points_struct(x=x.cuda()), x.shape[0], nw.PREC_F16)
         StashCache.release(c["lease"])
         errs[split] = (rel_err(got, ref), rel_err(sdf2.cpu(), ref), rel_err(grad.cpu(), ref_grad))
-    print("W=256 L=%d skip=%s: split sdf %.2e / %.2e normals %.2e;  plain sdf %.2e / %.2e normals %.2e"
-          % ((n_layers, skip) + errs[True] + errs[False]))
+    print("W=%d L=%d skip=%s: split sdf %.2e / %.2e normals %.2e;  plain sdf %.2e / %.2e normals %.2e"
+          % ((W, n_layers, skip) + errs[True] + errs[False]))
     assert errs[True][0] < 5e-6 and errs[True][1] < 5e-6 and errs[True][2] < TOL_F16
     assert errs[False][0] > 20 * errs[True][0]  # the switch does switch
 
