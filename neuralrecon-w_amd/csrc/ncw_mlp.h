@@ -7,6 +7,18 @@
 template <class P>
 struct Fast { static constexpr bool v = (P::id == NCW_PREC_BF16); };
 
+// Workgroup barrier that orders LDS traffic only: `__syncthreads()` makes hipcc drain the vector-memory queue as well
+// (s_waitcnt vmcnt(0) in front of s_barrier), i.e. every barrier waits for the stash stores and the next layer's weight
+// prefetch issued before it.  The kernels that use this one exchange data between waves through LDS only (a stash block is
+// read back, if at all, by the thread that wrote it; register dependencies on outstanding loads are tracked by the
+// compiler), so global traffic may stay in flight across the barrier.  NOT for the LDS-DMA weight ring (ncw_common.h):
+// there the barrier is what publishes a `global_load_lds` to the other waves.
+NCW_DEV void ncw_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ---- point of lane ---------------------------------------------------------------------------
 // mode 0: x[p];  1: o + d z[p];  2: o + d (z_i + dist_i / 2) with dist_i = z_{i+1} - z_i, last =
 // sample_dist  (renderer.py:586-597 / :172-179)

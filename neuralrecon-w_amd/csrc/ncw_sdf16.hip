@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_infer16_kernel(NcwSdfNet n
             for (int q = 0; q < 3; ++q) w0[j][q] = s16_ld(net.w[0], 16, wave + 8 * j, q, lane);
         if (L - 1 > 1) s16_prefetch(r, net.w[1], 16, wave, lane);
         const f32x16 b0 = s16_bias(net.b[0], wave, lane), b1 = s16_bias(net.b[0], wave + 8, lane);
-        __syncthreads();
+        ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -184,18 +184,18 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_infer16_kernel(NcwSdfNet n
     }
     for (int l = 1; l < L - 1; ++l) {
         const f32x16 b0 = s16_bias(net.b[l], wave, lane), b1 = s16_bias(net.b[l], wave + 8, lane);
-        __syncthreads();  // layer l-1 outputs of all waves are in abuf
+        ncw_lds_barrier();  // layer l-1 outputs of all waves are in abuf
         s16_fill<T>(acc, b0, b1);
         s16_mma<T, S16_KU>(acc, r, net.w[l], 16, wave, abuf, lane);
         if (l + 1 < L - 1) s16_prefetch(r, net.w[l + 1], 16, wave, lane);
         if (l == net.skip_layer) s16_mma_gamma<T>(acc, net.w[l], wave, gbuf, lane);
-        __syncthreads();  // every wave has read abuf: overwrite in place
+        ncw_lds_barrier();  // every wave has read abuf: overwrite in place
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int j = 0; j < 2; ++j) s16_store_units(abuf, t, wave + 8 * j, s16_softplus(acc[j][t]), lane);
     }
-    __syncthreads();
+    ncw_lds_barrier();
     for (int tw = wave; tw < T; tw += S16_WAVES) {  // sdf row
         CVec<1> o;
         load_bias(o, net.b[L - 1], lane);
@@ -221,7 +221,7 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
     {
         const bf16x8 wt1_0 = s16_ld(net.wt[L - 1], 16, wave, 0, lane), wt1_1 = s16_ld(net.wt[L - 1], 16, wave + 8, 0, lane);
         const f32x16 b0 = s16_bias(net.b_feat, wave, lane), b1 = s16_bias(net.b_feat, wave + 8, lane);
-        __syncthreads();  // h_{L-1} complete in abuf
+        ncw_lds_barrier();  // h_{L-1} complete in abuf
         s16_fill<T>(acc, b0, b1);
         s16_mma<T, S16_KU, BS>(acc, r, net.w_feat, 16, wave, abuf, lane);
         if (L - 2 >= 1) s16_prefetch(r, net.wt[L - 2], (L - 2 == net.skip_layer) ? 18 : 16, wave, lane);
@@ -242,7 +242,7 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
         for (int e = 0; e < 8; ++e) e0f[e] = (ncw_h16)0.f;
         e0f[0] = (ncw_h16)(lane < 32 ? 1.f : 0.f);
         const f32x16 a0 = NCW_MFMA_H(wt1_0, e0f, s16_zero(), 0, 0, 0), a1 = NCW_MFMA_H(wt1_1, e0f, s16_zero(), 0, 0, 0);
-        __syncthreads();  // the feature layer and the sdf row have read h_{L-1}: overwrite abuf with t_{L-2}
+        ncw_lds_barrier();  // the feature layer and the sdf row have read h_{L-1}: overwrite abuf with t_{L-2}
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -259,12 +259,12 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
     f32x16 gg = s16_zero();
     for (int l = L - 2; l >= 1; --l) {
         const bool skip = (l == net.skip_layer);
-        __syncthreads();  // t_l complete in abuf
+        ncw_lds_barrier();  // t_l complete in abuf
         s16_fill<T>(acc, s16_zero(), s16_zero());
         s16_mma<T, S16_KU>(acc, r, net.wt[l], skip ? 18 : 16, wave, abuf, lane);
         if (l - 1 >= 1) s16_prefetch(r, net.wt[l - 1], (l - 1 == net.skip_layer) ? 18 : 16, wave, lane);
         if (skip && gjob) s16_mma1<S16_KU>(gg, net.wt[l], 18, 16 + jb, abuf, jt, lane);  // gamma columns of the skip layer
-        __syncthreads();
+        ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -277,7 +277,7 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
             }
     }
     // ---- adjoint layer 0: g_gamma += W_0^T t_0 (2 out-blocks), then grad = J_gamma^T g_gamma ------------------------
-    __syncthreads();
+    ncw_lds_barrier();
     float nx = 0.f, ny = 0.f, nz = 0.f;
     int64_t p = (tile0 + jt) * 32 + (lane & 31), ray;
     const bool valid = gjob && p < n;
@@ -307,7 +307,7 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
     if (gjob && jb == 1 && lane < 32) {
         part[(jt * 32 + lane) * 3 + 0] = nx; part[(jt * 32 + lane) * 3 + 1] = ny; part[(jt * 32 + lane) * 3 + 2] = nz;
     }
-    __syncthreads();
+    ncw_lds_barrier();
     if (gjob && jb == 0 && lane < 32 && valid) {
         grad[p * 3 + 0] = nx + part[(jt * 32 + lane) * 3 + 0];
         grad[p * 3 + 1] = ny + part[(jt * 32 + lane) * 3 + 1];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net
             for (int q = 0; q < 3; ++q) w0[j][q] = s16_ld(net.w[0], 16, wave + 8 * j, q, lane);
         s16_prefetch(r, L - 1 > 1 ? net.w[1] : net.w_feat, 16, wave, lane);
         const f32x16 b0 = s16_bias(net.b[0], wave, lane), b1 = s16_bias(net.b[0], wave + 8, lane);
-        __syncthreads();
+        ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -367,12 +367,12 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net
     }
     for (int l = 1; l < L - 1; ++l) {  // r = first units of w[l]
         const f32x16 b0 = s16_bias(net.b[l], wave, lane), b1 = s16_bias(net.b[l], wave + 8, lane);
-        __syncthreads();
+        ncw_lds_barrier();
         s16_fill<T>(acc, b0, b1);
         s16_mma<T, S16_KU>(acc, r, net.w[l], 16, wave, abuf, lane);
         s16_prefetch(r, l + 1 < L - 1 ? net.w[l + 1] : net.w_feat, 16, wave, lane);  // next: hidden or feature layer
         if (l == net.skip_layer) s16_mma_gamma<T>(acc, net.w[l], wave, gbuf, lane);
-        __syncthreads();
+        ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_bwd16_kernel(NcwSdfNet net
 #pragma unroll
             for (int q = 0; q < 3; ++q) w0[j][q] = s16_ld(net.w[0], 16, wave + 8 * j, q, lane);
         s16_prefetch(r, 1 <= L - 2 ? net.w[1] : net.wt_feat, 16, wave, lane);
-        __syncthreads();
+        ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -472,12 +472,12 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_bwd16_kernel(NcwSdfNet net
             }
     }
     for (int l = 1; l <= L - 2; ++l) {  // r = first units of w[l]
-        __syncthreads();
+        ncw_lds_barrier();
         s16_fill<T>(acc, s16_zero(), s16_zero());
         s16_mma<T, S16_KU>(acc, r, net.w[l], 16, wave, abuf, lane);
         s16_prefetch(r, l + 1 <= L - 2 ? net.w[l + 1] : net.wt_feat, 16, wave, lane);
         if (l == net.skip_layer) s16_mma_gamma<T>(acc, net.w[l], wave, gbuf, lane);
-        __syncthreads();
+        ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_bwd16_kernel(NcwSdfNet net
                 s16_store_units(abuf, t, wave + 8 * j, df, lane);
             }
         const bf16x8 wl0 = s16_ld(net.wt[L - 1], 16, wave, 0, lane), wl1 = s16_ld(net.wt[L - 1], 16, wave + 8, 0, lane);  // K = 1 unit
-        __syncthreads();  // dfeat complete in abuf
+        ncw_lds_barrier();  // dfeat complete in abuf
         s16_fill<T>(acc, s16_zero(), s16_zero());
         s16_mma<T, S16_KU>(acc, r, net.wt_feat, 16, wave, abuf, lane);
         if (L - 2 > 0) s16_prefetch(r, net.wt[L - 2], (L - 2 == net.skip_layer) ? 18 : 16, wave, lane);
@@ -515,18 +515,18 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_bwd16_kernel(NcwSdfNet net
             acc[0][t] = NCW_MFMA_H(wl0, gbuf[(t * 4 + 3) * 64 + lane], acc[0][t], 0, 0, 0);
             acc[1][t] = NCW_MFMA_H(wl1, gbuf[(t * 4 + 3) * 64 + lane], acc[1][t], 0, 0, 0);
         }
-        __syncthreads();
+        ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int j = 0; j < 2; ++j) fwd_epilogue(acc[j][t], L - 2, t, wave + 8 * j);
     }
     for (int l = L - 2; l >= 1; --l) {  // u = wt[l] zbar_l, zbar_{l-1} = u phi'(z_{l-1}) + zbar2_{l-1}
-        __syncthreads();
+        ncw_lds_barrier();
         s16_fill<T>(acc, s16_zero(), s16_zero());
         s16_mma<T, S16_KU>(acc, r, net.wt[l], (l == net.skip_layer) ? 18 : 16, wave, abuf, lane);
         if (l - 1 > 0) s16_prefetch(r, net.wt[l - 1], (l - 1 == net.skip_layer) ? 18 : 16, wave, lane);
-        __syncthreads();
+        ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -646,14 +646,14 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
         for (int q = 0; q < 3; ++q) s16s_ld_unit(w0[q], net.w[0], net.w_lo[0], 16, wave, q, lane);
         if (L - 1 > 1) s16s_prefetch(r, net.w[1], net.w_lo[1], 16, wave, lane);
         s16_fill<T>(acc, s16_bias(net.b[0], wave, lane), s16_bias(net.b[0], wave + 8, lane));
-        __syncthreads();  // gamma visible
+        ncw_lds_barrier();  // gamma visible
 #pragma unroll
         for (int q = 0; q < 3; ++q) s16s_unit(acc, w0[q], gsbuf, 4, q, lane);
         epilogue(1);
     }
     for (int l = 1; l < L - 1; ++l) {
         const f32x16 b0 = s16_bias(net.b[l], wave, lane), b1 = s16_bias(net.b[l], wave + 8, lane);
-        __syncthreads();  // layer l-1 outputs of all waves are in sbuf
+        ncw_lds_barrier();  // layer l-1 outputs of all waves are in sbuf
         s16_fill<T>(acc, b0, b1);
         s16s_mma(acc, r, net.w[l], net.w_lo[l], wave, sbuf, lane);
         if (l + 1 < L - 1) s16s_prefetch(r, net.w[l + 1], net.w_lo[l + 1], 16, wave, lane);
@@ -665,10 +665,10 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
                 s16s_unit(acc, g, gsbuf, 4, q, lane);
             }
         }
-        __syncthreads();  // every wave has read sbuf: overwrite in place
+        ncw_lds_barrier();  // every wave has read sbuf: overwrite in place
         epilogue(l + 1);
     }
-    __syncthreads();
+    ncw_lds_barrier();
     if (wave < T) {  // sdf row (1 output block), tile = wave
         CVec<1> o;
         load_bias(o, net.b[L - 1], lane);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
         sb_load_slice<3>(w0, net.w[0], 8, wave, 0, lane);
         sb_load_slice<16>(wa, L - 1 > 1 ? net.w[1] : net.w_feat, 8, wave, 0, lane);
         const f32x16 bias = bias_block(net.b[0]);
-        __syncthreads();
+        ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < SB_TILES; ++t) {
             f32x16 acc = bias;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
         if (skip) sb_load_slice<3>(wg, net.w[l], 8, wave, 16, lane);
         sb_load_slice<16>(wb, l + 1 < L - 1 ? net.w[l + 1] : net.w_feat, 8, wave, 0, lane);  // next: hidden or feature layer
         const f32x16 bias = bias_block(net.b[l]);
-        __syncthreads();
+        ncw_lds_barrier();
         const sb_lfrag* in = cur ? abuf1 : abuf0;
         sb_lfrag* out = cur ? abuf0 : abuf1;
 #pragma unroll
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
         bf16x8 wt1 = ((const __attribute__((address_space(1))) bf16x8*)net.wt[L - 1])[(size_t)wave * 64 + lane];  // unit 0, block ob
         if (L - 2 >= 1) sb_load_slice<16>(wb, net.wt[L - 2], (L - 2 == net.skip_layer) ? 10 : 8, wave, 0, lane);
         const f32x16 bias = bias_block(net.b_feat);
-        __syncthreads();  // h_{L-1} complete in abuf[cur]
+        ncw_lds_barrier();  // h_{L-1} complete in abuf[cur]
         const sb_lfrag* in = cur ? abuf1 : abuf0;
 #pragma unroll
         for (int tp = 0; tp < SB_TILES; tp += 2) {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
         const int stride = skip ? 10 : 8;
         (void)stride;
         if (!skip && l - 1 >= 1) sb_load_slice<16>(wb, net.wt[l - 1], (l - 1 == net.skip_layer) ? 10 : 8, wave, 0, lane);
-        __syncthreads();  // t_l complete in abuf[cur]
+        ncw_lds_barrier();  // t_l complete in abuf[cur]
         const sb_lfrag* in = cur ? abuf1 : abuf0;
         sb_lfrag* out = cur ? abuf0 : abuf1;
 #pragma unroll
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
     }
     // ---- adjoint layer 0: g_gamma += W_0^T t_0 (2 out-blocks), then grad = J_gamma^T g_gamma -----------------------
     sb_load_slice<16>(wb, net.wt[0], 2, jb, 0, lane);
-    __syncthreads();
+    ncw_lds_barrier();
     {
         const sb_lfrag* in = cur ? abuf1 : abuf0;
 #pragma unroll
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
     if (jb == 1 && lane < 32) {
         part[(jt * 32 + lane) * 3 + 0] = nx; part[(jt * 32 + lane) * 3 + 1] = ny; part[(jt * 32 + lane) * 3 + 2] = nz;
     }
-    __syncthreads();
+    ncw_lds_barrier();
     if (jb == 0 && lane < 32 && valid) {
         grad[p * 3 + 0] = nx + part[(jt * 32 + lane) * 3 + 0];
         grad[p * 3 + 1] = ny + part[(jt * 32 + lane) * 3 + 1];
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
         sb_load_slice<6>(w0, net.w_p[0], 8, wave, 0, lane);
         sb_load_slice<16>(wa, D > 1 ? net.w_p[1] : net.w_feat, 8, wave, 0, lane);
         const f32x16 bias = bias_of(net.b_p[0], wave);
-        __syncthreads();
+        ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < SB_TILES; ++t) {
             f32x16 acc = bias;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
         if (skip) sb_load_slice<6>(wx, net.w_p[i], 8, wave, 16, lane);  // units 16..21 = the gamma(p) columns
         sb_load_slice<16>(wb, i + 1 < D ? net.w_p[i + 1] : net.w_feat, 8, wave, 0, lane);
         const f32x16 bias = bias_of(net.b_p[i], wave);
-        __syncthreads();
+        ncw_lds_barrier();
         const sb_lfrag* in = cur ? abuf1 : abuf0;
         sb_lfrag* out = cur ? abuf0 : abuf1;
 #pragma unroll
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
         sb_load_slice<16>(wb, net.w_a[0], 4, hb, 0, lane);   // head layer 0: feature columns
         sb_load_slice<6>(wx, net.w_a[0], 4, hb, 16, lane);   //               AUX1 columns (units 16..21)
         const f32x16 bias = bias_of(net.b_feat, wave);
-        __syncthreads();  // h_D complete in abuf[cur]; nobody reads gamma(p) in xbuf any more
+        ncw_lds_barrier();  // h_D complete in abuf[cur]; nobody reads gamma(p) in xbuf any more
         const sb_lfrag* in = cur ? abuf1 : abuf0;
         sb_lfrag* out = cur ? abuf0 : abuf1;
         if (wave < SB_TILES) {
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
         bf16x8 wn[8];
         if (i + 1 < net.n_head) sb_load_slice<8>(wn, net.w_a[i + 1], 4, hb, 0, lane);
         const f32x16 bias = bias_of(net.b_a[i], hb);
-        __syncthreads();
+        ncw_lds_barrier();
         const sb_lfrag* in = cur ? abuf1 : abuf0;
         sb_lfrag* out = cur ? abuf0 : abuf1;
         const int ta = 2 * hp, tb = 2 * hp + 1;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
         cur ^= 1;
     }
     // ---- raw rgb (nerf.py:181), waves 0..3 ---------------------------------------------------------------------
-    __syncthreads();
+    ncw_lds_barrier();
     if (wave < SB_TILES) {
         const sb_lfrag* in = cur ? abuf1 : abuf0;
         bf16x8 w1[8];
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
         const bf16x8 wr = ((gfrag)net.wt_rgb)[(size_t)hb * 64 + lane];  // wt_rgb: 4 out-blocks, unit 0 (K = 3)
         if (NH > 1) sb_load_slice<8>(wa, net.wt_a[NH - 1], 4, hb, 0, lane);
         else sb_load_slice<8>(wa, net.wt_a[0], 11, wave, 0, lane);
-        __syncthreads();  // d_rgb / d_density units visible
+        ncw_lds_barrier();  // d_rgb / d_density units visible
         ue0 = NCW_MFMA_H(wr, xbuf[(ta * 6 + 0) * 64 + lane], zero16, 0, 0, 0);
         ue1 = NCW_MFMA_H(wr, xbuf[(tb * 6 + 0) * 64 + lane], zero16, 0, 0, 0);
     }
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
         sb_store_units(out, tb, hb, z1, lane);
         if (i - 1 >= 1) sb_load_slice<8>(wb, net.wt_a[i - 1], 4, hb, 0, lane);
         else sb_load_slice<8>(wb, net.wt_a[0], 11, wave, 0, lane);  // next: q = wt_a[0] ze_0, block = wave
-        __syncthreads();
+        ncw_lds_barrier();
         ue0 = zero16; ue1 = zero16;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
         sb_store_units(out, ta, hb, z0, lane);
         sb_store_units(out, tb, hb, z1, lane);
         sb_load_slice<16>(wb, net.wt_feat, 8, wave, 0, lane);  // next: u = wt_feat zf
-        __syncthreads();
+        ncw_lds_barrier();
         const sb_lfrag* in = out;
         sb_lfrag* out2 = cur ? abuf0 : abuf1;
 #pragma unroll
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
     {
         const bf16x8 wal = ((gfrag)net.wt_alpha)[(size_t)wave * 64 + lane];  // wt_alpha: 8 out-blocks, unit 0 (K = 1)
         if (D - 1 > 0) sb_load_slice<16>(wb, net.wt_p[D - 1], (D - 1 == net.skip + 1) ? 11 : 8, wave, 0, lane);
-        __syncthreads();  // zf complete
+        ncw_lds_barrier();  // zf complete
         const sb_lfrag* in = cur ? abuf1 : abuf0;
         sb_lfrag* out = cur ? abuf0 : abuf1;
 #pragma unroll
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
     // ---- trunk reversed: za_{i-1} = relu'(h_i) (wt_p[i] za_i), i = D-1 .. 1 (wa = slice of wt_p[i]) ----------------------
     for (int i = D - 1; i >= 1; --i) {
         if (i - 1 >= 1) sb_load_slice<16>(wb, net.wt_p[i - 1], (i - 1 == net.skip + 1) ? 11 : 8, wave, 0, lane);
-        __syncthreads();
+        ncw_lds_barrier();
         const sb_lfrag* in = cur ? abuf1 : abuf0;
         sb_lfrag* out = cur ? abuf0 : abuf1;
 #pragma unroll

@@ -124,7 +124,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
     const ss_lfrag* const gin = gbuf + lane;
     // hidden-layer epilogue: Softplus, stash, hi / lo fragments of this wave's block into abuf (in place)
     auto epilogue = [&](int l_out) {
-        __syncthreads();  // every wave has finished reading the layer input
+        ncw_lds_barrier();  // every wave has finished reading the layer input
 #pragma unroll
         for (int t = 0; t < SS_TILES; ++t) {
             f32x16 yv;
@@ -139,7 +139,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
                 abuf[((t * 16 + 2 * wave + tt) * 2 + 1) * 64 + lane] = lo;
             }
         }
-        __syncthreads();  // the layer output is complete
+        ncw_lds_barrier();  // the layer output is complete
     };
     // ---- layer 0: K = 39, the 3 gamma units ------------------------------------------------------------------
     {
@@ -149,7 +149,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         const f32x16 bias = ss_bias(net.b[0], wave, lane);
 #pragma unroll
         for (int t = 0; t < SS_TILES; ++t) acc[t] = bias;
-        __syncthreads();  // gamma visible
+        ncw_lds_barrier();  // gamma visible
         ss_mma<3>(acc, w0h, w0l, gin, 3, 0);
         epilogue(1);
     }
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) a0[r] = 0.f;
         a0 = NCW_MFMA_H(wt1, e0f, a0, 0, 0, 0);
-        __syncthreads();  // every wave is done with the split buffer (feature rows, sdf row): the plain buffers alias it
+        ncw_lds_barrier();  // every wave is done with the split buffer (feature rows, sdf row): the plain buffers alias it
         sb_lfrag* out = (sb_lfrag*)sbuf;  // abuf0
 #pragma unroll
         for (int t = 0; t < SS_TILES; ++t) {
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, 
     for (int l = L - 2; l >= 1; --l) {
         const bool skip = (l == net.skip_layer);
         if (!skip && l - 1 >= 1) sb_load_slice<16>(wb, net.wt[l - 1], (l - 1 == net.skip_layer) ? 10 : 8, wave, 0, lane);
-        __syncthreads();  // t_l complete in abuf[cur]
+        ncw_lds_barrier();  // t_l complete in abuf[cur]
         const sb_lfrag* in = cur ? abuf1 : abuf0;
         sb_lfrag* out = cur ? abuf0 : abuf1;
 #pragma unroll
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, 
     }
     // ---- adjoint layer 0: g_gamma += W_0^T t_0 (2 out-blocks), then grad = J_gamma^T g_gamma -----------------------
     sb_load_slice<16>(wb, net.wt[0], 2, jb, 0, lane);
-    __syncthreads();
+    ncw_lds_barrier();
     {
         const sb_lfrag* in = cur ? abuf1 : abuf0;
 #pragma unroll
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, 
     if (jb == 1 && lane < 32) {
         part[(jt * 32 + lane) * 3 + 0] = nx; part[(jt * 32 + lane) * 3 + 1] = ny; part[(jt * 32 + lane) * 3 + 2] = nz;
     }
-    __syncthreads();
+    ncw_lds_barrier();
     if (jb == 0 && lane < 32 && valid) {
         grad[p * 3 + 0] = nx + part[(jt * 32 + lane) * 3 + 0];
         grad[p * 3 + 1] = ny + part[(jt * 32 + lane) * 3 + 1];

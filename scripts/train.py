@@ -42,11 +42,17 @@ def main():
     args = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("NCW_TRAIN_ONE_GPU_TEST"):  # plumbing test: the ranks share GPU 0 (collectives over gloo)
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("NCW_DIST_BACKEND", "nccl")  # nccl = RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
     cfg = C.load_config(args.cfg_path, {"DATASET": {"ROOT_DIR": args.root_dir}} if args.root_dir else None)
     lr = C.scale_lr(cfg, world, args.batch_size)
@@ -121,6 +127,7 @@ def main():
         os.makedirs(save_dir, exist_ok=True)
         trainer.save_checkpoint(os.path.join(save_dir, "last.ckpt"), emb, neuconw, nerf, optimizer=step_fn.opt, global_step=step)
         print("%d steps in %.1f s; wrote %s" % (step, time.perf_counter() - t0, os.path.join(save_dir, "last.ckpt")))
+    print("[rank %d] finished after %d steps with %d rays resident" % (rank, step, len(cache)))
     if world > 1:
         dist.destroy_process_group()
 

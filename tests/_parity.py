@@ -29,9 +29,35 @@ def perturb_weights(neuconw, g_jit=0.1, v_jit=0.0, seed=11):
 
 
 _ORACLE_CACHE = {}
+_TRAINED = {}
 
 
-def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=True, cos_anneal=0.3, sdf_split=None):
+def trained_weights(W, ns, ni, seed, v_jit, steps, lr=1e-3, R=128):
+    """The state_dict after `steps` TrainSteps in the fp32 mode (bitwise reproducible on a given GPU: DESIGN.md 3.2) from
+    the seeded initial weights on a seeded synthetic batch: a NON-TRIVIAL network (an SDF that is no longer the geometric
+    initialisation's sphere, colour / background weights that have seen gradients) shared by every precision of a test."""
+    key = (W, ns, ni, seed, v_jit, steps, lr, R)
+    if key not in _TRAINED:
+        import neuralrecon_w_amd as nw
+
+        emb, neuconw, nerf, rdr = build_system(W=W, n_a=48, n_vocab=100, nerf_w=256, color_hidden=256, head=128, seed=seed,
+                                               prec=nw.PREC_F32, n_samples=ns, n_importance=ni)
+        perturb_weights(neuconw, 0.1, v_jit)
+        rdr.sync_free = True
+        loss = nw.NeuconWLoss(coef=1.0, igr_weight=0.1, mask_weight=0.1, depth_weight=0.1, use_mask=True, use_depth=True)
+        ts_ = nw.TrainStep(rdr, [emb, neuconw, nerf], loss, lr=lr, eps=1e-7, clip=0.99)
+        rays, t, label, rgbs = [x.cuda() for x in synth_rays(R, 123, 100)]
+        bg = torch.zeros(1, 3).cuda()
+        for i in range(steps):
+            ts_(rays, t, label, rgbs, background_rgb=bg, cos_anneal_ratio=0.3, perturb_overwrite=0)
+        torch.cuda.synchronize()
+        _TRAINED.clear()
+        _TRAINED[key] = {k: v.clone() for k, v in state_dict_cpu(emb, neuconw, nerf, torch.float32).items()}
+    return _TRAINED[key]
+
+
+def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=True, cos_anneal=0.3, sdf_split=None,
+             train_steps=0):
     """-> dict(errs={color, depth, weights_sum, gradient_error}, loss, loss_ref, grad_worst, inv_s).
     Gradient errors are scaled by the largest gradient of their network (the fp32 reference's own gradients of ~1e-7
     tensors carry ~1e-1 relative noise: tests/test_gpu_fullsize.py)."""
@@ -40,6 +66,10 @@ def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=Tru
     emb, neuconw, nerf, rdr = build_system(W=W, n_a=48, n_vocab=100, nerf_w=256, color_hidden=256, head=128, seed=seed,
                                            prec=prec, n_samples=ns, n_importance=ni)
     perturb_weights(neuconw, 0.1, v_jit)
+    if train_steps > 0:
+        sd_t = trained_weights(W, ns, ni, seed, v_jit, train_steps)
+        from tests._build import load_golden_weights
+        load_golden_weights({k: v.cuda() for k, v in sd_t.items()}, emb, neuconw, nerf)
     if sdf_split is not None:  # None = the product default (split-precision SDF value path in the fp16 mode at W = 256)
         neuconw.sdf_net.sdf_split = bool(sdf_split)
     with torch.no_grad():
@@ -50,7 +80,7 @@ def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=Tru
     loss = loss_from_outputs(out, rgbs.cuda())
     if with_grads:
         loss.backward()
-    key = (W, ns, ni, R, float(variance), float(v_jit), seed, with_grads, cos_anneal)
+    key = (W, ns, ni, R, float(variance), float(v_jit), seed, with_grads, cos_anneal, train_steps)
     hit = _ORACLE_CACHE.get(key)
     if hit is None:  # the oracle result does not depend on the GPU precision: shared by the parametrised cases
         sd = state_dict_cpu(emb, neuconw, nerf, torch.float64)

@@ -138,6 +138,26 @@ def test_train_step_vs_oracle_at_trained_operating_points(variance, v_jit, prec_
     assert r["grad_worst"] < tol_grad, r["grad_worst"]
 
 
+@pytest.mark.parametrize("prec_name", ["f32", "f16", "bf16"])
+def test_train_step_vs_oracle_after_training(prec_name):
+    """The same comparison on a network that has been TRAINED: 40 TrainSteps in the (bitwise reproducible) fp32 mode from
+    the seeded initial weights at lr 1e-3, then variance set to 0.6 (inv_s 403): an SDF that is no longer the geometric
+    initialisation's sphere, colour / background weights that have seen gradients.  Measured (MI355X; colour / depth /
+    weights_sum / eikonal / gradients): fp32 3.1e-6 / 9.6e-7 / 1.6e-6 / 9.2e-7 / 5.4e-5; fp16 (split SDF value path) 1.9e-4 /
+    1.1e-6 / 2.3e-5 / 1.9e-4 / 1.0e-2 -- depth and weights_sum (functions of the SDF alone) stay at the fp32 level, the
+    colour now shows the plain-fp16 COLOUR network on trained weights; bf16 1.1e-3 / 2.5e-4 / 3.0e-4 / 4.7e-3 / 8.8e-2."""
+    import neuralrecon_w_amd as nw
+    from tests._parity import run_case
+
+    prec = {"f32": nw.PREC_F32, "bf16": nw.PREC_BF16, "f16": nw.PREC_F16}[prec_name]
+    r = run_case(256, 64, 64, prec, 16, variance=0.6, train_steps=40)
+    print("after 40 fp32 steps, variance 0.6, %s:" % prec_name, {k: "%.2e" % v for k, v in r["errs"].items()}, "grads %.2e" % r["grad_worst"])
+    tol_out, tol_grad, tol_eik = {"f32": (1e-4, 2e-3, 1e-4), "f16": (4e-4, 2e-2, 4e-4), "bf16": (2.5e-3, 0.18, 1e-2)}[prec_name]
+    for k, e in r["errs"].items():
+        assert e < (tol_eik if k == "gradient_error" else tol_out), (k, e)
+    assert r["grad_worst"] < tol_grad, r["grad_worst"]
+
+
 def test_plain_fp16_value_path():
     """NEUCONW_SDF_SPLIT=0 / sdf_net.sdf_split = False: one fp16 rounding per operand in the SDF value chain too (the
     round-2 kernels: sdf_inferC, sdf_fwdB).  Measured: outputs 4.2e-4 at inv_s 20, 7.3e-3 at inv_s 403 (R = 16)."""

@@ -17,7 +17,7 @@ from tests._util import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _write_scene(root):
+def _write_scene(root, n_chunks=2):
     sys.path.insert(0, ROOT)
     import bench
 
@@ -35,8 +35,8 @@ def _write_scene(root):
                     "eval_bbx": [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], "voxel_size": 0.125, "min_track_length": 2},
                    open(os.path.join(root, "config.yaml"), "w"))
     labels = np.array([0, 1, 2, 4, 12, 20], dtype=np.float32)
-    for i in range(2):
-        rays, ts, label, rgbs = bench.synth_batch(300, 50 + i, "cpu")  # [o d near far depth_gt depth_w], ts, sky-or-0, rgb
+    for i in range(n_chunks):
+        rays, ts, label, rgbs = bench.synth_batch(300 + 40 * i, 50 + i, "cpu")  # [o d near far depth_gt depth_w], ts, sky-or-0, rgb
         n = rays.shape[0]
         row = np.zeros((n, 13), dtype=np.float32)
         row[:, :8] = rays[:, :8].numpy()
@@ -89,3 +89,34 @@ def test_train_driver_runs_refreshes_the_octree_and_resumes(tmp_path):
                         timeout=600)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
     assert "step 7 " in r2.stdout and "step 8 " in r2.stdout and "step 6 " not in r2.stdout
+
+
+def test_two_ranks_with_unequal_caches_run_the_same_number_of_steps(tmp_path):
+    """World size 2 (both ranks on GPU 0, gloo): three chunks of different length -> `_get_local_split` pads to four, the
+    black-list prefilter removes different numbers of rays per rank, so the ranks' caches differ in length.  Every rank must
+    run the same number of steps (all-reduce MIN of len(cache) // batch_size) or the one that finishes first strands the
+    other in the gradient all-reduce and last.ckpt is never written (the reference pads its chunks and filters inside the
+    batch: datasets/data.py:83-119)."""
+    import socket
+
+    root = str(tmp_path / "scene")
+    cfg = _write_scene(root, n_chunks=3)
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, NCW_DIST_BACKEND="gloo", NCW_TRAIN_ONE_GPU_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "scripts", "train.py"), "--cfg_path", cfg, "--batch_size", "64",
+           "--num_epochs", "1", "--exp_name", "ddp", "--prec", "f16", "--log_every", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    fin = [l for l in r.stdout.splitlines() if "finished after" in l]
+    assert len(fin) == 2, r.stdout[-2000:]
+    steps = {int(l.split("finished after ")[1].split(" steps")[0]) for l in fin}
+    resident = [int(l.split("with ")[1].split(" rays")[0]) for l in fin]
+    assert len(steps) == 1 and resident[0] != resident[1], (fin,)  # unequal caches, equal step counts
+    assert min(resident) // 64 == steps.pop()
+    assert os.path.isfile(os.path.join(root, "ckpts", "ddp", "last.ckpt"))
