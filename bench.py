@@ -332,6 +332,17 @@ def bench_grid512(args, nw, L, dev, world, rank):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    plain = None
+    if prec == nw.PREC_F16 and net.split_value(prec):  # the same sweep without the split-precision value path (4e-4 SDF error)
+        net.sdf_split = False
+        sweep()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sweep()
+        torch.cuda.synchronize()
+        plain = {"ms_per_sweep": (time.perf_counter() - t1) * 1e3, "note": "NEUCONW_SDF_SPLIT=0: one fp16 rounding per operand, "
+                 "SDF error 4-6e-4 (moves the zero level set by a tenth of a 512^3 voxel) instead of 5-9e-7"}
+        net.sdf_split = None
     macs = {256: 459008, 512: 1835520}[W]
     pts_s = total * K / dt
     peak = PEAK_BF16_TFLOPS if prec != nw.PREC_F32 else 157.3  # fp16 MFMA peak = bf16 peak
@@ -345,7 +356,8 @@ def bench_grid512(args, nw, L, dev, world, rank):
             "config": {"workload": "512^3 = 134,217,728 grid points, SDF 8x%d sdf-only inference, coordinates from the linear "
                                    "index on the chip, %d-point launches, contiguous 1/%d slice per rank" % (W, chunk, world),
                        "points_per_rank": per, "sdf_precision_note": "the product default for this path is fp32 "
-                       "(NEUCONW_INFER_PREC); this row times --prec"},
+                       "(NEUCONW_INFER_PREC); this row times --prec; fp16 = the split-precision value path (fp32-level SDF "
+                       "values, 3x the MFMAs: `frac` counts algorithmic FLOPs)", "plain_f16": plain},
             "roofline": {"kernel": "ncw_sdf_infer_points", "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                          "algorithmic_mflop_per_point": round(2.0 * macs / 1e6, 3)},

@@ -55,12 +55,24 @@ class _RenderFn(torch.autograd.Function):
             select = None
             if rdr.trim_sphere and not rdr.bg_dense and nerf.supports_selection(prec):
                 select = (z, M - S)
-            density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select)
+            # The background NeRF is independent of the SDF / colour chain until the compositor: with `bg_stream` (a
+            # second HIP stream, renderer.use_bg_stream) its launches overlap the ramps, tails and partial last rounds of the
+            # SDF / colour launches (1056 workgroups of 128 background points = 4.125 rounds of 256 CUs: the fifth round
+            # keeps 32 CUs busy) instead of queueing behind them.
+            side = rdr._bg_stream(dev) if rdr.use_bg_stream else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select)
+            else:
+                density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select)
             density, bg_rgb = density.view(R, M), bg_rgb.view(R, M, 3)
         pts_in = points_struct(rays_o=rays_o, rays_d=rays_d, z=z, sample_dist=sample_dist, mode=2)
         sdf, grad, sctx = neuconw.sdf_net.fwd_stash(pts_in, R * S, prec)
         feat_ptr = sctx["arena"].ptr(sctx["ids"]["feat"])
         rgb, cctx = neuconw.color_net.fwd_stash(pts_in, R * S, prec, grad, a_det, feat_ptr)
+        if use_bg and rdr.use_bg_stream:
+            torch.cuda.current_stream(dev).wait_stream(rdr._bg_stream(dev))  # join before the compositor
         comp = rayops.CompositeCtx(rays_o, rays_d, z, sample_dist, sdf.view(R, S), grad.view(R, S, 3),
                                    rgb.view(R, S, 3), inv_s, cos_anneal, z_feed, density, bg_rgb, background_rgb,
                                    rdr.trim_sphere)
@@ -104,6 +116,17 @@ class _RenderFn(torch.autograd.Function):
         # instead of f32 atomics (the weight-gradient split-K is order-fixed in fp32 too, stash.WgradBatch.run)
         ordered = rdr.reproducible if rdr.reproducible is not None else (prec == L.PREC_F32)
         lib = L.get_lib()
+        M = comp.S + comp.O
+        # the background backward on the second stream (see forward): issued BEFORE the colour / SDF backward of the main
+        # stream so that both are in flight together; joined before the weight-gradient launch.  (Atomics path only: the
+        # order-fixed d_a_rows reduction of the reproducible mode stays on one stream.)
+        side = rdr._bg_stream(dev) if (ctx.use_bg and rdr.use_bg_stream and not ordered) else None
+        d_a_bg = None
+        if side is not None:
+            d_a_bg = torch.zeros(ctx.a_shape, device=dev, dtype=torch.float32)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                nerf.bwd_stash(nctx, g["d_density"].view(R * M), g["d_bg_rgb"].view(R * M, 3), d_a_bg)
         if ordered:
             d_a = torch.empty(ctx.a_shape, device=dev, dtype=torch.float32)
             rows = torch.empty(R * S, n_a, device=dev, dtype=torch.float32)
@@ -114,8 +137,11 @@ class _RenderFn(torch.autograd.Function):
             neuconw.color_net.bwd_stash(cctx, g["d_rgb"].view(R * S, 3), d_grad, d_a, dfeat_ptr)
         neuconw.sdf_net.bwd_stash(sctx, g["d_sdf"].view(R * S), d_grad)
         plans = [sctx["plan"], cctx["plan"]]
-        if ctx.use_bg:
-            M = comp.S + comp.O
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+            d_a.add_(d_a_bg)
+            plans.append(nctx["plan"])
+        elif ctx.use_bg:
             if ordered:
                 # with the elimination only the selected samples write their row (at the ray sample's slot): the others
                 # are the exact zeros the dense evaluation would have produced (their cotangents are zero)
@@ -317,12 +343,24 @@ class NeuconWRenderer:
         # _RenderFn.backward.  `grad_scale` (property) reads / sets it; trainer.FlatAdam adapts it (halves after a step
         # with a non-finite gradient norm, doubles after `growth_interval` clean steps).
         self.loss_scale = LossScale(float(os.environ.get("NEUCONW_F16_LOSS_SCALE", "1024")))
+        # use_bg_stream: run the background NeRF's launches on a second HIP stream beside the SDF / colour chain (forward and
+        # backward; joined before the compositor / the weight-gradient launch).  NEUCONW_BG_STREAM=0 keeps one stream.
+        self.use_bg_stream = os.environ.get("NEUCONW_BG_STREAM", "1") not in ("0", "")
         # sync_free=True keeps render() free of device->host synchronisations (see sfm_depth_loss below);
         # the default reproduces the reference's output shapes exactly.
         self.sync_free = False
         # reproducible: None = on in fp32 (the parity mode is bitwise run-to-run reproducible), off in bf16 (f32 atomics
         # for the appearance-code gradient); True / False force it
         self.reproducible = None
+
+    def _bg_stream(self, device):
+        st = self.__dict__.get("_bg_streams")
+        if st is None:
+            st = self._bg_streams = {}
+        key = str(device)
+        if key not in st:
+            st[key] = torch.cuda.Stream(device=device)
+        return st[key]
 
     # ---- sampler (renderer.py:458-568, under no_grad) -------------------------------------------
     def _sdf_rays(self, rays_o, rays_d, z):
