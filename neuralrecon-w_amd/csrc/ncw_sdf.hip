@@ -412,6 +412,18 @@ int NCW_FN(ncw_sdf_fwd16_launch)(const NcwSdfNet* net, const NcwPoints& src, int
                                  const NcwSdfStash& stash, hipStream_t st);
 int NCW_FN(ncw_sdf_bwd16_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, const float* d_sdf, const float* d_grad,
                                  const NcwSdfStash& stash, hipStream_t st);
+// W = 512, exact fp32 (the parity mode at the shipped width): the same structure with f32 MFMAs (ncw_sdf16f.hip)
+#ifndef NCW_HALF_F16
+int ncw_sdf_infer16f_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st);
+int ncw_sdf_fwd16f_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
+                          hipStream_t st);
+int ncw_sdf_bwd16f_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, const float* d_sdf, const float* d_grad,
+                          const NcwSdfStash& stash, hipStream_t st);
+static bool sdf16f_on(const NcwSdfNet* net, int prec) { return net->rb == 16 && prec == NCW_PREC_F32 && net->n_layers >= 3; }
+#else
+static bool sdf16f_on(const NcwSdfNet*, int) { return false; }
+#endif
+
 static bool sdf16_on(const NcwSdfNet* net, int prec) {
     return net->rb == 16 && prec == NCW_PREC_BF16 && net->n_layers >= 3;
 }
@@ -442,6 +454,9 @@ static int sdf_infer_any(const NcwSdfNet* net, int prec, const NcwPoints& src, i
         return net->rb == 16 ? ncw_sdf_inferS16_launch_f16(net, src, n, sdf, st) : ncw_sdf_inferS_launch_f16(net, src, n, sdf, st);
 #endif
     if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_infer16_launch)(net, src, n, sdf, st);
+#ifndef NCW_HALF_F16
+    if (sdf16f_on(net, prec)) return ncw_sdf_infer16f_launch(net, src, n, sdf, st);
+#endif
     // W = 256, 16-bit: the fine-interleaved kernel of ncw_pp.hip (0.165 ms per 131,072 points; round 2's burst kernel 0.198,
     // the weights-through-LDS kernel below -- fp32 and the other widths -- 0.26)
     if (net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3 && net->n_layers <= 12)
@@ -500,6 +515,9 @@ extern "C" int NCW_FN(ncw_sdf_fwd)(const NcwSdfNet* net, int prec, const NcwPoin
     if (net->rb == 8 && prec == NCW_PREC_BF16 && net->n_layers >= 3)
         return NCW_FN(ncw_sdf_fwd8_launch)(net, *pts, n, sdf, grad, *stash, st);
     if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_fwd16_launch)(net, *pts, n, sdf, grad, *stash, st);
+#ifndef NCW_HALF_F16
+    if (sdf16f_on(net, prec)) return ncw_sdf_fwd16f_launch(net, *pts, n, sdf, grad, *stash, st);
+#endif
     NCW_SDF_DISPATCH(sdf_fwd_kernel, *net, *pts, n, sdf, grad, *stash);
     return 0;
 }
@@ -512,6 +530,9 @@ extern "C" int NCW_FN(ncw_sdf_bwd)(const NcwSdfNet* net, int prec, const NcwPoin
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (sdf16_on(net, prec)) return NCW_FN(ncw_sdf_bwd16_launch)(net, *pts, n, d_sdf, d_grad, *stash, st);
+#ifndef NCW_HALF_F16
+    if (sdf16f_on(net, prec)) return ncw_sdf_bwd16f_launch(net, *pts, n, d_sdf, d_grad, *stash, st);
+#endif
     NCW_SDF_DISPATCH(sdf_bwd_kernel, *net, *pts, n, d_sdf, d_grad, *stash);
     return 0;
 }

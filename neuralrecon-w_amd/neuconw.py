@@ -76,12 +76,14 @@ def _prec_of(v):
 
 def default_prec():
     """Precision of the TRAINING passes (the three MLPs forward/backward, the sampler's SDF queries): NEUCONW_PREC =
-    f16 (default) | bf16 | f32.  fp16 and bf16 run the same kernels at the same speed (csrc/ncw_common.h: one source,
-    compiled per 16-bit type); fp16's 10 mantissa bits put the rendered outputs within 1-4e-4 of the fp64 oracle where
-    bf16 is at 3-7e-3 (tests/test_gpu_fullsize.py), at the price of fp16's range: the backward runs under a 2^10 loss
-    scale (renderer.grad_scale) and the optimiser skips a step whose gradient norm is not finite.  Everything in the
-    path is bounded well inside +-65504 (points in the unit sphere, weight-normed layers, f32 outputs and accumulators);
-    bf16 stays available for scenes where that is in doubt, f32 is the <= 1e-4 parity mode."""
+    f16 (default) | bf16 | f32.  fp16 and bf16 run the same kernels (csrc/ncw_common.h: one source, compiled per 16-bit
+    type); in fp16 the SDF VALUE chain additionally runs in split precision at W = 256 / 512 (SDFNetwork.split_value: fp16
+    hi + lo operand pairs, fp32-like SDF values), which is what keeps the rendered outputs within 1e-4 of the fp64 oracle
+    where NeuS trains (inv_s in the hundreds; bf16: 1e-2 .. 6e-2, tests/test_gpu_fullsize.py), at the price of fp16's
+    range: the backward runs under a dynamic loss scale (renderer.loss_scale, adapted by trainer.FlatAdam) and the
+    optimiser skips a step whose gradient norm is not finite.  Everything in the path is bounded well inside +-65504
+    (points in the unit sphere, weight-normed layers, f32 outputs and accumulators); bf16 stays available for scenes
+    where that is in doubt, f32 is the bitwise reproducible parity mode."""
     import os
 
     return _prec_of(os.environ.get("NEUCONW_PREC", "f16"))
