@@ -26,6 +26,9 @@ MLP_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee", "-fno-slp-vectorize"]
 MLP_FILES = {"ncw_pp.hip"}
 if "NCW_MLP_FLAGS" in os.environ:  # A/B builds (scripts/): e.g. NCW_MLP_FLAGS="" NCW_BUILD_TAG=plain
     MLP_FLAGS = os.environ["NCW_MLP_FLAGS"].split()
+# second flag group (A/B builds): NCW_FLAGS2 applied to the files listed in NCW_FILES2
+FLAGS2 = os.environ.get("NCW_FLAGS2", "").split()
+FILES2 = set(os.environ.get("NCW_FILES2", "").split())
 
 
 # The fp16 mode (NCW_PREC_F16) is the SAME source compiled a second time with the 16-bit type switched (ncw_common.h:
@@ -52,7 +55,7 @@ def _compile(job):
     srcp = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), _deps_mtime()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + (MLP_FLAGS if src in MLP_FILES else []) + (["-DNCW_HALF_F16"] if f16 else [])
+    cmd = [HIPCC] + FLAGS + (MLP_FLAGS if src in MLP_FILES else []) + (FLAGS2 if src in FILES2 else []) + (["-DNCW_HALF_F16"] if f16 else [])
     cmd += ["-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
