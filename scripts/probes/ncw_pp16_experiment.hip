@@ -1,3 +1,7 @@
+// EXPERIMENT RECORD, not part of the library (profiles/r03/pp16_experiment.log).  To rebuild it: copy into
+// neuralrecon-w_amd/csrc/ as ncw_pp16.hip, add it to MLP_FILES / F16_FILES in build.py and dispatch ncw_sdf_infer16P_launch from
+// sdf_infer_any (ncw_sdf.hip).  8 waves (default): results identical to sdf_infer16.  -DP16_NWAVES=4: TIMING ONLY (its results were
+// wrong, not debugged).  NCW_P16_EXP selects the elimination variants.
 // Fine-interleaved SDF kernels at W = 512 (the width the reference ships), 16-bit operands: the streamed-weights structure of
 // ncw_sdf16.hip (wave w owns output blocks w and w + 8, its A fragments come from the packed matrix in L2 through a small register
 // ring, the activations live in LDS as B fragments and are rewritten in place) with the software pipeline of ncw_pp.hip on top.
