@@ -397,6 +397,24 @@ NCW_DEV void load_bias(CVec<RB>& acc, const float* __restrict__ bp, int lane) {
 // ---------------------------------------------------------------------------------------------
 // Softplus(beta=100) with torch's threshold 20 (models/neuconw.py:261) and its derivative
 // sigma(100 z) (exactly 1 above the threshold).  FAST selects hardware exp2/log2.
+// max(x, 0) as ONE integer max on the bit pattern (negative floats are negative integers, -0 -> +0): under the default IEEE
+// mode `fmaxf(x, 0)` on an MFMA result costs two instructions (the compiler quiets the input with v_max x, x first).  Differs from
+// fmaxf only for NaNs (a positive NaN stays a NaN instead of becoming 0 -- it then reaches the non-finite check of the optimiser).
+NCW_DEV float ncw_relu(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// A 16-byte fragment of a packed matrix for this lane: uniform base (SALU) + zero-extended 32-bit lane offset = the SGPR-base form
+// of global_load (a signed lane index makes the compiler build a 64-bit VGPR address with 2-3 VALU per load).  `frag` = index of
+// the 1 KiB fragment (64 lanes x 16 B) in the matrix.
+template <class V>
+NCW_DEV V ncw_ld_frag(const void* w, size_t frag, int lane) {
+    typedef const __attribute__((address_space(1))) V* gp;
+    const char* base = (const char*)w + frag * (64 * sizeof(V));
+    return *(gp)(base + (unsigned)lane * (unsigned)sizeof(V));
+}
+
 template <bool FAST>
 NCW_DEV void softplus100(float z, float& y, float& s) {
     if (FAST) {
@@ -409,7 +427,7 @@ NCW_DEV void softplus100(float z, float& y, float& s) {
         const float t = z * 144.26950408889634f;  // 100 z log2(e)
         const float w = __builtin_amdgcn_exp2f(-__builtin_fabsf(t));
         const float l = __builtin_amdgcn_logf(1.f + w);  // log2(1 + w)
-        y = __builtin_fmaf(l, 0.6931471805599453f * 0.01f, __builtin_fmaxf(z, 0.f));
+        y = __builtin_fmaf(l, 0.6931471805599453f * 0.01f, ncw_relu(z));
         s = 1.f - __builtin_amdgcn_exp2f(y * -144.26950408889634f);
     } else {
         const float bz = 100.f * z;

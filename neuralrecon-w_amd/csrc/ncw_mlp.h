@@ -137,7 +137,7 @@ NCW_DEV void relu_epilogue(Act<P, RB>& act, CVec<RB>& acc, typename P::selem* st
     for (int rb = 0; rb < RB; ++rb) {
         f32x16 yv;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) yv[r] = fmaxf(acc.v[rb][r], 0.f);
+        for (int r = 0; r < 16; ++r) yv[r] = ncw_relu(acc.v[rb][r]);
         if (st) stash_store_block(st, tile, RB, rb, yv, lane);
         to_act_block<RB>(act, rb, yv);
     }
@@ -213,7 +213,7 @@ struct ReluB {
         if (rb >= RB) return;
         f32x16 yv;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) yv[r] = fmaxf(z.v[rb][r], 0.f);
+        for (int r = 0; r < 16; ++r) yv[r] = ncw_relu(z.v[rb][r]);
         if (st) stash_store_block(st, tile, RB, rb, yv, lane);
         to_act_block<RB>(act, rb, yv);
     }

@@ -38,8 +38,7 @@ typedef __attribute__((address_space(3))) f32x4 pp_lf4;
 
 // One k-unit (1 KiB: 64 lanes x 16 B) of a packed matrix, global -> registers
 NCW_DEV bf16x8 pp_load_unit(const void* w, int unit_index, int lane) {
-    typedef const __attribute__((address_space(1))) bf16x8* gp;
-    return ((gp)w)[(size_t)unit_index * 64 + lane];
+    return ncw_ld_frag<bf16x8>(w, (size_t)unit_index, lane);
 }
 
 template <int NU>

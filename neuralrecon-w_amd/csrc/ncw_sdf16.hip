@@ -35,7 +35,7 @@ typedef const __attribute__((address_space(1))) bf16x8* s16_gfrag;
 struct S16W { bf16x8 f[S16_D][2]; };  // register ring: units q .. q + D - 1 of the wave's two output blocks
 
 NCW_DEV bf16x8 s16_ld(const void* w, int rb_stride, int ob, int u, int lane) {
-    return ((s16_gfrag)w)[((size_t)u * rb_stride + ob) * 64 + lane];
+    return ncw_ld_frag<bf16x8>(w, (size_t)u * rb_stride + ob, lane);
 }
 
 // the first S16_D units of a matrix (issued a layer ahead: they land during the previous epilogue and the barriers)

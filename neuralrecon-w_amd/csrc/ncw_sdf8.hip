@@ -33,10 +33,8 @@ typedef __attribute__((address_space(3))) bf16x8 sb_lfrag;
 
 template <int NU>
 NCW_DEV void sb_load_slice(bf16x8* a, const void* w, int rb_stride, int ob, int u0, int lane) {
-    typedef const __attribute__((address_space(1))) bf16x8* gp;
-    gp g = (gp)w + lane;
 #pragma unroll
-    for (int q = 0; q < NU; ++q) a[q] = g[((size_t)(u0 + q) * rb_stride + ob) * 64];
+    for (int q = 0; q < NU; ++q) a[q] = ncw_ld_frag<bf16x8>(w, (size_t)(u0 + q) * rb_stride + ob, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -348,7 +346,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
     auto relu16 = [](const f32x16& v) {
         f32x16 y;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = fmaxf(v[r], 0.f);
+        for (int r = 0; r < 16; ++r) y[r] = ncw_relu(v[r]);
         return y;
     };
     // ---- trunk layer 0 (K = 84: the 6 units of gamma(p)) ---------------------------------------------------

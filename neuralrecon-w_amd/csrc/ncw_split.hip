@@ -33,8 +33,7 @@ constexpr int SB_ACT = SS_TILES * 16 * 1024;      // the adjoint sweep's plain b
 typedef __attribute__((address_space(3))) bf16x8 ss_lfrag;
 
 NCW_DEV bf16x8 ss_gload(const void* w, size_t unit, int lane) {
-    typedef const __attribute__((address_space(1))) bf16x8* gp;
-    return ((gp)w)[unit * 64 + lane];
+    return ncw_ld_frag<bf16x8>(w, (size_t)unit, lane);
 }
 
 // units [u0, u0 + NU) of output block ob of a packed matrix (hi) and of its residual matrix (lo)
