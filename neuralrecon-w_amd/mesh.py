@@ -7,7 +7,8 @@ mc_tables.py) -> vertex welding with torch.unique -> optional colour pass -> bin
 (one linear zero crossing per sign-changing grid edge of the enabled cubes: tests/test_gpu_mesh.py checks it edge by
 edge); skimage's triangulation of the ambiguous cube configurations (Lewiner) is not reproducible without skimage, which
 is neither in the reference tree nor installable: **triangulation parity is unpinned** there.  Also kept: the `mask`
-semantics and the coordinate chain `verts * voxel_size + vol_origin`, `* scene_radius + scene_origin` (:116-117).
+semantics, the sparse mode (`gen_grid_spc`, tools/extract_mesh.py:60-102: SDF only inside the occupied octree voxels, cubes with
+all 8 corners evaluated) and the coordinate chain `verts * voxel_size + vol_origin`, `* scene_radius + scene_origin` (:116-117).
 Normals / winding point towards increasing SDF (outwards).
 """
 import struct
@@ -84,20 +85,86 @@ def vertex_colors(renderer, verts_training, embedding_a, chunk=1 << 16):
 
 
 @torch.no_grad()
+def gen_grid_spc(octree_data, eval_level):
+    """tools/extract_mesh.py:60-102 `gen_grid_spc` on the device: the lower corners of the level-`eval_level` sub-voxels of
+    the occupied voxels of the training octree (`voxel.octree_from_sfm`), in SfM coordinates.  Same arithmetic and dtypes as the
+    reference: index * voxel in float32, + float64 volume origin, (float32 downstream).  Returns the reference's `sparse_data`
+    dict (sparse_vol [K,3] float64 tensor on the GPU, voxel_size / vol_origin as numpy float64, dim)."""
+    from . import voxel
+
+    level = int(octree_data["level"])
+    dense = voxel.dense_from_occupancy(octree_data)           # convert_to_dense(octree, level)
+    dev = dense.device
+    low_dim = dense.shape[0]
+    sparse_ind = torch.nonzero(dense)                         # [n,3], lexicographic in (x,y,z)
+    up_level = int(eval_level) - level
+    if up_level < 0:
+        raise ValueError("eval_level %d below the octree level %d" % (eval_level, level))
+    up_times = 2 ** up_level
+    eval_dim = int(low_dim * up_times)
+    k = torch.arange(0, up_times, device=dev)
+    up_kernel = torch.stack(torch.meshgrid(k, k, k, indexing="ij"), dim=-1).reshape(-1, 3)
+    ind_up = sparse_ind.repeat_interleave(up_times ** 3, dim=0) * up_times + up_kernel.repeat([sparse_ind.shape[0], 1])
+    octree_scale = np.float64(octree_data["scale"])
+    so = octree_data["scene_origin"]
+    octree_origin = np.asarray(so.detach().cpu().numpy() if torch.is_tensor(so) else so, dtype=np.float64).reshape(3)
+    eval_voxel_size = 2 / (2 ** int(eval_level)) * octree_scale                       # :91
+    vol_origin = octree_origin - octree_scale                                         # :92
+    xyz_sfm = (ind_up * float(eval_voxel_size)).double() + torch.from_numpy(vol_origin).to(dev)  # :94 (f32 product, f64 sum)
+    return {"sparse_vol": xyz_sfm, "voxel_size": eval_voxel_size, "dim": eval_dim, "vol_origin": vol_origin}
+
+
+@torch.no_grad()
+def sparse_volume(sparse_data, sdf_values):
+    """utils/visualization.py:51-56,91-110: scatter the SDF of the sparse points into a dense [dim]^3 volume of ones and build
+    the cube mask -- a grid point is valid iff it and its 7 lower neighbours were evaluated (the reference's rolls, wrap-around
+    included).  Returns (sdf_dense, mask, ind)."""
+    sparse_vol = sparse_data["sparse_vol"].float()
+    dev = sparse_vol.device
+    dim = int(sparse_data["dim"])
+    vo64 = torch.from_numpy(np.asarray(sparse_data["vol_origin"], dtype=np.float64)).to(dev)
+    ind = torch.round((sparse_vol - vo64) / float(sparse_data["voxel_size"])).long()  # :51 (float64 like the reference)
+    sdf_dense = torch.ones(dim, dim, dim, device=dev, dtype=torch.float32)
+    sdf_dense[ind[:, 0], ind[:, 1], ind[:, 2]] = sdf_values.reshape(-1).float()
+    m = torch.zeros(dim, dim, dim, device=dev, dtype=torch.bool)
+    m[ind[:, 0], ind[:, 1], ind[:, 2]] = True
+    m = (m & torch.roll(m, shifts=1, dims=0) & torch.roll(m, shifts=1, dims=1) & torch.roll(m, shifts=1, dims=2)
+         & torch.roll(m, shifts=[1, 1], dims=[0, 1]) & torch.roll(m, shifts=[1, 1], dims=[0, 2])
+         & torch.roll(m, shifts=[1, 1], dims=[1, 2]) & torch.roll(m, shifts=[1, 1, 1], dims=[0, 1, 2]))
+    return sdf_dense, m, ind
+
+
+@torch.no_grad()
 def extract_mesh(renderer, dim, scene_radius, scene_origin, origin=None, radius=1.0, with_color=False, embedding_a=None,
-                 level=0.0, chunk_rgb=1 << 16):
-    """utils/visualization.py:37-159 (dense path).  Returns dict(vertices [V,3] world coordinates, faces [F,3],
-    vertices_training, colors [V,3] uint8 or None) as GPU tensors."""
-    origin = [0.0, 0.0, 0.0] if origin is None else [float(v) for v in origin]
-    lo = tuple(o - radius for o in origin)
-    hi = tuple(o + radius for o in origin)
-    sdf = _grid.sdf_grid(renderer.neuconw.sdf_net, dim, lo, hi, prec=renderer.infer_prec).view(dim, dim, dim)
-    verts, faces = isosurface(sdf, level)
-    voxel_size = 2 * radius / (dim - 1)                                      # :44
-    vol_origin = torch.tensor(lo, device=verts.device, dtype=torch.float32)  # :43
-    verts_t = verts * voxel_size + vol_origin                                # :116
-    so = torch.as_tensor(np.asarray(scene_origin, dtype=np.float32), device=verts.device).reshape(3)
-    verts_w = verts_t * float(scene_radius) + so                             # :117
+                 level=0.0, chunk_rgb=1 << 16, sparse_data=None, chunk=1 << 22, group=None):
+    """utils/visualization.py:37-159.  Dense path: the [dim]^3 lattice over `origin` +- `radius` (training coordinates), swept
+    on chip and sharded over the ranks (grid.sdf_grid).  Sparse path (`sparse_data` from gen_grid_spc): the SDF only at the
+    sub-voxels of the occupied octree voxels (sharded like neuconw_system.py:236-256), marching cubes under the all-8-corners
+    mask.  Returns dict(vertices [V,3] world coordinates, faces [F,3], vertices_training, colors [V,3] uint8 or None) as GPU
+    tensors, on every rank (the reference returns the mesh on rank 0 only)."""
+    dev = next(renderer.neuconw.parameters()).device
+    so = torch.as_tensor(np.asarray(scene_origin, dtype=np.float32), device=dev).reshape(3)
+    if sparse_data is None:
+        origin = [0.0, 0.0, 0.0] if origin is None else [float(v) for v in origin]
+        lo = tuple(o - radius for o in origin)
+        hi = tuple(o + radius for o in origin)
+        sdf = _grid.sdf_grid(renderer.neuconw.sdf_net, dim, lo, hi, prec=renderer.infer_prec, group=group).view(dim, dim, dim)
+        verts, faces = isosurface(sdf, level)
+        voxel_size = 2 * radius / (dim - 1)                                      # :44
+        vol_origin = torch.tensor(lo, device=dev, dtype=torch.float32)           # :43
+    else:
+        from . import voxel
+
+        sparse_vol = sparse_data["sparse_vol"].to(dev).float()
+        xyz = ((sparse_vol - so) / float(scene_radius)).contiguous()             # :58
+        sdf_sparse = voxel._sdf_sharded(renderer, xyz, int(chunk), group)
+        sdf, mask, _ = sparse_volume(dict(sparse_data, sparse_vol=sparse_vol), sdf_sparse)
+        verts, faces = isosurface(sdf, level, mask)
+        vo_sfm = torch.from_numpy(np.asarray(sparse_data["vol_origin"], dtype=np.float64)).float().to(dev)  # :53
+        vol_origin = (vo_sfm - so) / float(scene_radius)                         # :59
+        voxel_size = float(sparse_data["voxel_size"]) / float(scene_radius)      # :61
+    verts_t = verts * voxel_size + vol_origin                                    # :116
+    verts_w = verts_t * float(scene_radius) + so                                 # :117
     colors = None
     if with_color:
         colors = vertex_colors(renderer, verts_t, embedding_a, chunk_rgb).clamp(0, 255).to(torch.uint8)
