@@ -525,6 +525,9 @@ NCW_DEV void freq_encode(CVec<RB>& out, const float (&x)[D], int lane) {
 // ---------------------------------------------------------------------------------------------
 template <int RB>
 NCW_DEV void stash_store(float* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
+#ifdef NCW_EXP_NOSTORE
+    return;
+#endif
     f32x4* p = reinterpret_cast<f32x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -538,6 +541,9 @@ NCW_DEV void stash_store(float* __restrict__ base, size_t tile, const CVec<RB>& 
 }
 template <int RB>
 NCW_DEV void stash_store(ncw_h16* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
+#ifdef NCW_EXP_NOSTORE
+    return;
+#endif
     bf16x4* p = reinterpret_cast<bf16x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -551,6 +557,13 @@ NCW_DEV void stash_store(ncw_h16* __restrict__ base, size_t tile, const CVec<RB>
 }
 template <int RB>
 NCW_DEV void stash_load(CVec<RB>& c, const float* __restrict__ base, size_t tile, int lane) {
+#ifdef NCW_EXP_NOLOAD
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c.v[rb][q] = 0.37f + 0.01f * q;
+    return;
+#endif
     const f32x4* p = reinterpret_cast<const f32x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -563,6 +576,13 @@ NCW_DEV void stash_load(CVec<RB>& c, const float* __restrict__ base, size_t tile
 }
 template <int RB>
 NCW_DEV void stash_load(CVec<RB>& c, const ncw_h16* __restrict__ base, size_t tile, int lane) {
+#ifdef NCW_EXP_NOLOAD
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c.v[rb][q] = 0.37f + 0.01f * q;
+    return;
+#endif
     const bf16x4* p = reinterpret_cast<const bf16x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
