@@ -11,7 +11,6 @@ import torch
 import torch.distributed as dist
 
 from . import lib as L
-from .neuconw import default_infer_prec
 
 
 def local_range(total, rank, world):
@@ -24,7 +23,7 @@ def local_range(total, rank, world):
 def sdf_grid_range(sdf_net, dim, bound_min, bound_max, start, count, origin=(0.0, 0.0, 0.0), radius=1.0, prec=None,
                    chunk=1 << 24, out=None):
     """sdf of grid points [start, start+count) of linspace(bound_min, bound_max, dim)^3 ('ij', x slowest)."""
-    prec = default_infer_prec() if prec is None else prec
+    prec = sdf_net.value_prec() if prec is None else prec
     dev = next(sdf_net.parameters()).device
     if dev.type != "cuda":
         raise L.NeuconwHipError("sdf_grid needs the network on a GPU")

@@ -90,10 +90,11 @@ def default_prec():
 
 
 def default_infer_prec():
-    """Precision of the geometry-critical inference-only entry points (`sdf()`, `gradient()`, `NeuconW.forward`,
-    grid.sdf_grid, voxel.surface_selection, mesh.extract_mesh): fp32 like the reference evaluates them, unless
-    NEUCONW_INFER_PREC says otherwise.  bf16 SDF values carry ~5e-3 absolute error (tests/test_gpu_sdf.py), which
-    moves a zero level set / an `sdf <= threshold` selection by a fraction of a 512^3 voxel (~4e-3)."""
+    """Precision of the geometry-critical inference-only entry points (`gradient()`, `NeuconW.forward` / `renderer.rgb`, and
+    `sdf()` / grid.sdf_grid / voxel.surface_selection / mesh.extract_mesh at widths without a split-precision value path): fp32
+    like the reference evaluates them, unless NEUCONW_INFER_PREC says otherwise.  bf16 SDF values carry ~5e-3 absolute error
+    (tests/test_gpu_sdf.py), which moves a zero level set / an `sdf <= threshold` selection by a fraction of a 512^3 voxel
+    (~4e-3).  SDF VALUES alone default to `SDFNetwork.value_prec()`."""
     import os
 
     return _prec_of(os.environ.get("NEUCONW_INFER_PREC", "f32"))
@@ -159,6 +160,18 @@ class SDFNetwork(nn.Module):
         if on is None:
             on = os.environ.get("NEUCONW_SDF_SPLIT", "1") not in ("0", "")
         return bool(on) and prec == L.PREC_F16 and self.d_hidden in (256, 512) and self.n_lin >= 3
+
+    def value_prec(self):
+        """Default precision of the VALUE-ONLY evaluations (`sdf()`, the grid sweep, the octree refresh, the mesh lattice):
+        at W = 256 / 512 the split-precision fp16 chain -- SDF values 5-9e-7 of the fp64 oracle, the same as the exact-fp32
+        kernels (tests/test_gpu_sdf.py), 4-6x faster (512^3 at W = 512: 1.35 s against 5.9 s, itself 53 % of the f32 MFMA peak) -- otherwise fp32.
+        NEUCONW_INFER_PREC (f32 / f16 / bf16) overrides."""
+        import os
+
+        env = os.environ.get("NEUCONW_INFER_PREC")
+        if env:
+            return _prec_of(env)
+        return L.PREC_F16 if self.split_value(L.PREC_F16) else L.PREC_F32
 
     def plan(self, prec):
         dev = self.lin0.bias.device
@@ -244,8 +257,8 @@ class SDFNetwork(nn.Module):
     @torch.no_grad()
     def sdf(self, x, prec=None):
         """SDFNetwork.sdf (neuconw.py:281-282): x[..., 3] -> [N, 1]; no autograd (the reference only
-        calls it under no_grad: renderer.py:825, neuconw_system.py:245-249, visualization.py:75-80)."""
-        prec = default_infer_prec() if prec is None else prec
+        calls it under no_grad: renderer.py:825, neuconw_system.py:245-249, visualization.py:75-80).  prec None = value_prec()."""
+        prec = self.value_prec() if prec is None else prec
         if not x.is_cuda:
             raise L.NeuconwHipError("SDFNetwork.sdf: input is not on a GPU; the hot path has no CPU fallback")
         xf = x.reshape(-1, 3).float().contiguous()

@@ -329,7 +329,8 @@ class NeuconWRenderer:
         self.prec = default_prec() if prec is None else prec
         # inference-only helpers (sdf(), rgb(): octree refresh, grid sweep, mesh colours) run in fp32 like the
         # reference unless told otherwise; the training passes and the sampler follow `prec`
-        self.infer_prec = default_infer_prec() if infer_prec is None else infer_prec
+        # None = the defaults: fp32 for rgb() / NeuconW.forward, SDFNetwork.value_prec() for sdf() and the sweeps built on it
+        self.infer_prec = infer_prec
         if self.n_samples + self.n_importance + (self.boundary_samples or 0) + self.n_outside > 512:
             raise ValueError("n_samples + n_importance + boundary_samples + n_outside = %d > 512: the per-ray kernels keep a "
                              "ray's samples in LDS (RAY_MAXN 512).  Note config/defaults.py's N_SAMPLES = N_IMPORTANCE = "
@@ -554,5 +555,6 @@ class NeuconWRenderer:
 
     def rgb(self, pts, rays_d, a_embedded):
         num_points = pts.shape[0]
-        rgb, _, _, _ = self.neuconw(torch.cat([pts, rays_d, a_embedded], -1), self.infer_prec)
+        rgb, _, _, _ = self.neuconw(torch.cat([pts, rays_d, a_embedded], -1),
+                                    default_infer_prec() if self.infer_prec is None else self.infer_prec)
         return rgb.reshape(num_points, 3)

@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--chunk_rgb", type=int, default=1 << 16, help="vertices per launch of the colour pass")
     ap.add_argument("--ckpt_path", required=True, help="checkpoint in the reference's layout (trainer.save_checkpoint / PL)")
     ap.add_argument("--out_dir", default=None, help="default: results/<dataset_name>/<ckpt dir>_<ckpt name>/mesh")
-    ap.add_argument("--prec", default=None, choices=["bf16", "f16", "f32"], help="default: renderer.infer_prec (fp32)")
+    ap.add_argument("--prec", default=None, choices=["bf16", "f16", "f32"], help="default: fp32 for the colour pass, SDFNetwork.value_prec() for the SDF lattice")
     args = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
