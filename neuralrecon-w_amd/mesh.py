@@ -11,8 +11,6 @@ semantics, the sparse mode (`gen_grid_spc`, tools/extract_mesh.py:60-102: SDF on
 all 8 corners evaluated) and the coordinate chain `verts * voxel_size + vol_origin`, `* scene_radius + scene_origin` (:116-117).
 Normals / winding point towards increasing SDF (outwards).
 """
-import struct
-
 import numpy as np
 import torch
 

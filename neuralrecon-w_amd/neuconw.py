@@ -12,7 +12,7 @@ from torch import nn
 
 from . import lib as L
 from .packing import PackPlan
-from .stash import StashArena, StashCache, WgradBatch
+from .stash import StashArena, StashCache
 
 
 def points_struct(x=None, rays_o=None, rays_d=None, z=None, sample_dist=None, mode=0, idx=None, count=None):

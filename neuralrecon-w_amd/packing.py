@@ -6,7 +6,6 @@ A plan owns (per precision)
   * a dense f32 gradient arena + descriptor table for ncw_unpack_grads (weight-norm backward).
 Padding is written once (zeros) and never touched again.
 """
-import ctypes as C
 
 import torch
 

@@ -12,13 +12,12 @@ import os
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 import yaml
 
 from . import lib as L
 from . import rayops
 from .neuconw import default_infer_prec, default_prec, points_struct
-from .stash import LeaseGuard, StashCache, WgradBatch
+from .stash import LeaseGuard, WgradBatch
 
 from .labels import LABEL_IDS, label_id as _label_id  # noqa: E402  (ADE20K ids: datasets/mask_utils.py)
 

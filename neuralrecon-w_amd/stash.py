@@ -1,5 +1,4 @@
 """Activation-stash arenas and batched weight-gradient launches (host side)."""
-import ctypes as C
 
 import torch
 

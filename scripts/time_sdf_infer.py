@@ -1,4 +1,4 @@
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import neuralrecon_w_amd as nw
