@@ -129,13 +129,25 @@ class FlatAdam:
     def __init__(self, flat_params, lr, betas=(0.9, 0.999), eps=1e-7, clip=None, loss_scale=None, growth_interval=2000,
                  scale_min=1.0, scale_max=65536.0):
         self.fp = flat_params
-        self.lr, self.betas, self.eps, self.clip = float(lr), (float(betas[0]), float(betas[1])), float(eps), clip
+        # the learning rate is DEVICE data (ncw_adam_step_dev reads `lr_dev` at run time), so a schedule keeps working
+        # when the step is replayed from a HIP graph: assigning `opt.lr` refills the device scalar
+        self.lr_dev = torch.empty(1, device=flat_params.flat_grad.device, dtype=torch.float32)
+        self.lr = float(lr)
+        self.betas, self.eps, self.clip = (float(betas[0]), float(betas[1])), float(eps), clip
         self.exp_avg = torch.zeros_like(flat_params.flat_grad)
         self.exp_avg_sq = torch.zeros_like(flat_params.flat_grad)
         self.state = torch.zeros(8, device=flat_params.flat_grad.device, dtype=torch.int32)  # NcwAdamState
         self.loss_scale, self.growth_interval = loss_scale, int(growth_interval)
         self.scale_min, self.scale_max = float(scale_min), float(scale_max)
-        self.lr_dev = None  # optional device scalar overriding `lr` (a scheduler under graph replay)
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, v):
+        self._lr = float(v)
+        self.lr_dev.fill_(self._lr)  # an ordinary stream-ordered fill: also valid between graph replays
 
     # applied (non-skipped) steps: Adam's t.  Lives on the device; reading it synchronises (checkpoints, tests)
     @property

@@ -128,3 +128,32 @@ def test_flat_adam_matches_torch_adam():
     before = fp.flat.detach().clone()
     opt_t2.step()
     assert torch.allclose(fp.flat.detach(), before - 3e-3, atol=1e-6)  # first Adam step = -lr * sign(g)
+
+
+def test_captured_step_follows_lr_schedule():
+    """The learning rate is device data (FlatAdam.lr_dev): assigning `opt.lr` between HIP-graph replays -- how
+    scripts/train.py applies the per-epoch cosine / steplr schedule (train.py:21-25 `get_scheduler`) -- changes the replayed
+    update.  With lr = 0 from the first replay on, the parameters must stop moving while Adam's step counter keeps
+    advancing; restoring it moves them again."""
+    import neuralrecon_w_amd as nw
+
+    R = 64
+    rays, ts, label, rgbs = [t.cuda() for t in synth_rays(R, seed=13, n_vocab=64)]
+    bg = torch.zeros(1, 3, device="cuda")
+    emb, neuconw, nerf, rdr = build_system(seed=7, prec=nw.PREC_F32)
+    train = nw.TrainStep(rdr, [emb, neuconw, nerf], loss_from_outputs, lr=1e-3, eps=1e-7, clip=0.99, capture=True,
+                         capture_warmup=2)
+    for i in range(4):  # 2 eager + capture/replay + 1 replay at lr 1e-3
+        train(rays, ts, label, rgbs, background_rgb=bg, cos_anneal_ratio=0.1, perturb_overwrite=0)
+    assert train._graphs is not None
+    p0 = train.fp.flat.detach().clone()
+    train.opt.lr = 0.0
+    for i in range(2):
+        train(rays, ts, label, rgbs, background_rgb=bg, cos_anneal_ratio=0.1, perturb_overwrite=0)
+    assert torch.equal(train.fp.flat.detach(), p0), "a replay ignored opt.lr = 0: the capture baked the lr in"
+    assert train.opt.step_count == 6
+    train.opt.lr = 2e-3
+    train(rays, ts, label, rgbs, background_rgb=bg, cos_anneal_ratio=0.1, perturb_overwrite=0)
+    moved = float((train.fp.flat.detach() - p0).abs().max())
+    assert 1e-4 < moved <= 2e-3 * 1.5, moved  # an Adam step is <= ~lr per element
+    assert abs(train.opt.lr - 2e-3) < 1e-12 and abs(float(train.opt.lr_dev) - 2e-3) < 1e-9
