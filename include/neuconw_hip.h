@@ -39,6 +39,9 @@ extern "C" {
 
 /* library / device info; returns the ABI version (bumped on any signature change) */
 int ncw_abi_version(void);
+/* sha256 (hex) of the sources this library was built from (csrc/*.hip, csrc/*.h, this header); the Python binding
+ * refuses a library whose hash differs from the tree's (neuralrecon-w_amd/build.py source_hash) */
+const char* ncw_source_hash(void);
 /* writes "gfx950" style arch name of device 0 into buf; returns CU count (0 if no device) */
 int ncw_device_info(char* buf, int buflen);
 

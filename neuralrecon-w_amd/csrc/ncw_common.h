@@ -523,11 +523,22 @@ NCW_DEV void freq_encode(CVec<RB>& out, const float (&x)[D], int lane) {
 // Stash: fragment-native layout  [tile32][rb][g = r>>2][lane][4]  (each lane stores 4 consecutive
 // features of its point: 8 B bf16 / 16 B f32 per lane, 512 B / 1 KiB per wave-instruction).
 // ---------------------------------------------------------------------------------------------
+// Timing-experiment hooks (stash stores compiled out / stash loads replaced by constants) live in
+// scripts/probes/ncw_exp_hooks.h and exist only in probe libraries built beside the product with NCW_BUILD_TAG
+// (build.py defines NCW_PROBE_BUILD for those and for nothing else): the product library cannot be built with them.
+#ifdef NCW_PROBE_BUILD
+#include "../../scripts/probes/ncw_exp_hooks.h"
+#else
+#if defined(NCW_EXP_NOSTORE) || defined(NCW_EXP_NOLOAD)
+#error "NCW_EXP_* timing hooks are probe-only: build with NCW_BUILD_TAG=<tag> (neuralrecon-w_amd/build.py)"
+#endif
+#define NCW_EXP_STORE_HOOK()
+#define NCW_EXP_LOAD_HOOK(x)
+#endif
+
 template <int RB>
 NCW_DEV void stash_store(float* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
-#ifdef NCW_EXP_NOSTORE
-    return;
-#endif
+    NCW_EXP_STORE_HOOK();
     f32x4* p = reinterpret_cast<f32x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -541,9 +552,7 @@ NCW_DEV void stash_store(float* __restrict__ base, size_t tile, const CVec<RB>& 
 }
 template <int RB>
 NCW_DEV void stash_store(ncw_h16* __restrict__ base, size_t tile, const CVec<RB>& c, int lane) {
-#ifdef NCW_EXP_NOSTORE
-    return;
-#endif
+    NCW_EXP_STORE_HOOK();
     bf16x4* p = reinterpret_cast<bf16x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -557,13 +566,7 @@ NCW_DEV void stash_store(ncw_h16* __restrict__ base, size_t tile, const CVec<RB>
 }
 template <int RB>
 NCW_DEV void stash_load(CVec<RB>& c, const float* __restrict__ base, size_t tile, int lane) {
-#ifdef NCW_EXP_NOLOAD
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) c.v[rb][q] = 0.37f + 0.01f * q;
-    return;
-#endif
+    NCW_EXP_LOAD_HOOK(c);
     const f32x4* p = reinterpret_cast<const f32x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -576,13 +579,7 @@ NCW_DEV void stash_load(CVec<RB>& c, const float* __restrict__ base, size_t tile
 }
 template <int RB>
 NCW_DEV void stash_load(CVec<RB>& c, const ncw_h16* __restrict__ base, size_t tile, int lane) {
-#ifdef NCW_EXP_NOLOAD
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) c.v[rb][q] = 0.37f + 0.01f * q;
-    return;
-#endif
+    NCW_EXP_LOAD_HOOK(c);
     const bf16x4* p = reinterpret_cast<const bf16x4*>(base) + (tile * RB * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)

@@ -79,9 +79,7 @@ NCW_DEV void tile_setup(int64_t n, int64_t& tile, int64_t& p, bool& valid, int l
 // single-block stash store / activation conversion (keeps epilogue register pressure at one block)
 template <class SE>
 NCW_DEV void stash_store_block(SE* __restrict__ base, size_t tile, int RB, int rb, const f32x16& v, int lane) {
-#ifdef NCW_EXP_NOSTORE  // timing experiment (scripts/gpu): no stash stores, the readers see uninitialised memory
-    return;
-#endif
+    NCW_EXP_STORE_HOOK();
     typedef SE vec4 __attribute__((ext_vector_type(4)));
     vec4* p = reinterpret_cast<vec4*>(base) + ((tile * RB + rb) * 4) * 64 + lane;
 #pragma unroll
@@ -94,11 +92,7 @@ NCW_DEV void stash_store_block(SE* __restrict__ base, size_t tile, int RB, int r
 }
 template <class SE>
 NCW_DEV void stash_load_block(f32x16& v, const SE* __restrict__ base, size_t tile, int RB, int rb, int lane) {
-#ifdef NCW_EXP_NOLOAD  // timing experiment: no stash loads
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = 0.37f + 0.01f * q;
-    return;
-#endif
+    NCW_EXP_LOAD_HOOK(v);
     typedef SE vec4 __attribute__((ext_vector_type(4)));
     const vec4* p = reinterpret_cast<const vec4*>(base) + ((tile * RB + rb) * 4) * 64 + lane;
 #pragma unroll

@@ -190,6 +190,7 @@ _PROTOS = {
     "ncw_composite_fwd": (C.c_int, [C.POINTER(NcwCompositeIn), C.POINTER(NcwCompositeOut), _VP]),
     "ncw_composite_bwd": (C.c_int, [C.POINTER(NcwCompositeIn), C.POINTER(NcwCompositeGrad), _VP]),
     "ncw_abi_version": (C.c_int, []),
+    "ncw_source_hash": (C.c_char_p, []),
     "ncw_device_info": (C.c_int, [C.c_char_p, C.c_int]),
     "ncw_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ncw_unpack_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -249,6 +250,15 @@ def get_lib():
     v = lib.ncw_abi_version()
     if v != ABI_VERSION:
         raise NeuconwHipError("libneuconw_hip.so ABI %d != binding ABI %d: rebuild" % (v, ABI_VERSION))
+    # the library must have been built from the sources in this tree (build.source_hash): a stale prebuilt .so -- e.g. one
+    # shipped to a GPU box after csrc/ changed -- is refused, not silently tested.  Probe variants (NEUCONW_HIP_LIB) are exempt.
+    if not os.environ.get("NEUCONW_HIP_LIB") and os.path.isdir(os.path.join(HERE, "csrc")):
+        from . import build as _b
+
+        built, now = lib.ncw_source_hash().decode(), _b.source_hash()
+        if built != now:
+            raise NeuconwHipError("libneuconw_hip.so was built from other sources (%s.. != %s..): rebuild with "
+                                  "`python -c 'import __graft_entry__ as g; g.build()'`" % (built[:12], now[:12]))
     ns._cdll = lib
     _lib = ns
     return ns

@@ -13,7 +13,7 @@ from tests._util import ROOT, load_golden
 
 def _header_symbols():
     src = open(os.path.join(ROOT, "include", "neuconw_hip.h")).read()
-    return sorted(set(re.findall(r"^(?:int|int64_t)\s+(ncw_\w+)\s*\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|int64_t|const char\*)\s+(ncw_\w+)\s*\(", src, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -29,6 +29,38 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, name), "missing export: " + name
     assert sorted(L.exported_symbols()) == declared, "lib.py bindings out of sync with the header"
     assert cdll.ncw_abi_version() == L.ABI_VERSION
+
+
+def test_library_is_built_from_this_tree(monkeypatch):
+    """The shipped .so carries the sha256 of the sources it was built from; the binding recomputes it from csrc/ + include/
+    and refuses a library built from anything else (a GPU box runs the PREBUILT library: this is what ties the kernels under
+    test to the tree).  Also: a different hash is really refused."""
+    from neuralrecon_w_amd import build, lib as L
+
+    cdll = ctypes.CDLL(build.LIB)
+    cdll.ncw_source_hash.restype = ctypes.c_char_p
+    assert cdll.ncw_source_hash().decode() == build.source_hash(), "libneuconw_hip.so is stale: rebuild (__graft_entry__.build())"
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 64)
+    monkeypatch.delenv("NEUCONW_HIP_LIB", raising=False)
+    with pytest.raises(L.NeuconwHipError, match="built from other sources"):
+        L.get_lib()
+    monkeypatch.undo()
+    L.get_lib()  # the real tree loads
+
+
+def test_probe_hooks_cannot_enter_the_product_build():
+    """NCW_EXP_* timing hooks (scripts/probes/ncw_exp_hooks.h) compile only under NCW_BUILD_TAG (a probe library beside the
+    product); csrc/ncw_common.h #errors on them otherwise and build.py refuses the flag."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, NCW_EXTRA_HIPCC_FLAGS="-DNCW_EXP_NOLOAD")
+    env.pop("NCW_BUILD_TAG", None)
+    r = subprocess.run([sys.executable, "-c", "import neuralrecon_w_amd.build"], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "NCW_BUILD_TAG" in r.stderr
+    src = open(os.path.join(ROOT, "neuralrecon-w_amd", "csrc", "ncw_common.h")).read()
+    assert "#error" in src and "NCW_PROBE_BUILD" in src
 
 
 def test_struct_sizes_match_c_layout():
