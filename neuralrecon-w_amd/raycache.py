@@ -10,7 +10,8 @@ Here the rank's chunks are uploaded to HBM ONCE (a brandenburg_gate cache is ten
 batch is one row-gather launch (`ncw_batch_assemble`): no loader workers, no per-step H2D copy.  `prefilter=True`
 additionally removes the black-listed rays once at load time, so every batch has the full, fixed ray count and the
 step stays free of device->host syncs (the reference's per-batch filter yields a data-dependent batch size).
-h5 caches need h5py, which this image does not have: `cache_type="h5"` raises."""
+h5 chunks (the cache writer's default) are read through h5py when it is importable; this image has none, and then an h5
+cache is refused with a message naming the npz alternative."""
 import ctypes as C
 import os
 
@@ -41,6 +42,22 @@ def list_splits(root_dir, cache_dir):
     return next(os.walk(os.path.join(root_dir, cache_dir, "splits")))[1]
 
 
+def _read_chunk(stem, cache_type, key):
+    """One cache chunk as a numpy array.  npz: `arr_0` (phototourism.py:488-490); h5 (the DEFAULT `--cache_type` of
+    tools/prepare_data/prepare_data_cache.py:36-40, datasets `rays` / `rgbs`, phototourism.py:491-495) through h5py when it
+    is importable -- this image has none, and then the refusal says how to get a readable cache."""
+    if cache_type == "npz":
+        return np.load(stem + ".npz")["arr_0"]
+    try:
+        import h5py
+    except ImportError:
+        raise NotImplementedError(
+            "ray cache %s.h5: h5py is not installed here; re-run the reference's prepare_data_cache.py with "
+            "`--cache_type npz` (what config/defaults.py:89 reads) or install h5py" % stem)
+    with h5py.File(stem + ".h5", "r") as f:
+        return np.asarray(f[key][:])
+
+
 class RayCache:
     """The rank's training rays, resident on `device`.
 
@@ -57,12 +74,12 @@ class RayCache:
             raise ValueError("no cache splits assigned to this rank")
         first = os.path.join(root_dir, split_path, names[0])
         cache_type = os.listdir(first)[0].split(".")[-1]  # phototourism.py:478-481
-        if cache_type != "npz":
-            raise NotImplementedError("ray cache type %r: only npz caches are readable here (h5py is not installed)" % cache_type)
+        if cache_type not in ("npz", "h5"):
+            raise NotImplementedError("ray cache type %r: the reference writes npz or h5 chunks" % cache_type)
         rays, rgbs = [], []
         for nme in names:  # phototourism.py:482-513
-            rays.append(torch.from_numpy(np.load(os.path.join(root_dir, split_path, nme, "rays%d.npz" % img_downscale))["arr_0"]))
-            rgbs.append(torch.from_numpy(np.load(os.path.join(root_dir, split_path, nme, "rgbs%d.npz" % img_downscale))["arr_0"]))
+            rays.append(torch.from_numpy(_read_chunk(os.path.join(root_dir, split_path, nme, "rays%d" % img_downscale), cache_type, "rays")))
+            rgbs.append(torch.from_numpy(_read_chunk(os.path.join(root_dir, split_path, nme, "rgbs%d" % img_downscale), cache_type, "rgbs")))
         rays, rgbs = torch.cat(rays, 0), torch.cat(rgbs, 0)
         want = 13 if self.with_semantics else 12
         if rays.shape[1] != want or rgbs.shape[1] != 3 or rays.shape[0] != rgbs.shape[0]:
