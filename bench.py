@@ -155,7 +155,14 @@ def _oracle_setup(sample_rays, seed, variance=None):
     return sd, cfg, batch
 
 
-def cpu_baseline(sample_rays=256, repeats=2, max_threads=32, seed=1000):
+# The timed CPU program is the oracle (kind "port"): the GPU box has no /root/reference.  Its speed relative to the UNMODIFIED
+# reference (rendering/renderer.py render + NeuconWLoss + backward through the double forward + autograd.grad, ~9 M_sdf per
+# sample against the oracle's 6) was calibrated once where both exist (this repo's build container, 8 host threads, the same
+# 256 rays): scripts/diag/port_over_reference.py -> profiles/r04/port_over_reference.json.  None until measured.
+PORT_OVER_REFERENCE = {"value": 1.24, "measured": "profiles/r04/port_over_reference.json: the unmodified reference 1.74 s/step vs the oracle 1.40 s/step on the same 256 rays, 8 threads", "meaning": "reference time / port time: the reference's CPU throughput is this factor BELOW cpu_baseline.value"}
+
+
+def cpu_baseline(sample_rays=256, repeats=3, max_threads=32, seed=1000):
     """The CPU oracle (oracle/neuconw_oracle.py, pinned to the real reference by tests/golden) timed on
     this box's host cores on a bounded sample of the same workload (same nets, same sampler shape).
     Returns (cpu_baseline dict, reference outputs of that sample for the `parity` object)."""
@@ -176,9 +183,11 @@ def cpu_baseline(sample_rays=256, repeats=2, max_threads=32, seed=1000):
         times.append(time.perf_counter() - t0)
     t = sorted(times[1:])[len(times[1:]) // 2]
     S = N_SAMPLES + N_IMPORTANCE
-    ref = {k: out[k].detach() for k in ("color", "depth", "weights_sum")}
+    ref = {k: out[k].detach() for k in ("color", "depth", "weights_sum", "weights", "z_vals")}
     ref["loss"] = float(loss.detach())
-    return {"value": sample_rays * S / t, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+    ref["sdf"], ref["pts"] = _oracle_sdf_at_samples(sd, rays, ref["z_vals"])
+    return {"value": sample_rays * S / t, "unit": "ray-samples/s", "cores": cores, "kind": "port", "repeats": repeats,
+            "port_over_reference": PORT_OVER_REFERENCE,
             "sample": "the first %d rays of the timed %d-ray batch x %d samples (BASELINE.md 3), same networks / sampler, "
                       "fp32 torch-CPU oracle (the analytic-adjoint restatement: 6 M_sdf per sample where the reference's "
                       "double forward + autograd.grad spends ~9 M_sdf, SURVEY 8d -- this flatters the CPU side slightly), "
@@ -186,24 +195,70 @@ def cpu_baseline(sample_rays=256, repeats=2, max_threads=32, seed=1000):
                       % (sample_rays, R_PER_GPU, S, repeats, t)}, ref
 
 
-def oracle_outputs(sample_rays=256, seed=1000, variance=None):
-    """Forward-only oracle evaluation of the same sample (fp64), optionally at another variance (inv_s = exp(10 variance))."""
+def _oracle_sdf_at_samples(sd, rays, z):
+    """The SDF network (north_star names SDF among the outputs; render() itself does not return it) at the oracle's own
+    sample positions o + z d of every ray: the points the sampler and the compositor query.  -> (sdf [R*S], pts [R*S,3])."""
+    from oracle import neuconw_oracle as O
+
+    with torch.no_grad():
+        pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3)
+        sdf, _, _ = O.sdf_net({k[len("neuconw."):]: v.detach() for k, v in sd.items() if k.startswith("neuconw.sdf_net.")},
+                              pts.to(z.dtype), "sdf_net.", with_grad=False)
+    return sdf, pts
+
+
+def oracle_outputs(sample_rays=256, seed=1000, variance=None, state=None):
+    """Forward-only oracle evaluation of the same sample (fp64), optionally at another variance (inv_s = exp(10 variance))
+    or with another state_dict (`state`: the trained-weights point)."""
     from oracle import neuconw_oracle as O
 
     sd, cfg, (rays, ts, label, rgbs) = _oracle_setup(sample_rays, seed, variance)
+    if state is not None:
+        sd = dict(state)
     sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     with torch.no_grad():
         out = O.render(sd, cfg, rays.double(), ts, label, 0.5, torch.zeros(1, 3, dtype=torch.float64))
         loss = O.neuconw_loss(out, rgbs.double(), cfg)
-    ref = {k: out[k] for k in ("color", "depth", "weights_sum")}
+    ref = {k: out[k] for k in ("color", "depth", "weights_sum", "weights", "z_vals")}
     ref["loss"] = float(loss)
+    ref["sdf"], ref["pts"] = _oracle_sdf_at_samples(sd, rays.double(), ref["z_vals"])
     return ref
 
 
-def gpu_outputs(dev, prec, sample_rays=256, seed=1000, variance=None):
-    """The product's render + loss of the same sample, same (initial) weights, in the TIMED precision, deterministic
-    sampling (perturb 0) like the oracle leg."""
+def _state_dict_of(emb, neuconw, nerf):
+    sd = {"embedding_a.weight": emb.weight.detach().cpu().clone()}
+    sd.update({"neuconw." + k: v.detach().cpu().clone() for k, v in neuconw.state_dict().items() if not k.startswith("xyz_enc")})
+    sd.update({"nerf." + k: v.detach().cpu().clone() for k, v in nerf.state_dict().items()})
+    return sd
+
+
+def trained_state(dev, steps=40, sample_rays=256, seed=1000, lr=1e-3, variance=0.6):
+    """A NON-initial operating point for `parity`: `steps` TrainSteps in the fp32 mode (bitwise reproducible) from the bench's
+    initial weights on the parity sample, then SingleVarianceNetwork.variance set to `variance` (inv_s 403, where NeuS
+    trains) -- the recipe of tests/test_gpu_fullsize.py::test_train_step_vs_oracle_after_training.  -> CPU state_dict."""
+    import neuralrecon_w_amd as nw
+
+    emb, neuconw, nerf, rdr = build_models(dev, nw.PREC_F32)
+    train = nw.TrainStep(rdr, [emb, neuconw, nerf], loss_fn, lr=lr, eps=1e-7, clip=0.99)
+    rays, ts, label, rgbs = [t[:sample_rays] for t in synth_batch(R_PER_GPU, seed, dev)]
+    bg = torch.zeros(1, 3, device=dev)
+    for i in range(steps):
+        train(rays, ts, label, rgbs, background_rgb=bg, cos_anneal_ratio=0.5, perturb_overwrite=0)
+    with torch.no_grad():
+        neuconw.deviation_network.variance.fill_(float(variance))
+    torch.cuda.synchronize()
+    return _state_dict_of(emb, neuconw, nerf)
+
+
+def gpu_outputs(dev, prec, sample_rays=256, seed=1000, variance=None, pts=None, state=None):
+    """The product's render + loss of the same sample, same (initial, or `state`) weights, in the TIMED precision,
+    deterministic sampling (perturb 0) like the oracle leg; `pts`: where to evaluate the SDF network (the oracle's samples)."""
     emb, neuconw, nerf, rdr = build_models(dev, prec)
+    if state is not None:
+        with torch.no_grad():
+            emb.weight.copy_(state["embedding_a.weight"])
+            neuconw.load_state_dict({k[len("neuconw."):]: v for k, v in state.items() if k.startswith("neuconw.")}, strict=False)
+            nerf.load_state_dict({k[len("nerf."):]: v for k, v in state.items() if k.startswith("nerf.")})
     if variance is not None:
         with torch.no_grad():
             neuconw.deviation_network.variance.fill_(float(variance))
@@ -212,8 +267,11 @@ def gpu_outputs(dev, prec, sample_rays=256, seed=1000, variance=None):
         out = rdr.render(rays, ts, label, perturb_overwrite=0, background_rgb=torch.zeros(1, 3, device=dev),
                          cos_anneal_ratio=0.5)
         loss = loss_fn_torch(out, rgbs)
-    got = {k: out[k].detach().cpu() for k in ("color", "depth", "weights_sum")}
+    got = {k: out[k].detach().cpu() for k in ("color", "depth", "weights_sum", "weights")}
     got["loss"] = float(loss)
+    if pts is not None:  # the SDF network in the timed precision (the sampler's / compositor's queries)
+        with torch.no_grad():
+            got["sdf"] = neuconw.sdf(pts.float().to(dev), prec).reshape(-1).cpu()
     return got
 
 
@@ -226,6 +284,11 @@ def parity_errors(got, ref):
     """max |gpu - oracle| / max |oracle| per output (the north star's '1e-4 rel' measure) + the loss difference."""
     e = {"colour": _rel(got["color"], ref["color"]), "depth": _rel(got["depth"], ref["depth"]),
          "weights_sum": _rel(got["weights_sum"], ref["weights_sum"]), "loss": abs(got["loss"] - ref["loss"])}
+    if "weights" in got and got["weights"].shape == ref["weights"].shape:  # per-SAMPLE compositing weights [R, S + O]
+        e["weights"] = _rel(got["weights"], ref["weights"])
+    if "sdf" in got and "sdf" in ref:  # SDF values at the oracle's sample positions: absolute (unit-sphere units) and relative
+        e["sdf_abs"] = float((got["sdf"].double().reshape(-1) - ref["sdf"].double().reshape(-1)).abs().max())
+        e["sdf"] = _rel(got["sdf"], ref["sdf"])
     return {k: float("%.3g" % v) for k, v in e.items()}
 
 
@@ -241,7 +304,7 @@ def pmc_kernel_name(raw):
     return k.split("(")[0] if "(" in k else k
 
 
-def pmc_traffic(argv_inner, steps_inner, timeout=240):
+def pmc_traffic(argv_inner, steps_inner, timeout=240, env=None):
     """HBM traffic measured WITH this run: two rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass:
     MI355X_MICROARCH.md, PMC slots) of a short inner run of this script.  Returns ({kernel: bytes per launch},
     bytes per step over all kernels) or (None, None).  FETCH_SIZE is doubled (the guide's gfx950 rule for wide
@@ -262,7 +325,8 @@ def pmc_traffic(argv_inner, steps_inner, timeout=240):
         cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                os.path.abspath(__file__)] + argv_inner
         try:
-            subprocess.run(cmd, cwd=d, env=dict(os.environ, TMPDIR=d), capture_output=True, text=True, timeout=timeout)
+            subprocess.run(cmd, cwd=d, env=dict(os.environ if env is None else env, TMPDIR=d), capture_output=True, text=True,
+                           timeout=timeout)
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if not files:
                 return None, None
@@ -514,6 +578,13 @@ def main():
         dt = float(t.item())
     S = N_SAMPLES + N_IMPORTANCE + n_boundary
     value = world * R * S * args.steps / dt
+    # a step whose gradient norm is not finite is SKIPPED by ncw_adam_step_dev (fp16 loss-scale guard) and is cheaper than a
+    # real one: the line reports the count over warm-up + timed steps and the bench FAILS if any step was skipped
+    skipped = int(train.opt.skipped_steps) if hasattr(train.opt, "skipped_steps") else int(getattr(train, "skipped_steps", 0))
+    if world > 1:
+        t = torch.tensor([skipped], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        skipped = int(t.item())
     if args.inner:  # the PMC passes only need the kernels to run
         if rank == 0:
             print(json.dumps({"inner": True, "ms_per_step": dt / args.steps * 1e3}))
@@ -554,7 +625,7 @@ def main():
         peak = PEAK_BF16_TFLOPS if prec != nw.PREC_F32 else 157.3  # fp16 MFMA peak = bf16 peak
         frac_mfma = ach / peak
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(frac_mfma, 4), "frac_mfma": round(frac_mfma, 4), "frac_hbm": None, "traffic": None,
+                    "frac": round(frac_mfma, 4), "frac_mfma": round(frac_mfma, 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": rows[dom][1],
                     "algorithmic_gflop_per_launch": round(fl[dom] / rows[dom][1] / 1e9, 2),
                     "kernel_tflops": {k: round(fl[k] / (rows[k][0] * 1e-3) / 1e12, 1) for k in rows if fl.get(k)},
@@ -576,34 +647,91 @@ def main():
                 if wb is not None:
                     alg_bytes += type(wb).algorithmic_bytes(wb.items, esz)
             gbs = alg_bytes / (rows[dom][0] * 1e-3) / 1e9
-            roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                             "frac": round(gbs / 8000.0, 4), "frac_hbm": round(gbs / 8000.0, 4),
-                             "algorithmic_gbytes_per_step": round(alg_bytes / 1e9, 3), "mfma_tflops": round(ach, 1)})
+            # `frac` stays the SURVEY 8(d) fraction (algorithmic FLOPs / duration / MFMA peak: 8d classes the MLP backward
+            # as MFMA-bound); the bytes THIS DESIGN streams through the kernel are reported beside it as `frac_hbm_design`
+            roofline.update({"bound": "mfma", "bound_note": "SURVEY 8(d) prices the MLP backward against the MFMA peak; this "
+                             "design's weight-gradient launch streams its stash operands once and is HBM-bound at `frac_hbm_design`",
+                             "frac_hbm_design": round(gbs / 8000.0, 4), "design_gbytes_per_s": round(gbs, 1), "hbm_peak_gbytes_per_s": 8000.0,
+                             "design_gbytes_per_launch": round(alg_bytes / 1e9, 3), "mfma_tflops": round(ach, 1)})
         # step-level MFMA fraction: all algorithmic FLOPs of the step / wall time
         step_flops = 2.0 * R * ((N_SAMPLES + (UP_STEPS - 1) * N_IMPORTANCE // UP_STEPS) * M_SDF1
                                 + S * (6 * M_SDF + 3 * M_COL) + (S + N_OUTSIDE) * 3 * M_BG)
         roofline["step_algorithmic_tflop"] = round(step_flops / 1e12, 4)
+        # SURVEY 8(d)'s algorithmic HBM bytes: 8.3 KB per ray-sample (inputs + outputs + ONE 8 x W x 2 B activation stash)
+        roofline["survey_algorithmic_gbytes_per_step"] = round(8.3e3 * R * S / 1e9, 3)
         roofline["step_frac_of_mfma_peak"] = round(step_flops / (dt / args.steps) / 1e12 / peak, 4)
         # ---- HBM traffic, measured with this run (single-GPU runs; N > 1 would profile N ranks) ----------------
-        if not args.no_pmc and world == 1:
+        if not args.no_pmc:
+            # N > 1: the passes profile ONE single-process replica of the per-rank step on rank 0's device (the other ranks
+            # wait at the barrier below): the per-GPU kernels are the same at every N, the all-reduce is not in `traffic`
             inner_steps, inner_warm = 3, 2
-            inner = ["--inner", "--steps", str(inner_steps), "--warmup", str(inner_warm), "--prec", args.prec, "--rays", str(R),
-                     "--config", args.config, "--no-cpu-baseline", "--no-pmc", "--no-parity-mode"]
+            inner = ["--inner", "--gpus", "1", "--steps", str(inner_steps), "--warmup", str(inner_warm), "--prec", args.prec,
+                     "--rays", str(R), "--config", args.config, "--no-cpu-baseline", "--no-pmc", "--no-parity-mode"]
             if args.bg_eliminate:
                 inner.append("--bg-eliminate")
-            per_kernel, step_bytes = pmc_traffic(inner, inner_steps + inner_warm)
+            env1 = None
+            if world > 1:
+                env1 = {k: v for k, v in os.environ.items()
+                        if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
+                                     "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "ROLE_NAME")}
+                vis = os.environ.get("HIP_VISIBLE_DEVICES")
+                env1["HIP_VISIBLE_DEVICES"] = vis.split(",")[local_rank] if vis else str(local_rank)
+            per_kernel, step_bytes = pmc_traffic(inner, inner_steps + inner_warm, env=env1)
             if per_kernel:
                 sel = [v for k, v in per_kernel.items() if PMC_KERNEL.get(dom, "\0") in k]
                 roofline["traffic"] = round(max(sel), 0) if sel else None
                 roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH x 2 + WRITE)"
                 roofline["step_traffic_gb"] = round(step_bytes / 1e9, 3)
+                roofline["traffic_ratio"] = round(step_bytes / (8.3e3 * R * S), 2)  # measured step bytes / SURVEY 8(d) bytes
                 top = sorted(((k, v) for k, v in per_kernel.items()), key=lambda kv: -kv[1])[:10]
                 roofline["kernel_traffic_mb_per_launch"] = {k[:48]: round(v / 1e6, 1) for k, v in top}
+
+    # ---- the gradient all-reduce on its own: the flat fp32 gradient buffer, in place, ReduceOp.AVG on RCCL (what
+    # FlatParams.allreduce issues once per step).  At N = 1 a one-rank RCCL group is created just for this: it prices the
+    # launch + the in-place kernel, not the wire; at N > 1 it is the real collective over xGMI (max over ranks).
+    allreduce = None
+    try:
+        own_group = False
+        if world == 1 and not dist.is_initialized():
+            import socket
+
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+            own_group = True
+        backend = dist.get_backend()
+        op = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
+        buf = train.fp.flat_grad.clone()
+        for _ in range(3):
+            dist.all_reduce(buf, op=op)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        n_ar = 20
+        for _ in range(n_ar):
+            dist.all_reduce(buf, op=op)
+        torch.cuda.synchronize()
+        d_ar = (time.perf_counter() - t1) / n_ar
+        if world > 1:
+            t = torch.tensor([d_ar], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d_ar = float(t.item())
+        allreduce = {"allreduce_ms": round(d_ar * 1e3, 4), "bytes": buf.numel() * 4, "backend": backend, "world": world,
+                     "op": "AVG" if backend == "nccl" else "SUM (+ one division launch)",
+                     "note": "in-place all-reduce of the flat fp32 gradient buffer, back to back, host-timed over %d calls" % n_ar}
+        del buf
+        if own_group:
+            dist.destroy_process_group()
+    except Exception as e:  # never take the bench line down
+        allreduce = {"allreduce_ms": None, "error": "%r" % (e,)}
 
     # ---- the fp32 parity mode (the <= 1e-4 mode, tests/test_gpu_render.py) timed in the same process ---------------
     parity = None
     alt = elim = plain = None
-    if not args.no_parity_mode and world == 1 and args.prec in ("bf16", "f16") and not args.graph:
+    if not args.no_parity_mode and args.prec in ("bf16", "f16") and not args.graph:
         del train, step
         torch.cuda.empty_cache()
         alt_name = "bf16" if args.prec == "f16" else "f16"
@@ -685,7 +813,7 @@ def main():
 
     cpu = None
     parity_obj = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:  # N > 1: rank 0 alone (the other ranks wait at the barrier below)
         try:
             cpu, ref32 = cpu_baseline()
         except Exception as e:  # the baseline must never take the bench line down
@@ -698,15 +826,25 @@ def main():
             try:
                 parity_obj = {"dtype": args.prec, "rays": 256, "measure": "max|gpu - oracle| / max|oracle| (loss: absolute)",
                               "oracle": "fp32 torch-CPU oracle of the cpu_baseline leg (inv_s 20); fp64 oracle at inv_s 403"}
-                parity_obj.update(parity_errors(gpu_outputs(dev, prec), ref32))
+                parity_obj["outputs"] = ("colour / depth / weights_sum per ray; `weights` = per-SAMPLE compositing weights [R, S+O]; "
+                                         "`sdf` = SDF network at the oracle's sample positions (sdf_abs in unit-sphere units)")
+                parity_obj.update(parity_errors(gpu_outputs(dev, prec, pts=ref32["pts"]), ref32))
                 ref_t = oracle_outputs(variance=0.6)
-                parity_obj["at_inv_s_403"] = parity_errors(gpu_outputs(dev, prec, variance=0.6), ref_t)
+                parity_obj["at_inv_s_403"] = parity_errors(gpu_outputs(dev, prec, variance=0.6, pts=ref_t["pts"]), ref_t)
+                # trained weights: 40 fp32 TrainSteps on these rays, then variance 0.6 (tests/test_gpu_fullsize.py)
+                st_tr = trained_state(dev)
+                ref_tr = oracle_outputs(state=st_tr)
+                parity_obj["trained_40_steps_inv_s_403"] = parity_errors(gpu_outputs(dev, prec, pts=ref_tr["pts"], state=st_tr), ref_tr)
                 if prec != nw.PREC_F32:
-                    parity_obj["f32_mode"] = parity_errors(gpu_outputs(dev, nw.PREC_F32), ref32)
-                    parity_obj["f32_mode_at_inv_s_403"] = parity_errors(gpu_outputs(dev, nw.PREC_F32, variance=0.6), ref_t)
+                    parity_obj["f32_mode"] = parity_errors(gpu_outputs(dev, nw.PREC_F32, pts=ref32["pts"]), ref32)
+                    parity_obj["f32_mode_at_inv_s_403"] = parity_errors(gpu_outputs(dev, nw.PREC_F32, variance=0.6, pts=ref_t["pts"]), ref_t)
+                    parity_obj["f32_mode_trained_40_steps_inv_s_403"] = parity_errors(
+                        gpu_outputs(dev, nw.PREC_F32, pts=ref_tr["pts"], state=st_tr), ref_tr)
             except Exception as e:
                 parity_obj = {"dtype": args.prec, "error": "failed: %r" % (e,)}
 
+    if world > 1:
+        dist.barrier()  # rank 0's CPU-baseline / parity / PMC legs are over
     if rank == 0:
         names = {"headline": "BASELINE.json configs[1]", "shipped": "shipped yaml shape, secondary",
                  "voxel": "BASELINE.json configs[2] (voxel-guided), secondary"}
@@ -726,7 +864,8 @@ def main():
                        "rays_per_gpu": R, "samples_per_ray": S, "global_rays": world * R, "parallelism": "dp%d" % world,
                        "world_size": world, "ranks": ranks,
                        "submission": "hip-graph replay" if args.graph else "eager",
-                       "final_loss": float(loss.detach())},
+                       "final_loss": float(loss.detach()), "skipped_steps": skipped},
+            "allreduce": allreduce, "allreduce_ms": allreduce.get("allreduce_ms") if allreduce else None,
             "roofline": roofline, "parity": parity_obj, "parity_mode": parity, "alt_mode": alt, "plain_f16_mode": plain,
             "bg_elimination": elim,
             "cpu_baseline": cpu,
@@ -734,6 +873,9 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+    if skipped > 0:
+        raise SystemExit("bench.py: %d of the %d warm-up + timed steps were SKIPPED by the non-finite-gradient guard (fp16 loss "
+                         "scale): the timed region is not %d real steps" % (skipped, args.warmup + args.steps, args.steps))
 
 
 if __name__ == "__main__":

@@ -46,18 +46,24 @@ def sdf_grid_range(sdf_net, dim, bound_min, bound_max, start, count, origin=(0.0
 
 @torch.no_grad()
 def sdf_grid(sdf_net, dim, bound_min=(-1.0, -1.0, -1.0), bound_max=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0),
-             radius=1.0, prec=None, group=None):
+             radius=1.0, prec=None, group=None, force_collective=False):
     """Full [dim, dim, dim] SDF grid; with torch.distributed initialised every rank evaluates its
-    contiguous 1/world slice and one all_gather assembles the result on all ranks."""
+    contiguous 1/world slice and one all_gather assembles the result on all ranks (utils/visualization.py:27-35,81-83).
+    `force_collective`: issue the all_gather in a ONE-rank group too (tests push the RCCL path through a single GPU)."""
     total = dim ** 3
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         start, count, per = local_range(total, rank, world)
         dev = next(sdf_net.parameters()).device
         local = torch.zeros(per, device=dev, dtype=torch.float32)
         if count > 0:
             sdf_grid_range(sdf_net, dim, bound_min, bound_max, start, count, origin, radius, prec, out=local)
-        full = torch.empty(per * world, device=dev, dtype=torch.float32)
-        dist.all_gather_into_tensor(full, local, group=group)
+        if dist.get_backend(group) == "nccl":  # RCCL: one flat all-gather straight into the result
+            full = torch.empty(per * world, device=dev, dtype=torch.float32)
+            dist.all_gather_into_tensor(full, local, group=group)
+        else:  # gloo (CPU tests, ranks sharing one GPU): the list form
+            parts = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(parts, local, group=group)
+            full = torch.cat(parts)
         return full[:total].view(dim, dim, dim)
     return sdf_grid_range(sdf_net, dim, bound_min, bound_max, 0, total, origin, radius, prec).view(dim, dim, dim)

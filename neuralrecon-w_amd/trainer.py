@@ -79,14 +79,16 @@ class FlatParams:
                 off, k = self.slices[id(p)]
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
 
-    def allreduce(self, world_size=None, group=None, async_op=False):
+    def allreduce(self, world_size=None, group=None, async_op=False, force=False):
         """Mean of the flat gradient over ranks: ONE all-reduce (RCCL over xGMI), in place.  async_op=True returns a
-        handle whose wait() completes the mean (the caller overlaps host work / independent launches with the wire
-        time); RCCL averages in the collective (ReduceOp.AVG), gloo sums and the division is one more launch."""
+        handle whose wait() completes the mean; RCCL averages in the collective (ReduceOp.AVG), gloo sums and the division
+        is one more launch.  TrainStep waits for it right away (the step is SYNCHRONOUS in the exchange: every gradient
+        becomes final in one weight-gradient launch at the very end of the backward).  `force`: issue the
+        collective in a one-rank group too (tests push the RCCL path through a single GPU)."""
         if not dist.is_available() or not dist.is_initialized():
             return None
         world_size = dist.get_world_size(group) if world_size is None else world_size
-        if world_size == 1:
+        if world_size == 1 and not force:
             return None
         avg = dist.get_backend(group) == "nccl"
         work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group,

@@ -155,7 +155,7 @@ def shard_range(total, rank, world):
     return start, max(0, min(per, total - start)), per
 
 
-def _sdf_sharded(renderer, xyz_training, chunk, group=None):
+def _sdf_sharded(renderer, xyz_training, chunk, group=None, force_collective=False):
     """renderer.sdf over all points; with torch.distributed initialised each rank sweeps its slice and ONE
     all_gather assembles the result (neuconw_system.py:236-256)."""
     import torch.distributed as dist
@@ -168,7 +168,7 @@ def _sdf_sharded(renderer, xyz_training, chunk, group=None):
     for i in range(0, count, chunk):
         j = min(count, i + chunk)
         local[i:j] = renderer.sdf(xyz_training[start + i:start + j].reshape(-1, 1, 3)).reshape(-1)
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
         return local[:n]
     parts = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(parts, local, group=group)
@@ -176,7 +176,7 @@ def _sdf_sharded(renderer, xyz_training, chunk, group=None):
 
 
 @torch.no_grad()
-def surface_selection(renderer, train_level, threshold, chunk=1 << 22, group=None):
+def surface_selection(renderer, train_level, threshold, chunk=1 << 22, group=None, force_collective=False):
     """neuconw_system.py:186-264.  Returns (points_sfm [K,3] float32 on the GPU: the lower corners of the
     level-`train_level` sub-voxels of the occupied coarse voxels whose sdf <= threshold; train_voxel_size).
     Same arithmetic and operation order as the reference (float32 `ind * voxel + origin`), so the selected
@@ -202,7 +202,7 @@ def surface_selection(renderer, train_level, threshold, chunk=1 << 22, group=Non
     xyz_sfm = ind_up * train_voxel_size + vol_origin          # int64 * python float -> float32, then + float32
     scene_origin = renderer.origin.float().to(dev).reshape(3)
     xyz_training = (xyz_sfm - scene_origin) / renderer.radius
-    sdf = _sdf_sharded(renderer, xyz_training.contiguous(), int(chunk), group)
+    sdf = _sdf_sharded(renderer, xyz_training.contiguous(), int(chunk), group, force_collective)
     return xyz_sfm[sdf <= threshold], train_voxel_size
 
 

@@ -78,3 +78,34 @@ def test_bench_gpus_2_prints_one_line_with_world_2():
     assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["global_rays"] == 512
     assert out["scaling"] == "weak" and out["value"] > 0 and len(out["config"]["ranks"]) == 2
     assert abs(out["value"] - 2 * 256 * 128 / (out["ms_per_step"] * 1e-3)) < 1e-3 * out["value"]
+
+
+def test_inference_collectives_with_two_ranks():
+    """The two inference-side exchange steps at world 2 (ranks sharing GPU 0, gloo): grid.sdf_grid's all_gather over padded
+    contiguous slices (config 5, utils/visualization.py:27-35,81-83) and voxel.surface_selection's sharded sweep + all_gather
+    (N1, neuconw_system.py:236-258) reproduce the single-process results exactly."""
+    out = _torchrun([os.path.join(ROOT, "tests", "_ddp_infer_worker.py")], {})
+    print(out)
+    assert out["world"] == 2 and out["all_ranks_ok"]
+    assert out["grid_equal"] and out["selection_equal"]
+    assert 0 < out["selection_points"] < out["candidates"]
+
+
+def test_bench_gpus_2_line_is_complete():
+    """An N > 1 bench line carries what the N = 1 line carries (a SCALE record must not be "unmeasured" by construction):
+    `cpu_baseline`, `parity` (rank 0), the secondary modes, `allreduce_ms`, `roofline` with per-kernel HIP-event times, and
+    `skipped_steps` 0.  (PMC passes are exercised at N = 1 by the driver; here --no-pmc keeps the test short.)"""
+    env = dict(os.environ, NCW_DIST_BACKEND="gloo", NCW_BENCH_ONE_GPU_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-pmc"],
+                       capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["skipped_steps"] == 0
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["repeats"] >= 3
+    assert out["parity"]["colour"] < 1.2e-4 and "weights" in out["parity"] and "sdf_abs" in out["parity"]
+    assert "trained_40_steps_inv_s_403" in out["parity"]
+    assert out["parity_mode"]["ms_per_step"] > 0 and out["bg_elimination"]["ms_per_step"] > 0
+    assert out["allreduce_ms"] is not None and out["allreduce"]["world"] == 2
+    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1 and out["roofline"]["frac_hbm_design"] > 0

@@ -109,15 +109,19 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
 #   (0.7, 0)  inv_s 1097 1.5e-4 / 2.0e-2     3.4e-5 [1.3e-4] / 2.8e-3                        1.6e-3           1.9e-3 / 1.6e-1
 #   (0.6, 0.05) (weight_v jittered 5 %: a non-sphere SDF)  1.1e-6 / 3.0e-4   2.3e-5 [6.7e-5] / 1.0e-3   1.6e-4   1.1e-2 / 2.4e-1
 # Once inv_s is in the hundreds the discrete sampler amplifies 1e-7 SDF differences on single rays: ANY two fp32-accurate
-# evaluations differ by 1e-4 .. 6e-4 there (the exact-fp32 kernels vs the fp64 oracle: 6.1e-4 at inv_s 403; the split fp16
-# path 5.5e-5 with one summation order of its kernels and 4.3e-4 with another), so at variance >= 0.6 the fp32 and the fp16
-# tolerances are the same noise floor (1.3e-3).  The plain fp16 value path is 10x and bf16 100x above it.  DESIGN.md 4 has
-# the full table.
+# evaluations differ by 1e-4 .. 8e-4 there.  Settled with the REAL REFERENCE (round 4, scripts/diag/port_over_reference.py ->
+# profiles/r04/port_over_reference.json, checked by tests/test_reference_noise_floor.py): the reference's own fp32 arithmetic on
+# exactly these inputs is off the fp64 oracle by (colour / depth / weights_sum; worst parameter gradient)
+#   (0.5, 0) 8.6e-6 / 2.3e-5 / 9.6e-6; 1.1e-3     (0.6, 0) 5.7e-4 / 7.8e-4 / 6.5e-4; 2.1e-3
+#   (0.7, 0) 1.4e-4 / 1.9e-4 / 1.6e-4; 2.5e-2     (0.6, 0.05) 8.8e-7 / 8.0e-7 / 8.5e-7; 2.6e-4
+# -- the same numbers as our exact-fp32 kernels (first column above) -- so the output tolerances at variance >= 0.6 are <= 2.5x
+# the reference's own deviation (1.3e-3 at (0.6, 0), 4.5e-4 at (0.7, 0)), for fp32 and fp16 alike.  The plain fp16 value path
+# is 10x and bf16 100x above it.  DESIGN.md 4 has the full table.
 # (tol colour/depth/weights_sum, tol parameter gradients, tol eikonal term)
 TRAINED_TOL = {
     (0.5, 0.0): {"f32": (1e-4, 2e-3, 1e-4), "f16": (1.2e-4, 2.6e-3, 3e-4), "bf16": (3e-2, 0.75, 4e-3)},
     (0.6, 0.0): {"f32": (1.3e-3, 3.5e-3, 1e-4), "f16": (1.3e-3, 4e-3, 3e-4), "bf16": (0.12, 0.1, 4e-3)},
-    (0.7, 0.0): {"f32": (1.3e-3, 4e-2, 1e-4), "f16": (1.3e-3, 4e-2, 3e-4), "bf16": (4e-3, 0.32, 4e-3)},
+    (0.7, 0.0): {"f32": (4.5e-4, 4e-2, 1e-4), "f16": (4.5e-4, 4e-2, 3e-4), "bf16": (4e-3, 0.32, 4e-3)},
     (0.6, 0.05): {"f32": (1e-4, 2e-3, 1e-4), "f16": (1.2e-4, 2.1e-3, 2e-4), "bf16": (3e-3, 0.5, 2.2e-2)},
 }
 

@@ -137,7 +137,11 @@ def _check_h5_equals_npz(tmp_path):
 
 def test_h5_cache_reads_like_npz_with_real_h5py(tmp_path):
     """datasets/phototourism.py:491-511: an h5 cache (the writer's default) loads to the same tensors as the npz one."""
+    import types
+
     h5py = pytest.importorskip("h5py")
+    if not isinstance(h5py, types.ModuleType) or not isinstance(getattr(h5py, "__version__", None), str):
+        pytest.skip("h5py is a stand-in here (oracle/ref_import.py stubs it for the reference's imports)")
     _write_h5_cache(tmp_path, h5py)
     _check_h5_equals_npz(tmp_path)
 
