@@ -351,6 +351,46 @@ def pmc_traffic(argv_inner, steps_inner, timeout=240, env=None):
     return out, total / max(steps_inner, 1)
 
 
+def time_allreduce(numel, dev, world, n_ar=20):
+    """In-place all-reduce of a flat fp32 buffer of `numel` elements on the initialised process group, back to back."""
+    backend = dist.get_backend()
+    op = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
+    buf = torch.ones(numel, device=dev, dtype=torch.float32)
+    for _ in range(3):
+        dist.all_reduce(buf, op=op)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(n_ar):
+        dist.all_reduce(buf, op=op)
+    torch.cuda.synchronize()
+    d_ar = (time.perf_counter() - t1) / n_ar
+    if world > 1:
+        t = torch.tensor([d_ar], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        d_ar = float(t.item())
+    return {"allreduce_ms": round(d_ar * 1e3, 4), "bytes": numel * 4, "backend": backend, "world": world,
+            "op": "AVG" if backend == "nccl" else "SUM (+ one division launch)",
+            "note": "in-place all-reduce of the flat fp32 gradient buffer, back to back, host-timed over %d calls%s"
+                    % (n_ar, "; ONE-rank RCCL group: launch + kernel, no wire" if world == 1 else "")}
+
+
+def allreduce_probe(numel):
+    """`bench.py --allreduce-probe N` (child of an N = 1 run): one-rank RCCL group on cuda:0, prints time_allreduce's dict."""
+    import socket
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    print(json.dumps(time_allreduce(numel, dev, 1)), flush=True)
+    dist.destroy_process_group()
+
+
 def voxel_shell(level=7, r0=0.5, thick=0.05, device="cuda"):
     """the voxels of a level-7 grid that intersect a sphere shell of radius 0.5 +- 0.05."""
     G = 1 << level
@@ -429,6 +469,8 @@ def bench_grid512(args, nw, L, dev, world, rank):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--allreduce-probe":
+        return allreduce_probe(int(sys.argv[2]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -691,40 +733,17 @@ def main():
     # launch + the in-place kernel, not the wire; at N > 1 it is the real collective over xGMI (max over ranks).
     allreduce = None
     try:
-        own_group = False
         if world == 1 and not dist.is_initialized():
-            import socket
+            # a ONE-rank RCCL group, in a child process with a hard time limit: a backend that cannot come up on this box
+            # must cost the bench line a null, never a hang
+            import subprocess
 
-            sk = socket.socket()
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-            sk.close()
-            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
-            own_group = True
-        backend = dist.get_backend()
-        op = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
-        buf = train.fp.flat_grad.clone()
-        for _ in range(3):
-            dist.all_reduce(buf, op=op)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-        n_ar = 20
-        for _ in range(n_ar):
-            dist.all_reduce(buf, op=op)
-        torch.cuda.synchronize()
-        d_ar = (time.perf_counter() - t1) / n_ar
-        if world > 1:
-            t = torch.tensor([d_ar], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            d_ar = float(t.item())
-        allreduce = {"allreduce_ms": round(d_ar * 1e3, 4), "bytes": buf.numel() * 4, "backend": backend, "world": world,
-                     "op": "AVG" if backend == "nccl" else "SUM (+ one division launch)",
-                     "note": "in-place all-reduce of the flat fp32 gradient buffer, back to back, host-timed over %d calls" % n_ar}
-        del buf
-        if own_group:
-            dist.destroy_process_group()
+            r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--allreduce-probe", str(train.fp.flat_grad.numel())],
+                                capture_output=True, text=True, timeout=90, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+            ls_ = [l for l in r_.stdout.splitlines() if l.startswith("{")]
+            allreduce = json.loads(ls_[-1]) if ls_ else {"allreduce_ms": None, "error": (r_.stderr or r_.stdout)[-300:]}
+        else:
+            allreduce = time_allreduce(train.fp.flat_grad.numel(), dev, world)
     except Exception as e:  # never take the bench line down
         allreduce = {"allreduce_ms": None, "error": "%r" % (e,)}
 

@@ -39,7 +39,7 @@ extern "C" {
 
 /* library / device info; returns the ABI version (bumped on any signature change) */
 int ncw_abi_version(void);
-/* sha256 (hex) of the sources this library was built from (csrc/*.hip, csrc/*.h, this header); the Python binding
+/* sha256 (hex) of the sources this library was built from (every .hip / .h file of csrc/ and this header); the Python binding
  * refuses a library whose hash differs from the tree's (neuralrecon-w_amd/build.py source_hash) */
 const char* ncw_source_hash(void);
 /* writes "gfx950" style arch name of device 0 into buf; returns CU count (0 if no device) */
@@ -227,6 +227,9 @@ typedef struct NcwColorStash {
     void* ze[4];     /* rbh */
     void* zx[8];     /* rbc */
     void* zo;        /* 1 block: dL/d(pre-sigmoid rgb), features 0..2 */
+    const float* aux_bias; /* NULL, or [R, 32 rbh] fp32 from ncw_aux_ray_bias: the per-ray part of the head's first layer,
+                            * W_e0[:, view-dir | appearance columns] . [gamma_4(d) | a], added to that layer's bias in the
+                            * FORWARD instead of being multiplied from 16-bit operands (the backward is unchanged) */
 } NcwColorStash;
 
 /* normals [n,3] (the SDF gradient), a [R or n, n_a] appearance rows indexed by the point's ray,
@@ -291,6 +294,12 @@ int ncw_batch_assemble(const float* all_rays, int ncols, const float* all_rgbs, 
  * Per-step glue of render() / the loss as single launches (each replaces 6-25 tiny torch kernels; the step is
  * GPU-bound, so every 3-5 us launch counts).
  * ---------------------------------------------------------------------------------------- */
+/* models/neuconw.py:131-140: out[r, j] = sum_k w[j, col0 + k] * [gamma_4(rays_d[r]) (27) | a[r] (n_a)][k], fp32, once per RAY
+ * (w: the row-major fp32 weight of static_linear_0, row stride ldw; out row stride ldo >= n_out).  The appearance code and
+ * the view direction are per-ray constants: their fp16 rounding is coherent along a ray and was the largest term of the fp16
+ * mode's colour error on trained weights (scripts/diag/emul_color16.py). */
+int ncw_aux_ray_bias(const float* w, int ldw, int col0, int n_out, const float* rays_d, const float* a, int n_a, int64_t R,
+                     float* out, int ldo, void* stream);
 /* renderer.py:793-806: rays [R,ncols >= 8] -> rays_o = (rays[:,0:3] - origin) / radius, rays_d = rays[:,3:6],
  * near = rays[:,6] / radius, far = rays[:,7] / radius, depth_gt = rays[:,8] / radius, depth_weight = rays[:,9]
  * (zeros when ncols < 10).  origin: HOST float[3]. */

@@ -94,7 +94,52 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     if (d_ge && i == 0) d_ge[0] = g * igr_w;
 }
 
+// Per-ray part of the appearance head's first layer (models/neuconw.py:137-140: e = [f | gamma_4(view dir) | a] -> static_linear_0):
+// W[:, col0 : col0 + 27 + n_a] . [gamma_4(d_ray) | a_ray] is the SAME for every sample of a ray, so it is evaluated once per
+// ray in fp32 (libm sin / cos, fmaf) and enters the fused colour kernel as a per-ray bias.  One workgroup per ray.
+__global__ __launch_bounds__(128) void aux_ray_bias_kernel(const float* __restrict__ w, int ldw, int col0, int n_out,
+                                                          const float* __restrict__ rays_d, const float* __restrict__ a, int n_a,
+                                                          float* __restrict__ out, int ldo) {
+    __shared__ float x[96];
+    const int64_t ray = blockIdx.x;
+    const int t = threadIdx.x;
+    const int K = 27 + n_a;
+    if (t < K) {
+        float v;
+        if (t < 27) {  // gamma_4: [d (3) | sin(2^k d) (3) | cos(2^k d) (3)] k = 0..3  (models/neuconw.py:7-55)
+            const float d[3] = {rays_d[ray * 3 + 0], rays_d[ray * 3 + 1], rays_d[ray * 3 + 2]};
+            if (t < 3) v = d[t];
+            else {
+                const int j = t - 3, k = j / 6, rem = j - 6 * k;
+                const float arg = d[rem % 3] * (float)(1 << k);
+                v = rem >= 3 ? cosf(arg) : sinf(arg);
+            }
+        } else {
+            v = a[ray * n_a + (t - 27)];
+        }
+        x[t] = v;
+    }
+    __syncthreads();
+    for (int j = t; j < n_out; j += 128) {
+        const float* wr = w + (size_t)j * ldw + col0;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(wr[k], x[k], acc);
+        out[ray * ldo + j] = acc;
+    }
+}
+
 }  // namespace
+
+extern "C" int ncw_aux_ray_bias(const float* w, int ldw, int col0, int n_out, const float* rays_d, const float* a, int n_a,
+                                int64_t R, float* out, int ldo, void* stream) {
+    if (R <= 0) return 0;
+    if (!w || !rays_d || !a || !out || n_a < 0 || n_a > 69 || n_out <= 0 || ldo < n_out || col0 < 0 || col0 + 27 + n_a > ldw)
+        return NCW_E_BADARG;
+    hipLaunchKernelGGL(aux_ray_bias_kernel, dim3((unsigned)R), dim3(128), 0, (hipStream_t)stream, w, ldw, col0, n_out, rays_d, a,
+                       n_a, out, ldo);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int ncw_ray_prologue(const float* rays, int ncols, int64_t R, const float* origin_host, float radius, float* rays_o,
                                 float* rays_d, float* near, float* far, float* depth_gt, float* depth_weight, void* stream) {

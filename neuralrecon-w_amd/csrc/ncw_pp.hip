@@ -24,6 +24,9 @@
 // One s_barrier per segment (M(l+1,g) starts after every wave's E(l,g)); activation buffers: per group two 32 KiB
 // buffers (layer parity), 128 KiB.  The barrier waits for LDS only (lgkmcnt), so the next layer's weight slice
 // (global -> registers, issued two loads per MFMA pair, a whole layer ahead) and stash stores stay in flight.
+#include <cstdlib>
+#include <cstring>
+
 #include "ncw_mlp.h"
 
 namespace {
@@ -151,10 +154,70 @@ NCW_DEV void pp_epi_step(int u, const PPAcc<NB>& e, bf16x8 (&frag)[NB], pp_lfrag
     }
 }
 
+#ifdef NCW_HALF_F16
+// ------------------------------------------------------------------------------------------------
+// Packed-fp16 Softplus epilogues (round 4 experiment, fp16 build only: gfx950 has no packed bf16 VALU arithmetic).
+// The f32 form costs, per PAIR of accumulator registers, 8 plain VALU + 4 transcendentals + the f32 -> f16 conversion, i.e.
+// more VALU-pipe time than the pair's two MFMAs need matrix-pipe time.  The activation is rounded to fp16
+// for the next layer's B operand anyway, so the pair is converted FIRST (one v_cvt_pk_f16_f32) and the Softplus runs on
+// both halves of a register:
+//   EPI 1 ("pk16"):  t = 100 z log2 e (v_pk_mul_f16); w = 2^-|t| (2 x v_exp_f16); l = log2(1 + w) (v_pk_add_f16, 2 x
+//                    v_log_f16); y = l ln2/100 + max(z, 0) (v_pk_max_f16, v_pk_fma_f16): 5 plain + 4 transcendentals.
+//   EPI 2 ("poly16"): y = max(z, 0) + c(min(|z|, 0.06)), c = log1p(exp(-100 a)) / 100 as a degree-4 polynomial in
+//                    a (fit error 8.4e-6, fp16 Horner 2.5e-5): 9 plain VALU per PAIR, no transcendental.
+// Value-only kernel: nothing recomputes Softplus' from these activations.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 pp_h2 __attribute__((ext_vector_type(2)));
+typedef float pp_f2 __attribute__((ext_vector_type(2)));
+
+template <int EPI>
+NCW_DEV pp_h2 pp_softplus_pk(float z0, float z1) {
+    const pp_f2 zf = {z0, z1};
+    const pp_h2 z = __builtin_convertvector(zf, pp_h2);
+    const pp_h2 zero = {(_Float16)0.f, (_Float16)0.f};
+    const pp_h2 relu = __builtin_elementwise_max(z, zero);
+    if (EPI == 1) {
+        const pp_h2 k = {(_Float16)144.26950408889634f, (_Float16)144.26950408889634f};
+        const pp_h2 t = z * k;
+        const pp_h2 w = __builtin_elementwise_exp2(-__builtin_elementwise_abs(t));
+        const pp_h2 one = {(_Float16)1.f, (_Float16)1.f};
+        const pp_h2 l = __builtin_elementwise_log2(one + w);
+        const pp_h2 c = {(_Float16)(0.6931471805599453f * 0.01f), (_Float16)(0.6931471805599453f * 0.01f)};
+        return __builtin_elementwise_fma(l, c, relu);
+    } else {
+        // a = min(|z|, 0.06) = min(max(z, -z), 0.06); coefficients in a (fp16 Horner: 2.5e-5 abs)
+        const pp_h2 amax = {(_Float16)0.06f, (_Float16)0.06f};
+        const pp_h2 u = __builtin_elementwise_min(__builtin_elementwise_max(z, -z), amax);
+        const pp_h2 c4 = {(_Float16)1067.45f, (_Float16)1067.45f}, c3 = {(_Float16)-204.556f, (_Float16)-204.556f},
+                    c2 = {(_Float16)15.0246f, (_Float16)15.0246f}, c1 = {(_Float16)-0.510718f, (_Float16)-0.510718f},
+                    c0 = {(_Float16)0.00693755f, (_Float16)0.00693755f};
+        pp_h2 p = __builtin_elementwise_fma(c4, u, c3);
+        p = __builtin_elementwise_fma(p, u, c2);
+        p = __builtin_elementwise_fma(p, u, c1);
+        p = __builtin_elementwise_fma(p, u, c0);
+        return relu + p;
+    }
+}
+
+// pp_epi_step with the pair-wise packed epilogue
+template <int EPI, int NB>
+NCW_DEV void pp_epi_step_pk(int u, const PPAcc<NB>& e, bf16x8 (&frag)[NB], pp_lfrag* out, int ob0, int ob_step, int lane) {
+    const int j = u >> 3, r = 2 * (u & 7);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const pp_h2 y = pp_softplus_pk<EPI>(e.v[nb][j][r], e.v[nb][j][r + 1]);
+        frag[nb][r & 7] = y[0];
+        frag[nb][(r & 7) + 1] = y[1];
+        if ((u & 3) == 3) out[(j * 16 + 2 * (ob0 + nb * ob_step) + ((u & 7) >> 2)) * 64 + lane] = frag[nb];
+    }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // SDF inference (SDFNetwork.sdf, models/neuconw.py:281-282): gamma -> L-1 Softplus layers -> sdf row.
+// EPI: 0 = f32 Softplus epilogue; 1 / 2 = the packed-fp16 forms above (fp16 build only).
 // ------------------------------------------------------------------------------------------------
-template <int NB>
+template <int NB, int EPI>
 __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
                                                                        float* __restrict__ sdf) {
     constexpr int NW = PP_WAVES / NB;  // waves per workgroup
@@ -205,6 +268,15 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
 #define PP_SEG_END() pp_barrier()
     pp_barrier();
     auto softplus_f = [](float z, int, int, int) { return pp_softplus(z); };
+#ifdef NCW_HALF_F16
+#define PP_EPI(u, acc, outp)                                                                   \
+    do {                                                                                       \
+        if (EPI == 0) pp_epi_step<NB>(u, acc, frag, outp, ob, NW, lane, softplus_f);           \
+        else pp_epi_step_pk<(EPI == 0 ? 1 : EPI), NB>(u, acc, frag, outp, ob, NW, lane);      \
+    } while (0)
+#else
+#define PP_EPI(u, acc, outp) pp_epi_step<NB>(u, acc, frag, outp, ob, NW, lane, softplus_f)
+#endif
     // ---- layer 0 (K = 39: the 3 gamma units): [M(0,g0)] [M(0,g1) | E(0,g0)] ---------------------------------------------
     {
         read_bias(0);
@@ -218,7 +290,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
             for (int nb = 0; nb < NB; ++nb) pp_load_slice<3>(wx[nb], net.w[1], 8, ob + nb * NW, 16, lane);
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) pp_epi_step<NB>(u, x, frag, abuf + (0 * 2 + 0) * (PP_GRP / 16), ob, NW, lane, softplus_f);
+        for (int u = 0; u < 16; ++u) PP_EPI(u, x, abuf + (0 * 2 + 0) * (PP_GRP / 16));
     }
     // ---- hidden layer l >= 1: [M(l,g0) -> x | E(l-1,g1) <- y] [M(l,g1) -> y | E(l,g0) <- x] ------------------------------
     // (the bias block of a segment is read BEFORE the barrier that opens it: no LDS round trip at the segment head)
@@ -229,7 +301,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
         {   // g = 0
             const pp_lfrag* in = abuf + (0 * 2 + ((l - 1) & 1)) * (PP_GRP / 16) + lane;
             pp_lfrag* out = abuf + (1 * 2 + ((l - 1) & 1)) * (PP_GRP / 16);  // E(l-1, g1)
-            auto epi = [&](int u) { pp_epi_step<NB>(u, y, frag, out, ob, NW, lane, softplus_f); };
+            auto epi = [&](int u) { PP_EPI(u, y, out); };
             pp_segment<false, NB>(x, bias, wa, in, nullptr, 8, ob, NW, lane, epi);
             if (l == net.skip_layer) pp_mma_x<3, NB>(x, wx, gbuf + lane);
             read_bias(l);
@@ -238,7 +310,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
         {   // g = 1: the layer's last use of its weight slice -> the next layer's slice takes its registers
             const pp_lfrag* in = abuf + (1 * 2 + ((l - 1) & 1)) * (PP_GRP / 16) + lane;
             pp_lfrag* out = abuf + (0 * 2 + (l & 1)) * (PP_GRP / 16);        // E(l, g0)
-            auto epi = [&](int u) { pp_epi_step<NB>(u, x, frag, out, ob, NW, lane, softplus_f); };
+            auto epi = [&](int u) { PP_EPI(u, x, out); };
             if (more) pp_segment<true, NB>(y, bias, wa, in, net.w[l + 1], 8, ob, NW, lane, epi);
             else pp_segment<false, NB>(y, bias, wa, in, nullptr, 8, ob, NW, lane, epi);
             if (l == net.skip_layer) pp_mma_x<3, NB>(y, wx, gbuf + 2 * 3 * 64 + lane);
@@ -255,7 +327,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
     {
         pp_lfrag* out = abuf + (1 * 2 + ((NL - 1) & 1)) * (PP_GRP / 16);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) pp_epi_step<NB>(u, y, frag, out, ob, NW, lane, softplus_f);
+        for (int u = 0; u < 16; ++u) PP_EPI(u, y, out);
         PP_SEG_END();
     }
     // ---- sdf row: tile t by wave t % NW ------------------------------------------------------------------------------------
@@ -277,7 +349,18 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
 int NCW_FN(ncw_sdf_inferC_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
     const dim3 grid((unsigned)((tiles + PP_TILES - 1) / PP_TILES));
-    hipLaunchKernelGGL(sdf_inferC_kernel<1>, grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
+#ifdef NCW_HALF_F16
+    // round-4 A/B (scripts/diag/pp_epilogue.py): NCW_PP_EPI = f32 | pk16 | poly16, read once
+    static const int epi = [] {
+        const char* e = getenv("NCW_PP_EPI");
+        return e == nullptr ? 0 : (!strcmp(e, "pk16") ? 1 : (!strcmp(e, "poly16") ? 2 : 0));
+    }();
+    if (epi == 1) hipLaunchKernelGGL((sdf_inferC_kernel<1, 1>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
+    else if (epi == 2) hipLaunchKernelGGL((sdf_inferC_kernel<1, 2>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
+    else hipLaunchKernelGGL((sdf_inferC_kernel<1, 0>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
+#else
+    hipLaunchKernelGGL((sdf_inferC_kernel<1, 0>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
+#endif
     NCW_CHECK_LAUNCH();
     return 0;
 }

@@ -4,7 +4,9 @@ but every forward/backward runs in the hand-written gfx950 kernels of libneuconw
 These nn.Modules only OWN the parameters (so optimisers, DDP and checkpoints see ordinary
 nn.Parameters); they contain no torch compute on the hot path.
 """
+import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -397,6 +399,9 @@ class RenderingNetwork(_PackedNet):
             od["static_linear_%d" % i] = PlainLinear(nn.Linear(head_channels, head_channels))
         self.static_encoding = nn.Sequential(od)
         self.xyz_encoding_final = PlainLinear(nn.Linear(d_feature, d_feature))
+        # 16-bit modes: per-ray fp32 evaluation of the head's view-direction / appearance-code columns (fwd_stash);
+        # NEUCONW_COLOR_RAY_BIAS=0 / .ray_bias = False = those columns as 16-bit MFMA operands like the rest
+        self.ray_bias = os.environ.get("NEUCONW_COLOR_RAY_BIAS", "1") != "0"
         self._init_plans()
 
     @property
@@ -465,6 +470,23 @@ class RenderingNetwork(_PackedNet):
         rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
         normals = normals.contiguous().float()
         a = a.contiguous().float()
+        # 16-bit modes: the per-RAY part of the head's first layer -- W_e0[:, view-dir | appearance columns] . [gamma_4(d) | a]
+        # (models/neuconw.py:131-140) -- is evaluated once per ray in fp32 (ncw_aux_ray_bias) and added to that layer's bias;
+        # rounding `a` and gamma(d) to 16 bits is coherent along a ray and was the largest term of the fp16 mode's colour
+        # error on trained weights (scripts/diag/emul_color16.py).  The backward / weight gradients are unchanged.
+        st.aux_bias = None
+        lin0 = self.static_encoding[0]
+        if prec != L.PREC_F32 and self.ray_bias and pts.rays_d and not hasattr(lin0, "weight_v"):
+            R, no = a.shape[0], 32 * RBH
+            ab = ent.get("aux_bias")
+            if ab is None or ab.shape[0] != R:
+                ab = ent["aux_bias"] = torch.empty(R, no, device=dev, dtype=torch.float32)
+            w0 = lin0.weight.detach()
+            assert w0.is_contiguous() and w0.dtype == torch.float32 and w0.shape == (self.head_channels, self.d_feature + 27 + self.n_a)
+            L.check(L.get_lib().ncw_aux_ray_bias(L.ptr(w0), w0.shape[1], self.d_feature, self.head_channels,
+                                                 ctypes.c_void_p(pts.rays_d), L.ptr(a), self.n_a, R, L.ptr(ab), no, L.stream_ptr(dev)),
+                    "ncw_aux_ray_bias")
+            st.aux_bias = ab.data_ptr()
         L.check(L.get_lib().ncw_color_fwd(plan.net, prec, pts, n, L.ptr(normals), L.ptr(a), feat_ptr, L.ptr(rgb), st,
                                           L.stream_ptr(dev)), "ncw_color_fwd")
         return rgb, dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, rgb=rgb, feat_ptr=feat_ptr,

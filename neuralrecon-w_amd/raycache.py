@@ -130,12 +130,16 @@ class RayCache:
         k = batch["keep"]
         return batch["rays"][k], batch["ts"][k], batch["semantics"][k], batch["rgbs"][k]
 
-    def epoch(self, batch_size, generator=None, drop_last=False, max_batches=None):
+    def epoch(self, batch_size, generator=None, drop_last=False, max_batches=None, skip_batches=0):
         """Shuffled batches of one epoch (DataLoader(shuffle=True): a uniform permutation; drawn on the device).
-        max_batches: stop after that many (every rank of a data-parallel job must run the same number of steps)."""
+        max_batches: stop after that many (every rank of a data-parallel job must run the same number of steps);
+        skip_batches: a resumed run drops the batches the interrupted epoch already consumed (same permutation when the
+        generator is restored to its state at the start of that epoch)."""
         n = len(self)
         perm = torch.randperm(n, device=self.device, generator=generator)
         for i, s in enumerate(range(0, n, batch_size)):
             if (drop_last and s + batch_size > n) or (max_batches is not None and i >= max_batches):
                 return
+            if i < skip_batches:
+                continue
             yield self.batch(perm[s:s + batch_size])

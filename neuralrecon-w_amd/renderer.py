@@ -60,18 +60,25 @@ class _RenderFn(torch.autograd.Function):
             # keeps 32 CUs busy) instead of queueing behind them.
             side = rdr._bg_stream(dev) if rdr.use_bg_stream else None
             if side is not None:
-                side.wait_stream(torch.cuda.current_stream(dev))
+                main = torch.cuda.current_stream(dev)
+                side.wait_stream(main)
                 with torch.cuda.stream(side):
                     density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select)
+                # allocated under the side stream, consumed by the compositor on the main stream after the join below: tell
+                # the caching allocator, so that freeing them can never hand the memory out while the main stream still reads it
+                density.record_stream(main)
+                bg_rgb.record_stream(main)
             else:
                 density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select)
             density, bg_rgb = density.view(R, M), bg_rgb.view(R, M, 3)
-        pts_in = points_struct(rays_o=rays_o, rays_d=rays_d, z=z, sample_dist=sample_dist, mode=2)
-        sdf, grad, sctx = neuconw.sdf_net.fwd_stash(pts_in, R * S, prec)
-        feat_ptr = sctx["arena"].ptr(sctx["ids"]["feat"])
-        rgb, cctx = neuconw.color_net.fwd_stash(pts_in, R * S, prec, grad, a_det, feat_ptr)
-        if use_bg and rdr.use_bg_stream:
-            torch.cuda.current_stream(dev).wait_stream(rdr._bg_stream(dev))  # join before the compositor
+        try:
+            pts_in = points_struct(rays_o=rays_o, rays_d=rays_d, z=z, sample_dist=sample_dist, mode=2)
+            sdf, grad, sctx = neuconw.sdf_net.fwd_stash(pts_in, R * S, prec)
+            feat_ptr = sctx["arena"].ptr(sctx["ids"]["feat"])
+            rgb, cctx = neuconw.color_net.fwd_stash(pts_in, R * S, prec, grad, a_det, feat_ptr)
+        finally:  # the main stream ALWAYS rejoins the side stream (also when the SDF / colour chain raised)
+            if use_bg and rdr.use_bg_stream:
+                torch.cuda.current_stream(dev).wait_stream(rdr._bg_stream(dev))  # join before the compositor
         comp = rayops.CompositeCtx(rays_o, rays_d, z, sample_dist, sdf.view(R, S), grad.view(R, S, 3),
                                    rgb.view(R, S, 3), inv_s, cos_anneal, z_feed, density, bg_rgb, background_rgb,
                                    rdr.trim_sphere)
@@ -126,18 +133,23 @@ class _RenderFn(torch.autograd.Function):
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 nerf.bwd_stash(nctx, g["d_density"].view(R * M), g["d_bg_rgb"].view(R * M, 3), d_a_bg)
-        if ordered:
-            d_a = torch.empty(ctx.a_shape, device=dev, dtype=torch.float32)
-            rows = torch.empty(R * S, n_a, device=dev, dtype=torch.float32)
-            neuconw.color_net.bwd_stash(cctx, g["d_rgb"].view(R * S, 3), d_grad, None, dfeat_ptr, d_a_rows=rows)
-            L.check(lib.ncw_ray_sum_rows(L.ptr(rows), R, S, n_a, L.ptr(d_a), 0, L.stream_ptr(dev)), "ncw_ray_sum_rows")
-        else:
-            d_a = torch.zeros(ctx.a_shape, device=dev, dtype=torch.float32)
-            neuconw.color_net.bwd_stash(cctx, g["d_rgb"].view(R * S, 3), d_grad, d_a, dfeat_ptr)
-        neuconw.sdf_net.bwd_stash(sctx, g["d_sdf"].view(R * S), d_grad)
+            for t_ in (g["d_density"], g["d_bg_rgb"]):  # main-stream tensors read by the side stream
+                t_.record_stream(side)
+        try:
+            if ordered:
+                d_a = torch.empty(ctx.a_shape, device=dev, dtype=torch.float32)
+                rows = torch.empty(R * S, n_a, device=dev, dtype=torch.float32)
+                neuconw.color_net.bwd_stash(cctx, g["d_rgb"].view(R * S, 3), d_grad, None, dfeat_ptr, d_a_rows=rows)
+                L.check(lib.ncw_ray_sum_rows(L.ptr(rows), R, S, n_a, L.ptr(d_a), 0, L.stream_ptr(dev)), "ncw_ray_sum_rows")
+            else:
+                d_a = torch.zeros(ctx.a_shape, device=dev, dtype=torch.float32)
+                neuconw.color_net.bwd_stash(cctx, g["d_rgb"].view(R * S, 3), d_grad, d_a, dfeat_ptr)
+            neuconw.sdf_net.bwd_stash(sctx, g["d_sdf"].view(R * S), d_grad)
+        finally:  # the main stream always rejoins the side stream
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
         plans = [sctx["plan"], cctx["plan"]]
         if side is not None:
-            torch.cuda.current_stream(dev).wait_stream(side)
             d_a.add_(d_a_bg)
             plans.append(nctx["plan"])
         elif ctx.use_bg:

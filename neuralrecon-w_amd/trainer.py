@@ -247,7 +247,8 @@ class TrainStep:
         self.capture, self.capture_warmup = bool(capture), int(capture_warmup)
         self._n_eager, self._graphs, self._static = 0, None, None
         self.fp = FlatParams(modules, renderer)
-        self.fp.broadcast(group=group)
+        if world_size > 1:  # DDP's constructor-time broadcast; a world_size-1 TrainStep inside a larger job (one rank's own
+            self.fp.broadcast(group=group)  # diagnostics, e.g. bench.py's parity legs) must not enter a collective
         kw = dict(lr=lr, eps=eps, betas=betas)
         # clip + Adam as ONE C-ABI call (FlatAdam: device-resident step state, so it is graph-capturable too);
         # native_optimizer=False keeps stock torch.optim.Adam over the flat buffer (eager only)
@@ -377,7 +378,33 @@ def reference_param_order(embedding_a, neuconw, nerf):
     return list(embedding_a.parameters()) + list(neuconw.parameters()) + list(nerf.parameters())
 
 
-def save_checkpoint(path, embedding_a, neuconw, nerf, optimizer=None, global_step=0, extra=None, epoch=0):
+def resume_state(optimizer, renderer=None, epoch=0, step_in_epoch=0, generator_state=None):
+    """What a bit-for-bit continuation needs beyond weights and Adam moments (the checkpoint's `ncw_resume` entry): the epoch
+    and the batches of it already consumed, the batch generator's state at the START of that epoch (the epoch's permutation
+    is drawn from it), and the fp16 dynamic loss scale with its clean / skipped step counters (NcwAdamState)."""
+    st = {"epoch": int(epoch), "step_in_epoch": int(step_in_epoch),
+          "generator_state": None if generator_state is None else generator_state.detach().cpu().clone()}
+    if hasattr(optimizer, "state"):  # FlatAdam: device-resident NcwAdamState {step, good, skipped, ...}
+        s_ = optimizer.state.detach().cpu()
+        st.update(adam_good=int(s_[1]), adam_skipped=int(s_[2]))
+    ls = getattr(renderer, "loss_scale", None)
+    if ls is not None:
+        st["loss_scale"] = float(ls.value())
+    return st
+
+
+def apply_resume_state(st, optimizer, renderer=None):
+    """Restores the optimiser-side entries of `resume_state`; returns (epoch, step_in_epoch, generator_state)."""
+    if hasattr(optimizer, "state") and "adam_good" in st:
+        optimizer.state[1] = int(st["adam_good"])
+        optimizer.state[2] = int(st["adam_skipped"])
+    ls = getattr(renderer, "loss_scale", None)
+    if ls is not None and st.get("loss_scale"):
+        ls.set(float(st["loss_scale"]))
+    return int(st.get("epoch", 0)), int(st.get("step_in_epoch", 0)), st.get("generator_state")
+
+
+def save_checkpoint(path, embedding_a, neuconw, nerf, optimizer=None, global_step=0, extra=None, epoch=0, lr_scheduler=None):
     """Writes {'state_dict': {prefix.key: tensor}, 'global_step', 'epoch', ['optimizer_states': [...]]} plus the keys
     PyTorch-Lightning 1.4.8's `resume_from_checkpoint` looks up ('lr_schedulers', 'callbacks',
     'pytorch-lightning_version').  TESTED round trips: the reference's `load_ckpt` / `extract_model_state_dict` (weights)
@@ -387,7 +414,10 @@ def save_checkpoint(path, embedding_a, neuconw, nerf, optimizer=None, global_ste
     for prefix, mod in (("embedding_a", embedding_a), ("neuconw", neuconw), ("nerf", nerf)):
         for k, v in mod.state_dict().items():
             sd[prefix + "." + k] = v.detach().cpu().clone()   # clone: parameters may be views of the flat buffer
-    ckpt = {"state_dict": sd, "global_step": int(global_step), "epoch": int(epoch), "lr_schedulers": [], "callbacks": {},
+    # lr_scheduler: the per-epoch scheduler's state in torch's `_LRScheduler.state_dict()` layout (what PL stores under
+    # 'lr_schedulers'; utils/__init__.py:45-61): {"last_epoch", "_step_count", "_last_lr", ...} -- None for 'none'
+    ckpt = {"state_dict": sd, "global_step": int(global_step), "epoch": int(epoch),
+            "lr_schedulers": [] if lr_scheduler is None else [dict(lr_scheduler)], "callbacks": {},
             "pytorch-lightning_version": "1.4.8"}
     if optimizer is not None:
         if hasattr(optimizer, "torch_state_dict"):  # FlatAdam -> torch.optim.Adam's layout in the reference's parameter

@@ -80,12 +80,13 @@ def main():
               % (len(names), len(cache), dev, steps_per_epoch, lr))
     step_fn = nw.TrainStep(rdr, [emb, neuconw, nerf], C.neuconw_loss(cfg), lr=lr, eps=1e-7, clip=0.99, world_size=world)
     order = trainer.reference_param_order(emb, neuconw, nerf)
-    step = 0
+    step, resume = 0, None
     if args.ckpt_path:
         ck = trainer.load_checkpoint(args.ckpt_path, emb, neuconw, nerf, flat_params=step_fn.fp)
         step = int(ck.get("global_step", 0))
         if ck.get("optimizer_states"):
             step_fn.opt.load_state_dict(ck["optimizer_states"][0], order)
+        resume = ck.get("ncw_resume")
     update_freq = int(n["UPDATE_FREQ"])
     train_level = C.surface_level(n["TRAIN_VOXEL_SIZE"], scene["eval_bbx"]) if update_freq > 0 else None
     save_dir = os.path.join(cfg["TRAINER"]["SAVE_DIR"], args.exp_name)
@@ -93,20 +94,50 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(cfg["TRAINER"]["SEED"] + rank)
     t0, t_last, done = time.perf_counter(), time.perf_counter(), False
-    first_epoch = step // steps_per_epoch
+    # Resume: continue the interrupted epoch where it stopped -- same permutation (the generator goes back to its state at
+    # the start of that epoch), the consumed batches skipped, the fp16 loss scale and its counters restored -- so a resumed
+    # run executes the same steps as an uninterrupted one.  (Checkpoints without `ncw_resume`, e.g. the reference's own:
+    # the epoch restarts from its first batch with a fresh generator, as before.)
+    first_epoch, skip = step // steps_per_epoch, 0
+    if resume is not None:
+        first_epoch, skip, gstate = trainer.apply_resume_state(resume, step_fn.opt, rdr)
+        if world > 1:  # per-rank generator states are not in rank 0's checkpoint: only rank 0 continues its permutation
+            gstate = gstate if rank == 0 else None
+        if gstate is not None:
+            gen.set_state(gstate.to(gen.get_state().device))
+        if skip >= steps_per_epoch:
+            first_epoch, skip = first_epoch + 1, 0
+    if resume is not None and update_freq > 0 and step >= update_freq:
+        # the fine octree is not part of a checkpoint: rebuild it from the restored SDF (identical to the uninterrupted run's
+        # when the checkpoint was written right after a refresh, i.e. at a multiple of UPDATE_FREQ steps)
+        if rdr.octree_data is None:  # normally built by the first render (NEAR_FAR_OVERRIDE) -- here before any
+            rdr.octree_data = rdr.get_octree(dev)
+        voxel.octree_update(rdr, train_level, n["SDF_THRESHOLD"])
+    sched_kind = cfg["TRAINER"].get("LR_SCHEDULER", "none")
+
+    def sched_state(epoch_):  # torch _LRScheduler.state_dict() entries PL restores (utils/__init__.py:45-61)
+        if sched_kind in (None, "none"):
+            return None
+        cur = C.lr_at_epoch(cfg, lr, epoch_, args.num_epochs)
+        return {"last_epoch": int(epoch_), "_step_count": int(epoch_) + 1, "_last_lr": [cur], "base_lrs": [lr], "kind": sched_kind}
+
     for epoch in range(first_epoch, args.num_epochs):
         if hasattr(step_fn.opt, "lr"):  # utils/__init__.py:45-61: the scheduler steps once per epoch
             step_fn.opt.lr = C.lr_at_epoch(cfg, lr, epoch, args.num_epochs)
-        for b in cache.epoch(args.batch_size, generator=gen, drop_last=True, max_batches=steps_per_epoch):
+        gen_state0 = gen.get_state()  # the permutation of this epoch is drawn from here
+        in_epoch = skip if epoch == first_epoch else 0
+        for b in cache.epoch(args.batch_size, generator=gen, drop_last=True, max_batches=steps_per_epoch, skip_batches=in_epoch):
             rdr.nerf_far_override = False  # neuconw_system.py:343: training always reads near / far from the cache
             ratio = 1.0 if n["ANNEAL_END"] == 0 else min(1.0, step / n["ANNEAL_END"])
             loss, out = step_fn(b["rays"], b["ts"], b["semantics"], b["rgbs"], background_rgb=bg, cos_anneal_ratio=ratio)
             if update_freq > 0 and (step + 1) % update_freq == 0:  # :361-365
                 voxel.octree_update(rdr, train_level, n["SDF_THRESHOLD"])
-            if step % cfg["TRAINER"]["SAVE_FREQ"] == 0 and rank == 0:  # :367-374
+            in_epoch += 1
+            if step % cfg["TRAINER"]["SAVE_FREQ"] == 0 and rank == 0:  # :367-374  (written AFTER the step: global_step + 1 done)
                 os.makedirs(save_dir, exist_ok=True)
                 trainer.save_checkpoint(os.path.join(save_dir, "iter_%d.ckpt" % step), emb, neuconw, nerf,
-                                        optimizer=step_fn.opt, global_step=step, epoch=epoch)
+                                        optimizer=step_fn.opt, global_step=step + 1, epoch=epoch, lr_scheduler=sched_state(epoch),
+                                        extra={"ncw_resume": trainer.resume_state(step_fn.opt, rdr, epoch, in_epoch, gen_state0)})
             if rank == 0 and step % args.log_every == 0:
                 now = time.perf_counter()
                 gn = float(getattr(step_fn, "last_grad_norm", float("nan")))
@@ -125,7 +156,9 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         os.makedirs(save_dir, exist_ok=True)
-        trainer.save_checkpoint(os.path.join(save_dir, "last.ckpt"), emb, neuconw, nerf, optimizer=step_fn.opt, global_step=step)
+        trainer.save_checkpoint(os.path.join(save_dir, "last.ckpt"), emb, neuconw, nerf, optimizer=step_fn.opt, global_step=step,
+                                epoch=epoch, lr_scheduler=sched_state(epoch),
+                                extra={"ncw_resume": trainer.resume_state(step_fn.opt, rdr, epoch, in_epoch, gen_state0)})
         print("%d steps in %.1f s; wrote %s" % (step, time.perf_counter() - t0, os.path.join(save_dir, "last.ckpt")))
     print("[rank %d] finished after %d steps with %d rays resident" % (rank, step, len(cache)))
     if world > 1:

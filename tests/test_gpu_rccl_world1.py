@@ -23,7 +23,7 @@ def test_collective_call_sites_run_over_rccl_with_one_rank():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_world1_worker.py")], capture_output=True, text=True,
-                       env=env, timeout=600, cwd=ROOT)
+                       env=env, timeout=180, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     print(out)

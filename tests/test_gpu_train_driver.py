@@ -91,6 +91,39 @@ def test_train_driver_runs_refreshes_the_octree_and_resumes(tmp_path):
     assert "step 7 " in r2.stdout and "step 8 " in r2.stdout and "step 6 " not in r2.stdout
 
 
+def test_resumed_run_equals_the_uninterrupted_run(tmp_path):
+    """fp32 mode (bitwise reproducible): 9 steps in one go == 6 steps + a resumed run to 9, bit for bit.  Needs everything the
+    checkpoint's `ncw_resume` entry carries: the interrupted epoch's permutation (generator state at the start of the epoch),
+    the batches already consumed, the cosine schedule's epoch -- and the fine octree rebuilt from the restored SDF (the
+    checkpoint is written right after a refresh: UPDATE_FREQ 3)."""
+    root = str(tmp_path / "scene")
+    cfg = _write_scene(root)
+    exp = yaml.safe_load(open(cfg))
+    exp["TRAINER"]["LR_SCHEDULER"] = "cosine"
+    yaml.safe_dump(exp, open(cfg, "w"))
+    base = [sys.executable, os.path.join(ROOT, "scripts", "train.py"), "--cfg_path", cfg, "--batch_size", "64", "--num_epochs", "3",
+            "--prec", "f32", "--log_every", "1"]
+
+    def run(extra):
+        r = subprocess.run(base + extra, capture_output=True, text=True, cwd=ROOT, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return r.stdout
+
+    run(["--max_steps", "9", "--exp_name", "full"])
+    run(["--max_steps", "6", "--exp_name", "part"])
+    ck6 = torch.load(os.path.join(root, "ckpts", "part", "last.ckpt"), map_location="cpu")
+    assert ck6["ncw_resume"]["generator_state"] is not None and ck6["lr_schedulers"] and ck6["lr_schedulers"][0]["kind"] == "cosine"
+    out = run(["--max_steps", "9", "--exp_name", "rest", "--ckpt_path", os.path.join(root, "ckpts", "part", "last.ckpt")])
+    assert "step 6 " in out and "step 8 " in out and "step 5 " not in out
+    a = torch.load(os.path.join(root, "ckpts", "full", "last.ckpt"), map_location="cpu")
+    b = torch.load(os.path.join(root, "ckpts", "rest", "last.ckpt"), map_location="cpu")
+    assert a["global_step"] == b["global_step"] == 9
+    for k in a["state_dict"]:
+        assert torch.equal(a["state_dict"][k], b["state_dict"][k]), k
+    for i in a["optimizer_states"][0]["state"]:
+        assert torch.equal(a["optimizer_states"][0]["state"][i]["exp_avg_sq"], b["optimizer_states"][0]["state"][i]["exp_avg_sq"]), i
+
+
 def test_two_ranks_with_unequal_caches_run_the_same_number_of_steps(tmp_path):
     """World size 2 (both ranks on GPU 0, gloo): three chunks of different length -> `_get_local_split` pads to four, the
     black-list prefilter removes different numbers of rays per rank, so the ranks' caches differ in length.  Every rank must
