@@ -271,6 +271,8 @@ typedef struct NcwNerfStash {
     void* zfeat;     /* rbn                             */
     void* ze[4];     /* rbh                             */
     void* zrgb;      /* 1 block: features 0..2          */
+    const float* aux_bias; /* NULL, or [R, 32 rbh] fp32 from ncw_aux_ray_bias (as NcwColorStash.aux_bias): the per-ray part of
+                            * apperence_encoding.static_linear_0 (models/nerf.py:131-139,173-174), forward only */
 } NcwNerfStash;
 
 /* pts: mode 2 on z_feed (section mid-points, inverted-sphere reparametrisation applied inside), or

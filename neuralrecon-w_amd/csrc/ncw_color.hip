@@ -21,19 +21,6 @@ NCW_DEV void build_aux2(CVec<1>& aux, const float (&x)[3], const float (&nrm)[3]
     }
 }
 
-NCW_DEV void act_zero(Act<PrecF32, 3>& a) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a.v[i][r] = 0.f;
-}
-NCW_DEV void act_zero(Act<PrecBF16, 3>& a) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a.f[i][e] = (ncw_h16)0.f;
-}
-
 template <class P, int RBF, int RBH, int RBC>
 struct ColShapes {
     // both colour kernels fit 256 registers at d_feature = 256: 2 workgroups / CU; with a 512-wide feature
@@ -79,7 +66,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
         to_act(aux1a, aux1);
         // per-ray part of the head's first layer evaluated in fp32 by ncw_aux_ray_bias: the AUX1 operand of THIS pass is
         // zero (the stash above keeps the real one for the backward and the weight gradients)
-        if (st.aux_bias != nullptr) act_zero(aux1a);
+        if (st.aux_bias != nullptr) ncw_act_zero3(aux1a);
     }
     Act<P, 1> aux2a;
     {
@@ -111,17 +98,8 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
     {
         CVec<RBH> e;
         load_bias(e, net.b_e[0], lane);
-        if (st.aux_bias != nullptr) {  // + W_e0[:, dir | a] . [gamma_4(d) | a] of this point's ray (fp32, [R][32 RBH])
-            const f32x4* ab = reinterpret_cast<const f32x4*>(st.aux_bias + ray * (32 * RBH)) + (lane >> 5);
-#pragma unroll
-            for (int rb = 0; rb < RBH; ++rb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 t = ab[rb * 8 + 2 * g];  // features 32 rb + 8 g + 4 h .. + 3
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) e.v[rb][4 * g + c] += t[c];
-                }
-        }
+        // + W_e0[:, dir | a] . [gamma_4(d) | a] of this point's ray (fp32, [R][32 RBH])
+        if (st.aux_bias != nullptr) ncw_add_ray_bias<RBH>(e, st.aux_bias + ray * (32 * RBH), lane);
         const void* wn = net.n_head > 1 ? net.w_e[1] : net.w_l[0];
         const int nb = net.n_head > 1 ? SH::FCB_E : SH::FCB_L0;
         mma_stream<RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e[0], wn, nb, lane);

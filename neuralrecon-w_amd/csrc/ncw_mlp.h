@@ -305,6 +305,37 @@ NCW_DEV void build_aux1(CVec<3>& aux, const float (&dir)[3], const float* __rest
         }
 }
 
+// 16-bit modes: the AUX1 columns of an appearance head's first layer are evaluated once per RAY in fp32 (ncw_aux_ray_bias) and
+// enter the fused kernels as a per-ray bias row [32 RB] (f32, C-layout feature order = plain feature index); the AUX1
+// operand of the forward pass is then zero.
+NCW_DEV void ncw_act_zero3(Act<PrecF32, 3>& a) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.v[i][r] = 0.f;
+}
+NCW_DEV void ncw_act_zero3(Act<PrecBF16, 3>& a) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a.f[i][e] = (ncw_h16)0.f;
+}
+// block rb of the row: features 32 rb + 8 g + 4 h + c <-> register 4 g + c of half h
+NCW_DEV void ncw_add_ray_bias_block(f32x16& v, const float* __restrict__ row, int rb, int lane) {
+    const f32x4* ab = reinterpret_cast<const f32x4*>(row) + 8 * rb + (lane >> 5);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = ab[2 * g];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[4 * g + c] += t[c];
+    }
+}
+template <int RB>
+NCW_DEV void ncw_add_ray_bias(CVec<RB>& e, const float* __restrict__ row, int lane) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) ncw_add_ray_bias_block(e.v[rb], row, rb, lane);
+}
+
 // d_a[ray][j] += sum over the wave's points of the AUX1-part adjoint (features 27 .. 27+n_a)
 // rows != nullptr: store this point's adjoint as row p of rows[n][n_a] instead (no atomics; ncw_ray_sum_rows adds a
 // ray's rows in sample order -- the reproducible path of the fp32 parity mode)

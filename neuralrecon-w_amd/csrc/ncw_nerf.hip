@@ -74,6 +74,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
         build_aux1<Fast<P>::v>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
         stash_store<3>((SE*)st.aux1, tile, aux1, lane);
         to_act(aux1a, aux1);
+        if (st.aux_bias != nullptr) ncw_act_zero3(aux1a);  // the per-ray part of the head comes from ncw_aux_ray_bias (fp32)
     }
     auto next_trunk = [&](int i, const void*& w, int& bytes) {  // matrix consumed after trunk layer i
         const int m = i + 1;
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
     Act<P, RBH> ea;
     {
         load_bias(e, net.b_a[0], lane);
+        if (st.aux_bias != nullptr) ncw_add_ray_bias<RBH>(e, st.aux_bias + ray * (32 * RBH), lane);
         wn = net.n_head > 1 ? net.w_a[1] : net.w_rgb;
         nb = net.n_head > 1 ? SH::FCB_A : SH::FCB_RGB;
         mma_stream<RBN + 3, RBH, 32 * RBN + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_a[0], wn, nb, lane);

@@ -154,9 +154,9 @@ NCW_DEV void pp_epi_step(int u, const PPAcc<NB>& e, bf16x8 (&frag)[NB], pp_lfrag
     }
 }
 
-#ifdef NCW_HALF_F16
+#if defined(NCW_HALF_F16) && defined(NCW_PROBE_BUILD)
 // ------------------------------------------------------------------------------------------------
-// Packed-fp16 Softplus epilogues (round 4 experiment, fp16 build only: gfx950 has no packed bf16 VALU arithmetic).
+// PROBE BUILDS ONLY (NCW_BUILD_TAG): packed-fp16 Softplus epilogues (round 4 experiment, fp16 build only: gfx950 has no packed bf16 VALU arithmetic).
 // The f32 form costs, per PAIR of accumulator registers, 8 plain VALU + 4 transcendentals + the f32 -> f16 conversion, i.e.
 // more VALU-pipe time than the pair's two MFMAs need matrix-pipe time.  The activation is rounded to fp16
 // for the next layer's B operand anyway, so the pair is converted FIRST (one v_cvt_pk_f16_f32) and the Softplus runs on
@@ -166,6 +166,10 @@ NCW_DEV void pp_epi_step(int u, const PPAcc<NB>& e, bf16x8 (&frag)[NB], pp_lfrag
 //   EPI 2 ("poly16"): y = max(z, 0) + c(min(|z|, 0.06)), c = log1p(exp(-100 a)) / 100 as a degree-4 polynomial in
 //                    a (fit error 8.4e-6, fp16 Horner 2.5e-5): 9 plain VALU per PAIR, no transcendental.
 // Value-only kernel: nothing recomputes Softplus' from these activations.
+// MEASURED (profiles/r04/pp_epilogue.log, MI355X, plain fp16 sdf_infer, 131,072 / 1,048,576 points): f32 epilogue 0.216 / 1.283 ms
+// (30.0 % of the MFMA peak at 1 M points), pk16 0.211 / 1.283 ms -- no gain: v_exp_f16 / v_log_f16 are not packed, the compiler
+// needs two v_pack_b32_f16 around them: 7 plain + 4 transcendental per pair against 8 + 4 -- poly16 0.194 / 1.133 ms (34.0 %)
+// but max |sdf - fp64| 2.1e-3 against 6.0e-4: rejected.  Whole-kernel VALU per MFMA 8.57 / 8.31 / 7.77.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 pp_h2 __attribute__((ext_vector_type(2)));
 typedef float pp_f2 __attribute__((ext_vector_type(2)));
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
 #define PP_SEG_END() pp_barrier()
     pp_barrier();
     auto softplus_f = [](float z, int, int, int) { return pp_softplus(z); };
-#ifdef NCW_HALF_F16
+#if defined(NCW_HALF_F16) && defined(NCW_PROBE_BUILD)
 #define PP_EPI(u, acc, outp)                                                                   \
     do {                                                                                       \
         if (EPI == 0) pp_epi_step<NB>(u, acc, frag, outp, ob, NW, lane, softplus_f);           \
@@ -349,8 +353,8 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
 int NCW_FN(ncw_sdf_inferC_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
     const dim3 grid((unsigned)((tiles + PP_TILES - 1) / PP_TILES));
-#ifdef NCW_HALF_F16
-    // round-4 A/B (scripts/diag/pp_epilogue.py): NCW_PP_EPI = f32 | pk16 | poly16, read once
+#if defined(NCW_HALF_F16) && defined(NCW_PROBE_BUILD)
+    // round-4 A/B (scripts/diag/pp_epilogue.py, probe library only): NCW_PP_EPI = f32 | pk16 | poly16, read once
     static const int epi = [] {
         const char* e = getenv("NCW_PP_EPI");
         return e == nullptr ? 0 : (!strcmp(e, "pk16") ? 1 : (!strcmp(e, "poly16") ? 2 : 0));

@@ -299,10 +299,12 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
                                                                  float* __restrict__ density, float* __restrict__ rgb,
                                                                  NcwNerfStash st) {
     typedef ncw_h16 SE;
-    __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_X];
+    __shared__ __attribute__((aligned(16))) char lds[2 * SB_ACT + SB_X + SB_TILES * 32 * 4];
     sb_lfrag* const abuf0 = (sb_lfrag*)(ncw_lchar*)lds;
     sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
     sb_lfrag* const xbuf = abuf0 + 2 * SB_ACT / 16;
+    typedef __attribute__((address_space(3))) int sb_lint;
+    sb_lint* const rbuf = (sb_lint*)(xbuf + SB_X / 16);  // ray index of every point of the workgroup (per-ray head bias)
     const int lane = ncw_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t tile0 = (int64_t)blockIdx.x * SB_TILES;
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
             inverted_sphere8(xs, p4);
         }
         const float dir[3] = {src.rays_d[ray * 3 + 0], src.rays_d[ray * 3 + 1], src.rays_d[ray * 3 + 2]};
+        if (lane < 32) rbuf[wave * 32 + lane] = (int)ray;
         CVec<3> gp;
         freq_encode<3, 4, 10, true>(gp, p4, lane);
         stash_store<3>((SE*)st.gp, (size_t)(tile0 + wave), gp, lane);
@@ -461,10 +464,15 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
                 acc0 = NCW_MFMA_H(wa[q], in[(ta * 16 + q) * 64 + lane], acc0, 0, 0, 0);
                 acc1 = NCW_MFMA_H(wa[q], in[(tb * 16 + q) * 64 + lane], acc1, 0, 0, 0);
             }
+            if (st.aux_bias != nullptr) {  // the AUX1 columns: per-ray fp32 rows of ncw_aux_ray_bias instead of 16-bit operands
+                ncw_add_ray_bias_block(acc0, st.aux_bias + (size_t)rbuf[ta * 32 + (lane & 31)] * 128, hb, lane);
+                ncw_add_ray_bias_block(acc1, st.aux_bias + (size_t)rbuf[tb * 32 + (lane & 31)] * 128, hb, lane);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                acc0 = NCW_MFMA_H(wx[q], xbuf[(ta * 6 + q) * 64 + lane], acc0, 0, 0, 0);
-                acc1 = NCW_MFMA_H(wx[q], xbuf[(tb * 6 + q) * 64 + lane], acc1, 0, 0, 0);
+                for (int q = 0; q < 6; ++q) {
+                    acc0 = NCW_MFMA_H(wx[q], xbuf[(ta * 6 + q) * 64 + lane], acc0, 0, 0, 0);
+                    acc1 = NCW_MFMA_H(wx[q], xbuf[(tb * 6 + q) * 64 + lane], acc1, 0, 0, 0);
+                }
             }
         } else {
 #pragma unroll

@@ -1,5 +1,7 @@
 """Host-side mirror of the reference's models/nerf.py NeRF (background network): same ctor,
 same state_dict keys; compute in libneuconw_hip.so (ncw_nerf_fwd / ncw_nerf_bwd)."""
+import ctypes
+import os
 from collections import OrderedDict
 
 import torch
@@ -40,6 +42,7 @@ class NeRF(_PackedNet):
         self.feature_linear = nn.Linear(W, W)
         self.alpha_linear = nn.Linear(W, 1)
         self.rgb_linear = nn.Linear(W // 2, 3)
+        self.ray_bias = os.environ.get("NEUCONW_COLOR_RAY_BIAS", "1") != "0"  # fwd_stash: per-ray fp32 head columns (16-bit modes)
         self._init_plans()
 
     @property
@@ -153,6 +156,20 @@ class NeRF(_PackedNet):
             rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
         a = a.contiguous().float()
         x4c = x4.contiguous().float() if x4 is not None else None
+        # 16-bit modes: the appearance head's view-direction / appearance-code columns once per ray in fp32 (as
+        # RenderingNetwork.fwd_stash; models/nerf.py:131-139,173-174).  Forward only.
+        st.aux_bias = None
+        lin0 = self.apperence_encoding[0]
+        if prec != L.PREC_F32 and self.ray_bias and pts.rays_d and hasattr(lin0, "weight"):
+            R, no = a.shape[0], 32 * RBH
+            ab = ent.get("aux_bias")
+            if ab is None or ab.shape[0] != R:
+                ab = ent["aux_bias"] = torch.empty(R, no, device=dev, dtype=torch.float32)
+            w0 = lin0.weight.detach()
+            assert w0.is_contiguous() and w0.dtype == torch.float32 and w0.shape == (self.W // 2, self.W + 27 + self.in_channels_a)
+            L.check(L.get_lib().ncw_aux_ray_bias(L.ptr(w0), w0.shape[1], self.W, self.W // 2, ctypes.c_void_p(pts.rays_d), L.ptr(a),
+                                                 self.in_channels_a, R, L.ptr(ab), no, L.stream_ptr(dev)), "ncw_aux_ray_bias")
+            st.aux_bias = ab.data_ptr()
         L.check(L.get_lib().ncw_nerf_fwd(plan.net, prec, pts, L.ptr(x4c), n, L.ptr(a), L.ptr(density), L.ptr(rgb), st,
                                          L.stream_ptr(dev)), "ncw_nerf_fwd")
         return density, rgb, dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, keep=(a, x4c),

@@ -383,7 +383,11 @@ def resume_state(optimizer, renderer=None, epoch=0, step_in_epoch=0, generator_s
     and the batches of it already consumed, the batch generator's state at the START of that epoch (the epoch's permutation
     is drawn from it), and the fp16 dynamic loss scale with its clean / skipped step counters (NcwAdamState)."""
     st = {"epoch": int(epoch), "step_in_epoch": int(step_in_epoch),
-          "generator_state": None if generator_state is None else generator_state.detach().cpu().clone()}
+          "generator_state": None if generator_state is None else generator_state.detach().cpu().clone(),
+          # the sampler's jitter (renderer.py:477-480,536-541 `torch.rand`) draws from the device's global generator
+          "cuda_rng_state": torch.cuda.get_rng_state(optimizer.fp.flat_grad.device).clone()
+          if hasattr(optimizer, "fp") and optimizer.fp.flat_grad.is_cuda else None,
+          "cpu_rng_state": torch.get_rng_state().clone()}
     if hasattr(optimizer, "state"):  # FlatAdam: device-resident NcwAdamState {step, good, skipped, ...}
         s_ = optimizer.state.detach().cpu()
         st.update(adam_good=int(s_[1]), adam_skipped=int(s_[2]))
@@ -401,6 +405,10 @@ def apply_resume_state(st, optimizer, renderer=None):
     ls = getattr(renderer, "loss_scale", None)
     if ls is not None and st.get("loss_scale"):
         ls.set(float(st["loss_scale"]))
+    if st.get("cuda_rng_state") is not None and hasattr(optimizer, "fp") and optimizer.fp.flat_grad.is_cuda:
+        torch.cuda.set_rng_state(st["cuda_rng_state"], optimizer.fp.flat_grad.device)
+    if st.get("cpu_rng_state") is not None:
+        torch.set_rng_state(st["cpu_rng_state"])
     return int(st.get("epoch", 0)), int(st.get("step_in_epoch", 0)), st.get("generator_state")
 
 

@@ -3,6 +3,8 @@ epilogue against the two packed-fp16 forms (NCW_PP_EPI = f32 | pk16 | poly16, re
 variant).  Per variant: ms per 131,072 and per 1,048,576 points (HIP events, median of 20), algorithmic TFLOP/s and fraction of
 the 2.5 PFLOP/s dense peak (SDF value chain: 459,008 MAC per point), max |sdf - fp64 oracle| on 8,192 points.
 
+The packed variants exist only in a PROBE library (the product build has the f32 epilogue alone):
+    NCW_BUILD_TAG=epi python -m neuralrecon_w_amd.build && NEUCONW_HIP_LIB=neuralrecon-w_amd/libneuconw_hip_epi.so \
     python scripts/diag/pp_epilogue.py            (driver)      python scripts/diag/pp_epilogue.py --one   (one variant)
 """
 import json
