@@ -42,7 +42,8 @@ class NeRF(_PackedNet):
         self.feature_linear = nn.Linear(W, W)
         self.alpha_linear = nn.Linear(W, 1)
         self.rgb_linear = nn.Linear(W // 2, 3)
-        self.ray_bias = os.environ.get("NEUCONW_COLOR_RAY_BIAS", "1") != "0"  # fwd_stash: per-ray fp32 head columns (16-bit modes)
+        # fwd_stash: per-ray fp32 head columns (16-bit modes); NEUCONW_NERF_RAY_BIAS overrides NEUCONW_COLOR_RAY_BIAS for this net
+        self.ray_bias = os.environ.get("NEUCONW_NERF_RAY_BIAS", os.environ.get("NEUCONW_COLOR_RAY_BIAS", "1")) != "0"
         self._init_plans()
 
     @property

@@ -92,7 +92,7 @@ def test_train_driver_runs_refreshes_the_octree_and_resumes(tmp_path):
 
 
 def test_resumed_run_equals_the_uninterrupted_run(tmp_path):
-    """fp32 mode (bitwise reproducible): 9 steps in one go == 6 steps + a resumed run to 9, bit for bit.  Needs everything the
+    """fp32 mode: 9 steps in one go == 6 steps + a resumed run to 9 (step for step the same losses).  Needs everything the
     checkpoint's `ncw_resume` entry carries: the interrupted epoch's permutation (generator state at the start of the epoch),
     the batches already consumed, the cosine schedule's epoch -- and the fine octree rebuilt from the restored SDF (the
     checkpoint is written right after a refresh: UPDATE_FREQ 3)."""
@@ -109,19 +109,33 @@ def test_resumed_run_equals_the_uninterrupted_run(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         return r.stdout
 
-    run(["--max_steps", "9", "--exp_name", "full"])
+    def losses(out):
+        return {int(l.split("step")[1].split()[0]): float(l.split("loss")[1].split()[0]) for l in out.splitlines() if l.startswith("epoch")}
+
+    full = losses(run(["--max_steps", "9", "--exp_name", "full"]))
     run(["--max_steps", "6", "--exp_name", "part"])
     ck6 = torch.load(os.path.join(root, "ckpts", "part", "last.ckpt"), map_location="cpu")
-    assert ck6["ncw_resume"]["generator_state"] is not None and ck6["lr_schedulers"] and ck6["lr_schedulers"][0]["kind"] == "cosine"
+    assert ck6["ncw_resume"]["generator_state"] is not None and ck6["ncw_resume"]["cuda_rng_state"] is not None
+    assert ck6["lr_schedulers"] and ck6["lr_schedulers"][0]["kind"] == "cosine"
     out = run(["--max_steps", "9", "--exp_name", "rest", "--ckpt_path", os.path.join(root, "ckpts", "part", "last.ckpt")])
-    assert "step 6 " in out and "step 8 " in out and "step 5 " not in out
+    rest = losses(out)
+    assert sorted(rest) == [6, 7, 8], sorted(rest)
+    # the same batches (permutation + consumed-batch offset), the same sampler jitter (device RNG), the same octree: the
+    # per-step losses agree to the print precision; another batch or jitter moves them by 1e-2 (the learning rate of this
+    # recipe, 1.6e-6, is far too small for the WEIGHTS to tell the two apart, and the embedding's scatter-add atomics --
+    # 64 rays on a 64-entry vocabulary -- are order-dependent in the last bit, so nothing here is compared bitwise)
+    for k in (6, 7, 8):
+        assert abs(rest[k] - full[k]) <= 3e-5, (k, rest[k], full[k])
+    assert len({round(v, 4) for v in full.values()}) > 5  # the batches do differ from step to step
     a = torch.load(os.path.join(root, "ckpts", "full", "last.ckpt"), map_location="cpu")
     b = torch.load(os.path.join(root, "ckpts", "rest", "last.ckpt"), map_location="cpu")
     assert a["global_step"] == b["global_step"] == 9
     for k in a["state_dict"]:
-        assert torch.equal(a["state_dict"][k], b["state_dict"][k]), k
-    for i in a["optimizer_states"][0]["state"]:
-        assert torch.equal(a["optimizer_states"][0]["state"][i]["exp_avg_sq"], b["optimizer_states"][0]["state"][i]["exp_avg_sq"]), i
+        assert torch.allclose(a["state_dict"][k], b["state_dict"][k], rtol=0, atol=2e-6), k
+    sa, sb = a["optimizer_states"][0]["state"], b["optimizer_states"][0]["state"]
+    for i in sa:
+        assert float(sa[i]["step"]) == float(sb[i]["step"]) == 9.0
+        assert torch.allclose(sa[i]["exp_avg"], sb[i]["exp_avg"], rtol=2e-2, atol=1e-7 * float(sa[i]["exp_avg"].abs().max() + 1e-30) + 1e-12), i
 
 
 def test_two_ranks_with_unequal_caches_run_the_same_number_of_steps(tmp_path):
