@@ -76,6 +76,49 @@ def test_split_precision_value_path(W, n_layers, skip):
     assert errs[False][0] > 20 * errs[True][0]  # the switch does switch
 
 
+def test_value_path_default_on_trained_weights_and_small_weights():
+    """The value-only entry points (`sdf()`, grid sweep, octree refresh, mesh lattice) default to the split fp16 chain at W = 256.
+    Its lo halves are stored UNSCALED (h16(w - h16(w))), so for |w| or |h| < 0.25 they are fp16 SUBNORMALS: the chain's accuracy
+    rests on the f16 MFMA and the conversions preserving them (they do: flushed lo halves would leave the plain-fp16 error of
+    6e-4).  Checked where it matters: (a) on a TRAINED network (40 fp32 steps, tests/_parity.trained_weights) `sdf()` in its default
+    precision is as close to the fp64 oracle as the exact-fp32 kernels, (b) with every weight scaled to |w| < 0.02 (all lo halves
+    deep in the subnormals, pre-activations tiny) the relative error stays at the fp32 level, (c) no value overflows fp16."""
+    import neuralrecon_w_amd as nw
+    from oracle import neuconw_oracle as O
+    from tests._build import build_system, load_golden_weights
+    from tests._parity import trained_weights
+
+    emb, neuconw, nerf, rdr = build_system(W=256, n_a=48, n_vocab=100, nerf_w=256, color_hidden=256, head=128, seed=5, prec=nw.PREC_F16,
+                                           n_samples=64, n_importance=64)
+    load_golden_weights({k: v.cuda() for k, v in trained_weights(256, 64, 64, 5, 0.0, 40).items()}, emb, neuconw, nerf)
+    net = neuconw.sdf_net
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand(8192, 3, generator=g) * 2 - 1)
+    sd = {"sdf_net." + k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    ref = O.sdf_net(sd, x.double(), with_grad=False)[0]
+    assert net.value_prec() == nw.PREC_F16 and net.split_value(nw.PREC_F16)
+    e_def = rel_err(rdr.sdf(x.cuda()).cpu()[:, 0], ref)
+    e_f32 = rel_err(net.sdf(x.cuda(), prec=nw.PREC_F32).cpu()[:, 0], ref)
+    print("trained weights: sdf() default (split fp16) %.2e, exact-fp32 kernels %.2e" % (e_def, e_f32))
+    assert e_def < 3e-6 and e_def < 3 * e_f32 + 1e-6
+    small = _mk(256, 8, (4,))
+    with torch.no_grad():
+        for n_, p_ in small.named_parameters():
+            if n_.endswith("weight_g"):
+                p_.mul_(0.02 / float(p_.abs().max()) * 16.0)   # row norms -> every |w| < 0.02
+    sd = {"sdf_net." + k: v.detach().cpu().double() for k, v in small.state_dict().items()}
+    ref = O.sdf_net(sd, x.double(), with_grad=False)[0]
+    got = small.sdf(x.cuda(), prec=nw.PREC_F16).cpu()[:, 0]
+    e_small = rel_err(got, ref)
+    wmax = max(float(O._lin_eff(sd, "sdf_net.lin%d" % l)[0].abs().max()) for l in range(1, 8))
+    small.sdf_split = False
+    e_plain = rel_err(small.sdf(x.cuda(), prec=nw.PREC_F16).cpu()[:, 0], ref)
+    small.sdf_split = None
+    print("weights scaled to max |w| = %.3f: split fp16 sdf rel err %.2e (plain fp16 %.2e)" % (wmax, e_small, e_plain))
+    # lo halves flushed to zero would make the split chain the plain one
+    assert wmax < 0.1 and e_small < 5e-5 and e_small * 10 < e_plain and bool(torch.isfinite(got).all())
+
+
 def test_sdf_infer_golden_reference_weights():
     """Weights and outputs straight from the real reference (tests/golden/units_w64.npz)."""
     import neuralrecon_w_amd as nw
