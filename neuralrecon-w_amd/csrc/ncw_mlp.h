@@ -87,6 +87,20 @@ NCW_DEV void stash_store_block(SE* __restrict__ base, size_t tile, int RB, int r
         vec4 t;
 #pragma unroll
         for (int c = 0; c < 4; ++c) t[c] = (SE)v[4 * g + c];
+        NCW_STASH_ST(p[g * 64], t);
+    }
+}
+// default cache policy (ncw_common.h "Cache policy of the stash traffic"): stashes the same or the next kernel re-reads
+template <class SE>
+NCW_DEV void stash_store_block_keep(SE* __restrict__ base, size_t tile, int RB, int rb, const f32x16& v, int lane) {
+    NCW_EXP_STORE_HOOK();
+    typedef SE vec4 __attribute__((ext_vector_type(4)));
+    vec4* p = reinterpret_cast<vec4*>(base) + ((tile * RB + rb) * 4) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        vec4 t;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = (SE)v[4 * g + c];
         p[g * 64] = t;
     }
 }
@@ -97,7 +111,7 @@ NCW_DEV void stash_load_block(f32x16& v, const SE* __restrict__ base, size_t til
     const vec4* p = reinterpret_cast<const vec4*>(base) + ((tile * RB + rb) * 4) * 64 + lane;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        vec4 t = p[g * 64];
+        vec4 t = NCW_STASH_LD(p[g * 64]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[4 * g + c] = (float)t[c];
     }
@@ -127,7 +141,7 @@ NCW_DEV void softplus_epilogue(Act<P, RB>& act, CVec<RB>& acc, typename P::selem
             sv[r] = s;
         }
         if (st_s) stash_store_block(st_s, tile, RB, rb, sv, lane);
-        if (st_h) stash_store_block(st_h, tile, RB, rb, yv, lane);
+        if (st_h) stash_store_block_keep(st_h, tile, RB, rb, yv, lane);  // h_l: re-read by the adjoint sweep of the same kernel
         to_act_block<RB>(act, rb, yv);
     }
 }
@@ -187,7 +201,7 @@ struct SoftplusB {
             sv[r] = sg;
         }
         if (st_s) stash_store_block(st_s, tile, RB, rb, sv, lane);
-        if (st_h) stash_store_block(st_h, tile, RB, rb, yv, lane);
+        if (st_h) stash_store_block_keep(st_h, tile, RB, rb, yv, lane);  // h_l: re-read by the adjoint sweep of the same kernel
         to_act_block<RB>(act, rb, yv);
     }
     NCW_DEV auto b(int rb, int sub) const {

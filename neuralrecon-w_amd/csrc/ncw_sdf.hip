@@ -323,8 +323,8 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RB >= 16 ? 1 : 2)) void sdf_bwd
                 z2[r] = tbar * 100.f * tv[r] * (1.f - sv[r]);
                 ab[r] = tbar * sv[r];  // abar_l
             }
-            stash_store_block((SE*)st.zbar[l], tile, RB, rb, z2, lane);      // temporarily zbar2_l
-            stash_store_block((SE*)st.qbar[l + 1], tile, RB, rb, ab, lane);  // qbar_{l+1} = abar_l
+            stash_store_block_keep((SE*)st.zbar[l], tile, RB, rb, z2, lane);  // temporarily zbar2_l (re-read by pass 2)
+            stash_store_block((SE*)st.qbar[l + 1], tile, RB, rb, ab, lane);  // qbar_{l+1} = abar_l (read by wgrad only)
             to_act_block<RB>(qa, rb, ab);
         }
     }
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RB >= 16 ? 1 : 2)) void sdf_bwd
             stash_load_block(z2, (const SE*)st.zbar[l], tile, RB, rb, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) z2[r] = u.v[rb][r] * sv[r] + z2[r];
-            stash_store_block((SE*)st.zbar[l], tile, RB, rb, z2, lane);
+            stash_store_block((SE*)st.zbar[l], tile, RB, rb, z2, lane);  // final zbar_l (read by wgrad only)
             to_act_block<RB>(za, rb, z2);
         }
         if (l > 0) {

@@ -16,8 +16,12 @@
 // (8,192 cycles).  Nothing spills.
 #include "ncw_mlp.h"
 
-#ifdef S16_EXP_NOSTASH  // timing experiment only: no stash stores (the backward reads garbage)
+#ifdef S16_EXP_NOSTASH  // timing experiment only: no stash stores (the backward reads garbage) -- probe libraries only
+#ifndef NCW_PROBE_BUILD
+#error "S16_EXP_NOSTASH is a probe-only timing hook: build with NCW_BUILD_TAG=<tag> (neuralrecon-w_amd/build.py)"
+#endif
 #define stash_store_block(...) ((void)0)
+#define stash_store_block_keep(...) ((void)0)
 #endif
 
 namespace {
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a = NCW_MFMA_H(w0[j][q], gbuf[(t * 4 + q) * 64 + lane], a, 0, 0, 0);
                 const f32x16 y = s16_softplus(a);
-                stash_store_block((SE*)st.h[1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
+                stash_store_block_keep((SE*)st.h[1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
                 s16_store_units(abuf, t, wave + 8 * j, y, lane);
             }
     }
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x16 y = s16_softplus(acc[j][t]);
-                stash_store_block((SE*)st.h[l + 1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
+                stash_store_block_keep((SE*)st.h[l + 1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
                 s16_store_units(abuf, t, wave + 8 * j, y, lane);
             }
     }
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_bwd16_kernel(NcwSdfNet net
             z2[q] = tbar[q] * 100.f * tv[q] * (1.f - sv[q]);  // a_l phi''(z_l) = 100 t_l (1 - s_l)
             ab[q] = tbar[q] * sv[q];
         }
-        stash_store_block((SE*)st.zbar[l], (size_t)(tile0 + t), 16, ob, z2, lane);
+        stash_store_block_keep((SE*)st.zbar[l], (size_t)(tile0 + t), 16, ob, z2, lane);  // zbar2_l: re-read by pass 2
         stash_store_block((SE*)st.qbar[l + 1], (size_t)(tile0 + t), 16, ob, ab, lane);
         s16_store_units(abuf, t, ob, ab, lane);
     };
@@ -630,7 +634,7 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
             for (int j = 0; j < 2; ++j) {
                 const f32x16 y = s16_softplus(acc[j][t]);
                 const int ob = wave + 8 * j;
-                if (STASH) stash_store_block((SE*)st.h[l_out], (size_t)(tile0 + t), 16, ob, y, lane);
+                if (STASH) stash_store_block_keep((SE*)st.h[l_out], (size_t)(tile0 + t), 16, ob, y, lane);
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     bf16x8 hi, lo;

@@ -159,7 +159,7 @@ NCW_DEV void f_forward_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x16 y = f_softplus(acc[j][t]);
-                if (STASH) stash_store_block((float*)st.h[1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
+                if (STASH) stash_store_block_keep((float*)st.h[1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
                 f_store_units(abuf, t, wave + 8 * j, y, lane);
             }
     }
@@ -176,7 +176,7 @@ NCW_DEV void f_forward_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x16 y = f_softplus(acc[j][t]);
-                if (STASH) stash_store_block((float*)st.h[l + 1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
+                if (STASH) stash_store_block_keep((float*)st.h[l + 1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
                 f_store_units(abuf, t, wave + 8 * j, y, lane);
             }
     }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * F_WAVES) void sdf_bwd16f_kernel(NcwSdfNet net,
             z2[q] = tbar[q] * 100.f * tv[q] * (1.f - sv[q]);  // a_l phi''(z_l) = 100 t_l (1 - s_l)
             ab[q] = tbar[q] * sv[q];
         }
-        stash_store_block((SE*)st.zbar[l], (size_t)(tile0 + t), 16, ob, z2, lane);
+        stash_store_block_keep((SE*)st.zbar[l], (size_t)(tile0 + t), 16, ob, z2, lane);  // zbar2_l: re-read by pass 2
         stash_store_block((SE*)st.qbar[l + 1], (size_t)(tile0 + t), 16, ob, ab, lane);
         f_store_units(abuf, t, ob, ab, lane);
     };

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
             f32x16 yv;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[r], y, s); yv[r] = y; }
-            stash_store_block((SE*)st.h[1], (size_t)(tile0 + t), 8, wave, yv, lane);
+            stash_store_block_keep((SE*)st.h[1], (size_t)(tile0 + t), 8, wave, yv, lane);
             sb_store_units(abuf0, t, wave, yv, lane);
         }
     }
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
                 f32x16 yv;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[r], y, s); yv[r] = y; }
-                stash_store_block((SE*)st.h[l + 1], (size_t)(tile0 + tp + j), 8, wave, yv, lane);
+                stash_store_block_keep((SE*)st.h[l + 1], (size_t)(tile0 + tp + j), 8, wave, yv, lane);
                 sb_store_units(out, tp + j, wave, yv, lane);
             }
         }

@@ -129,7 +129,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
             f32x16 yv;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[t][r], y, s); yv[r] = y; }
-            if (STASH) stash_store_block((SE*)st.h[l_out], (size_t)(tile0 + t), 8, wave, yv, lane);
+            if (STASH) stash_store_block_keep((SE*)st.h[l_out], (size_t)(tile0 + t), 8, wave, yv, lane);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 bf16x8 hi, lo;

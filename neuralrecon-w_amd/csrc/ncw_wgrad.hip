@@ -295,7 +295,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const NcwWgradDesc* __re
             const unsigned uhi = __builtin_amdgcn_readfirstlane((unsigned)(ubi >> 32));
             const unsigned long long ubu = ((unsigned long long)uhi << 32) | ulo;
             const unsigned loff = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lbuf + blk * 2048 + r0 * 256));
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+            // `nt`: every stash operand is read exactly once per product (ncw_common.h "Cache policy of the stash traffic")
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
                          :: "v"(src), "s"(ubu), "s"(loff) : "memory");
         }
     };
