@@ -284,6 +284,10 @@ def parity_errors(got, ref):
     """max |gpu - oracle| / max |oracle| per output (the north star's '1e-4 rel' measure) + the loss difference."""
     e = {"colour": _rel(got["color"], ref["color"]), "depth": _rel(got["depth"], ref["depth"]),
          "weights_sum": _rel(got["weights_sum"], ref["weights_sum"]), "loss": abs(got["loss"] - ref["loss"])}
+    # how the colour error is distributed over the rays (the headline number is the MAX over rays and channels)
+    per_ray = (got["color"].double() - ref["color"].double()).abs().amax(dim=-1) / (ref["color"].double().abs().max() + 1e-12)
+    e["colour_p99"] = float(torch.quantile(per_ray, 0.99))
+    e["colour_rays_above_1e-4"] = float((per_ray > 1e-4).double().mean())
     if "weights" in got and got["weights"].shape == ref["weights"].shape:  # per-SAMPLE compositing weights [R, S + O]
         e["weights"] = _rel(got["weights"], ref["weights"])
     if "sdf" in got and "sdf" in ref:  # SDF values at the oracle's sample positions: absolute (unit-sphere units) and relative

@@ -1,0 +1,17 @@
+#!/bin/bash
+# One gpurun call that verifies a build on the MI355X box: the whole `-m gpu` suite, smoke(), the round's profile set
+# (rocprofv3 kernel stats + PMC passes + the default bench line) and the secondary bench rows.  Every stage runs under
+# `timeout` and writes its own log, so a hang costs one stage, not the call (NOTEBOOK R4.6).
+#     gpurun --timeout 2400 -- 'bash scripts/gpu_verify.sh [tag]'      -> gpurun_out/verify/, gpurun_out/<round>/
+set -u
+cd "$(dirname "$0")/.."
+TAG=${1:-v1}
+OUT=gpurun_out/verify; mkdir -p $OUT; rm -f $OUT/status
+T="timeout -k 10"
+$T 900 python -m pytest tests -m gpu -q --timeout 500 > $OUT/full.log 2>&1; echo "pytest -m gpu rc $?" >> $OUT/status
+$T 100 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc $?" >> $OUT/status
+$T 900 bash scripts/collect_profiles.sh "$TAG" > $OUT/collect.log 2>&1; echo "collect_profiles rc $?" >> $OUT/status
+$T 300 python bench.py --config shipped --no-pmc > $OUT/bench_shipped_2048rays_$TAG.json 2>/dev/null; echo "shipped rc $?" >> $OUT/status
+$T 300 python bench.py --config voxel --no-pmc > $OUT/bench_voxel_$TAG.json 2>/dev/null; echo "voxel rc $?" >> $OUT/status
+$T 300 python bench.py --bg-eliminate --no-cpu-baseline --no-parity-mode > $OUT/bench_elim_$TAG.json 2>/dev/null; echo "elim rc $?" >> $OUT/status
+cat $OUT/status; grep -E "passed|failed" $OUT/full.log | tail -2; grep -E "^FAILED" $OUT/full.log; tail -3 $OUT/smoke.log
