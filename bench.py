@@ -535,10 +535,15 @@ def main():
         backend = os.environ.get("NCW_DIST_BACKEND", "nccl")
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
+        import datetime
+
+        # rank 0 runs the CPU baseline / parity / PMC legs alone while the other ranks wait in a barrier (1-4 min): give the
+        # collective watchdog room
+        tmo = datetime.timedelta(minutes=30)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (torch.distributed.run --nproc-per-node must equal --gpus)"
                          % (args.gpus, world))
@@ -722,7 +727,7 @@ def main():
                                      "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "ROLE_NAME")}
                 vis = os.environ.get("HIP_VISIBLE_DEVICES")
                 env1["HIP_VISIBLE_DEVICES"] = vis.split(",")[local_rank] if vis else str(local_rank)
-            per_kernel, step_bytes = pmc_traffic(inner, inner_steps + inner_warm, env=env1)
+            per_kernel, step_bytes = pmc_traffic(inner, inner_steps + inner_warm, timeout=240 if world == 1 else 150, env=env1)
             if per_kernel:
                 sel = [v for k, v in per_kernel.items() if PMC_KERNEL.get(dom, "\0") in k]
                 roofline["traffic"] = round(max(sel), 0) if sel else None
