@@ -1,5 +1,7 @@
 """Activation-stash arenas and batched weight-gradient launches (host side)."""
 
+import os
+
 import torch
 
 from . import lib as L
@@ -61,7 +63,7 @@ class WgradBatch:
     PER PRODUCT such that the launch is ~3 rounds of equal-length workgroups over the 256 CUs
     (scripts/bench_wgrad.py: 5.2 TB/s of stash bytes, against 4.3 TB/s for one launch per network/shape).  f32: the exact kernel, one launch per point count."""
 
-    TARGET_WGS = 768
+    TARGET_WGS = int(os.environ.get("NCW_WGRAD_TARGET_WGS", "768"))  # (env: tuning hook of scripts/diag/wgrad_rounds.sh)
     SEL_FRACTION = 0.125
 
     def __init__(self, device, prec, n_points, n_dev=None):
