@@ -215,6 +215,11 @@ typedef struct NcwColorNet {
     int32_t n_head;  /* static_head_layers                       */
     int32_t n_lin;   /* trunk Linear count (n_layers + 1)        */
     int32_t rbf, rbh, rbc, n_a;
+    /* fp16 mode, FORWARD only: the residual matrices h16(W - h16(W)) of the forward matrices above (packed with
+     * NcwPackDesc.residual); NULL = one rounding per weight.  With them ncw_color_fwd evaluates W_hi x + W_lo x: on trained
+     * weights the colour network's weight rounding was the largest remaining term of the fp16 mode's colour error
+     * (scripts/diag/emul_color16.py: 5 % of the rays above 1e-4 -> none). */
+    const void* w_f_lo; const void* w_e_lo[4]; const void* w_l_lo[8];
 } NcwColorNet;
 
 typedef struct NcwColorStash {

@@ -21,6 +21,21 @@ NCW_DEV void build_aux2(CVec<1>& aux, const float (&x)[3], const float (&nrm)[3]
     }
 }
 
+// acc += W in with W as a 16-bit hi + lo pair (w_lo: the residual matrix h16(W - h16(W)), same packed shape; nullptr = hi only):
+// two passes of the weight ring over the same activations.  self_bytes = first-chunk bytes of this matrix shape (what the
+// call before must have prefetched: the lo pass re-uses it), w_next / next_bytes as mma_stream.
+template <bool SPLIT, int RB_IN, int RB_OUT, int K_REAL, int SLOT, class P>
+NCW_DEV void mma_stream_split(CVec<RB_OUT>& acc, const Act<P, RB_IN>& in, WRing& ring, const typename P::welem* __restrict__ w_hi,
+                              const void* w_lo, int self_bytes, const void* w_next, int next_bytes, int lane) {
+    typedef typename P::welem WE;
+    if (SPLIT) {  // compile-time: a run-time branch here triples the inlined ring loops and the kernel spills
+        mma_stream<RB_IN, RB_OUT, K_REAL, SLOT>(acc, in, ring, w_hi, w_lo, self_bytes, lane);
+        mma_stream<RB_IN, RB_OUT, K_REAL, SLOT>(acc, in, ring, (const WE*)w_lo, w_next, next_bytes, lane);
+    } else {
+        mma_stream<RB_IN, RB_OUT, K_REAL, SLOT>(acc, in, ring, w_hi, w_next, next_bytes, lane);
+    }
+}
+
 template <class P, int RBF, int RBH, int RBC>
 struct ColShapes {
     // both colour kernels fit 256 registers at d_feature = 256: 2 workgroups / CU; with a 512-wide feature
@@ -38,7 +53,7 @@ struct ColShapes {
     static constexpr int FCB_TE0 = ncw_first_chunk_bytes<P, RBH, 32 * RBH, RBF + 3, SLOT>();
 };
 
-template <class P, int RBF, int RBH, int RBC>
+template <class P, int RBF, int RBH, int RBC, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_fwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
                                                                       const float* __restrict__ normals,
                                                                       const float* __restrict__ a,
@@ -87,7 +102,8 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
         }
         CVec<RBF> f;
         load_bias(f, net.b_f, lane);
-        mma_stream<RBF, RBF, 32 * RBF, SH::SLOT>(f, fin, ring, (const WE*)net.w_f, net.w_e[0], SH::FCB_E0, lane);
+        mma_stream_split<SPLIT, RBF, RBF, 32 * RBF, SH::SLOT>(f, fin, ring, (const WE*)net.w_f, net.w_f_lo, SH::FCB_F, net.w_e[0],
+                                                         SH::FCB_E0, lane);
         stash_store<RBF>((SE*)st.f, tile, f, lane);
         Act<P, RBF> fa;
         to_act(fa, f);
@@ -102,13 +118,15 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
         if (st.aux_bias != nullptr) ncw_add_ray_bias<RBH>(e, st.aux_bias + ray * (32 * RBH), lane);
         const void* wn = net.n_head > 1 ? net.w_e[1] : net.w_l[0];
         const int nb = net.n_head > 1 ? SH::FCB_E : SH::FCB_L0;
-        mma_stream<RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e[0], wn, nb, lane);
+        mma_stream_split<SPLIT, RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e[0], net.w_e_lo[0], SH::FCB_E0, wn,
+                                                                  nb, lane);
         relu_epilogue<P, RBH>(ea, e, (SE*)st.e[0], tile, lane);
         for (int i = 1; i < net.n_head; ++i) {
             load_bias(e, net.b_e[i], lane);
             const void* wn2 = i + 1 < net.n_head ? net.w_e[i + 1] : net.w_l[0];
             const int nb2 = i + 1 < net.n_head ? SH::FCB_E : SH::FCB_L0;
-            mma_stream<RBH, RBH, 32 * RBH, SH::SLOT>(e, ea, ring, (const WE*)net.w_e[i], wn2, nb2, lane);
+            mma_stream_split<SPLIT, RBH, RBH, 32 * RBH, SH::SLOT>(e, ea, ring, (const WE*)net.w_e[i], net.w_e_lo[i], SH::FCB_E, wn2, nb2,
+                                                             lane);
             relu_epilogue<P, RBH>(ea, e, (SE*)st.e[i], tile, lane);
         }
     }
@@ -120,19 +138,20 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
         Act<P, RBH + 1> cat2;
         act_concat<RBH, 1>(cat2, ea, aux2a);
         load_bias(x, net.b_l[0], lane);
-        mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l[1],
-                                                          1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
+        mma_stream_split<SPLIT, RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l_lo[0], SH::FCB_L0,
+                                                                net.w_l[1], 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
         relu_epilogue<P, RBC>(xa, x, (SE*)st.x[0], tile, lane);
     }
     for (int l = 1; l < last; ++l) {
         load_bias(x, net.b_l[l], lane);
-        mma_stream<RBC, RBC, 32 * RBC, SH::SLOT>(x, xa, ring, (const WE*)net.w_l[l], net.w_l[l + 1],
-                                                  l + 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
+        mma_stream_split<SPLIT, RBC, RBC, 32 * RBC, SH::SLOT>(x, xa, ring, (const WE*)net.w_l[l], net.w_l_lo[l], SH::FCB_L, net.w_l[l + 1],
+                                                        l + 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
         relu_epilogue<P, RBC>(xa, x, (SE*)st.x[l], tile, lane);
     }
     CVec<1> o;
     load_bias(o, net.b_l[last], lane);
-    mma_stream<RBC, 1, 32 * RBC, SH::SLOT>(o, xa, ring, (const WE*)net.w_l[last], nullptr, 0, lane);
+    mma_stream_split<SPLIT, RBC, 1, 32 * RBC, SH::SLOT>(o, xa, ring, (const WE*)net.w_l[last], net.w_l_lo[last], SH::FCB_LAST, nullptr, 0,
+                                                  lane);
     if (valid && lane < 32) {  // features 0,1,2 <-> registers 0,1,2 of half 0; sigmoid (neuconw.py:168-169)
         rgb[p * 3 + 0] = sigmoidf_<Fast<P>::v>(o.v[0][0]);
         rgb[p * 3 + 1] = sigmoidf_<Fast<P>::v>(o.v[0][1]);
@@ -271,6 +290,18 @@ extern "C" int NCW_FN(ncw_color_fwd)(const NcwColorNet* net, int prec, const Ncw
     if (pts->mode == 4) return NCW_E_UNSUPPORTED;  // point selections: background NeRF kernels only
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (net->w_f_lo != nullptr) {  // forward matrices as hi + lo pairs (NcwColorNet.w_*_lo): the 16-bit widths that ship
+        if (prec == NCW_PREC_F32) return NCW_E_BADARG;
+        const int key = net->rbf * 10000 + net->rbh * 100 + net->rbc;
+        for (int i = 0; i < net->n_head; ++i) if (net->w_e_lo[i] == nullptr) return NCW_E_BADARG;
+        for (int l = 0; l < net->n_lin; ++l) if (net->w_l_lo[l] == nullptr) return NCW_E_BADARG;
+        if (key == 20102) NCW_LAUNCH_TILES((color_fwd_kernel<PrecBF16, 2, 1, 2, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
+        else if (key == 20408) NCW_LAUNCH_TILES((color_fwd_kernel<PrecBF16, 2, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
+        else if (key == 80408) NCW_LAUNCH_TILES((color_fwd_kernel<PrecBF16, 8, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
+        else if (key == 160408) NCW_LAUNCH_TILES((color_fwd_kernel<PrecBF16, 16, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
+        else return NCW_E_UNSUPPORTED;
+        return 0;
+    }
     NCW_COLOR_DISPATCH(color_fwd_kernel, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
     return 0;
 }

@@ -402,6 +402,10 @@ class RenderingNetwork(_PackedNet):
         # 16-bit modes: per-ray fp32 evaluation of the head's view-direction / appearance-code columns (fwd_stash);
         # NEUCONW_COLOR_RAY_BIAS=0 / .ray_bias = False = those columns as 16-bit MFMA operands like the rest
         self.ray_bias = os.environ.get("NEUCONW_COLOR_RAY_BIAS", "1") != "0"
+        # fp16 mode: the forward evaluates every Linear of this network with its weights as fp16 hi + lo pairs (two MFMAs per
+        # product: W_hi x + W_lo x); NEUCONW_COLOR_WSPLIT=0 / .weight_split = False = one rounding per weight (set before the
+        # first forward: the packed-weight plan is built once per precision)
+        self.weight_split = os.environ.get("NEUCONW_COLOR_WSPLIT", "1") != "0"
         self._init_plans()
 
     @property
@@ -415,6 +419,8 @@ class RenderingNetwork(_PackedNet):
         net = L.NcwColorNet()
         sl = {}
 
+        split = prec == L.PREC_F16 and self.weight_split  # forward matrices as fp16 hi + lo pairs (ncw_color_fwd)
+
         def full(name, mod, rb_out, rb_in, segs):
             v, g, b = _wvb(mod)
             m, bs, mt = plan.new_matrix(rb_out, rb_in), plan.new_bias(rb_out), plan.new_matrix(rb_in, rb_out)
@@ -422,7 +428,11 @@ class RenderingNetwork(_PackedNet):
             plan.add_pack(v, g, b, m, bs, segs)
             plan.add_pack(v, g, None, mt, None, segs, transpose=True)
             plan.add_unpack(v, g, b, dn, segs)
-            sl[name] = (m, bs, mt, dn)
+            lo = None
+            if split:
+                lo = plan.new_matrix(rb_out, rb_in)
+                plan.add_pack(v, g, None, lo, None, segs, residual=True)
+            sl[name] = (m, bs, mt, dn, lo)
 
         full("f", self.xyz_encoding_final, RBF, RBF, [(0, W, 0)])
         full("e0", self.static_encoding[0], RBH, RBF + 3, [(0, W, 0), (W, 27 + A, 32 * RBF)])
@@ -434,12 +444,15 @@ class RenderingNetwork(_PackedNet):
         full("l%d" % (self.n_lin - 1), getattr(self, "lin%d" % (self.n_lin - 1)), 1, RBC, [(0, self.d_hidden, 0)])
         plan.finalize()
         net.w_f, net.b_f, net.wt_f = plan.mat_ptr(sl["f"][0]), plan.bias_ptr(sl["f"][1]), plan.mat_ptr(sl["f"][2])
+        net.w_f_lo = plan.mat_ptr(sl["f"][4]) if split else None
         for i in range(self.n_head):
             s = sl["e%d" % i]
             net.w_e[i], net.b_e[i], net.wt_e[i] = plan.mat_ptr(s[0]), plan.bias_ptr(s[1]), plan.mat_ptr(s[2])
+            net.w_e_lo[i] = plan.mat_ptr(s[4]) if split else None
         for l in range(self.n_lin):
             s = sl["l%d" % l]
             net.w_l[l], net.b_l[l], net.wt_l[l] = plan.mat_ptr(s[0]), plan.bias_ptr(s[1]), plan.mat_ptr(s[2])
+            net.w_l_lo[l] = plan.mat_ptr(s[4]) if split else None
         net.n_head, net.n_lin, net.rbf, net.rbh, net.rbc, net.n_a = self.n_head, self.n_lin, RBF, RBH, RBC, A
         plan.net, plan.slots = net, sl
         return plan

@@ -171,12 +171,13 @@ def test_train_step_vs_oracle_after_training(prec_name):
     print("after 40 fp32 steps, variance 0.6, %s:" % prec_name, {k: "%.2e" % v for k, v in r["errs"].items()},
           "grads %.2e (d variance %.2e)" % (g_rest, g_var))
     # Round 4: the head's view-direction / appearance-code columns per ray in fp32 (ncw_aux_ray_bias) for the colour network
-    # AND the background NeRF: fp16 colour 1.88e-4 -> 1.02e-4 (colour net only) -> measured with both: see DESIGN.md 4.
+    # AND the background NeRF: fp16 colour 1.88e-4 -> 1.02e-4 (colour net only) -> 8.7e-5 (both); the colour network's forward
+    # with its weights as fp16 hi + lo pairs (NcwColorNet.w_*_lo): 6.1e-5.  The bound is the north-star bar itself, 1e-4.
     # d(loss)/d(variance) is ONE scalar formed by a cancelling sum over all samples: on these inputs the REFERENCE's own fp32
     # arithmetic gets it to 3.7e-4 with colours at 3.2e-6 (profiles/r04/port_over_reference.json `d_variance_trained`), i.e. it
     # amplifies colour errors ~115x; with fp16 colours at 1e-4 it sits at 1e-2 .. 6e-2 (measured 1.0e-2 / 5.8e-2 with two
     # equally accurate forwards) and gets its own bound; every weight TENSOR stays under the old bound.
-    tol_out, tol_grad, tol_eik, tol_var = {"f32": (1e-4, 2e-3, 1e-4, 2e-3), "f16": (1.2e-4, 2e-2, 4e-4, 0.12),
+    tol_out, tol_grad, tol_eik, tol_var = {"f32": (1e-4, 2e-3, 1e-4, 2e-3), "f16": (1e-4, 2e-2, 4e-4, 0.12),
                                            "bf16": (2.5e-3, 0.18, 1e-2, 0.5)}[prec_name]
     for k, e in r["errs"].items():
         assert e < (tol_eik if k == "gradient_error" else tol_out), (k, e)
