@@ -183,7 +183,7 @@ def cpu_baseline(sample_rays=256, repeats=3, max_threads=32, seed=1000):
         times.append(time.perf_counter() - t0)
     t = sorted(times[1:])[len(times[1:]) // 2]
     S = N_SAMPLES + N_IMPORTANCE
-    ref = {k: out[k].detach() for k in ("color", "depth", "weights_sum", "weights", "z_vals")}
+    ref = {k: out[k].detach() for k in ("color", "depth", "weights_sum", "weights", "z_vals", "gradients", "cdf_fine")}
     ref["loss"] = float(loss.detach())
     ref["sdf"], ref["pts"] = _oracle_sdf_at_samples(sd, rays, ref["z_vals"])
     return {"value": sample_rays * S / t, "unit": "ray-samples/s", "cores": cores, "kind": "port", "repeats": repeats,
@@ -219,7 +219,7 @@ def oracle_outputs(sample_rays=256, seed=1000, variance=None, state=None):
     with torch.no_grad():
         out = O.render(sd, cfg, rays.double(), ts, label, 0.5, torch.zeros(1, 3, dtype=torch.float64))
         loss = O.neuconw_loss(out, rgbs.double(), cfg)
-    ref = {k: out[k] for k in ("color", "depth", "weights_sum", "weights", "z_vals")}
+    ref = {k: out[k] for k in ("color", "depth", "weights_sum", "weights", "z_vals", "gradients", "cdf_fine")}
     ref["loss"] = float(loss)
     ref["sdf"], ref["pts"] = _oracle_sdf_at_samples(sd, rays.double(), ref["z_vals"])
     return ref
@@ -267,7 +267,7 @@ def gpu_outputs(dev, prec, sample_rays=256, seed=1000, variance=None, pts=None, 
         out = rdr.render(rays, ts, label, perturb_overwrite=0, background_rgb=torch.zeros(1, 3, device=dev),
                          cos_anneal_ratio=0.5)
         loss = loss_fn_torch(out, rgbs)
-    got = {k: out[k].detach().cpu() for k in ("color", "depth", "weights_sum", "weights")}
+    got = {k: out[k].detach().cpu() for k in ("color", "depth", "weights_sum", "weights", "gradients", "cdf_fine")}
     got["loss"] = float(loss)
     if pts is not None:  # the SDF network in the timed precision (the sampler's / compositor's queries)
         with torch.no_grad():
@@ -290,6 +290,9 @@ def parity_errors(got, ref):
     e["colour_rays_above_1e-4"] = float((per_ray > 1e-4).double().mean())
     if "weights" in got and got["weights"].shape == ref["weights"].shape:  # per-SAMPLE compositing weights [R, S + O]
         e["weights"] = _rel(got["weights"], ref["weights"])
+    for k in ("gradients", "cdf_fine"):  # per-SAMPLE SDF gradients (normals) [R, S, 3] and the fine CDF [R, S]: index-wise like `weights`
+        if k in got and k in ref and got[k].shape == ref[k].shape:
+            e[k] = _rel(got[k], ref[k])
     if "sdf" in got and "sdf" in ref:  # SDF values at the oracle's sample positions: absolute (unit-sphere units) and relative
         e["sdf_abs"] = float((got["sdf"].double().reshape(-1) - ref["sdf"].double().reshape(-1)).abs().max())
         e["sdf"] = _rel(got["sdf"], ref["sdf"])
