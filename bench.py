@@ -857,6 +857,11 @@ def main():
             try:
                 parity_obj = {"dtype": args.prec, "rays": 256, "measure": "max|gpu - oracle| / max|oracle| (loss: absolute)",
                               "oracle": "fp32 torch-CPU oracle of the cpu_baseline leg (inv_s 20); fp64 oracle at inv_s 403"}
+                # what the UNMODIFIED reference's own fp32 arithmetic differs from the fp64 oracle by on these same 256 rays
+                # (build container, scripts/diag/port_over_reference.py family -> profiles/r04/port_over_reference.json)
+                parity_obj["reference_fp32_vs_fp64_oracle_same_rays"] = {
+                    "inv_s_20": {"colour": 1.09e-05, "depth": 1.73e-06, "weights_sum": 1.08e-05, "weights": 8.27e-04},
+                    "inv_s_403": {"colour": 2.57e-04, "depth": 2.74e-04, "weights_sum": 2.54e-04, "weights": 1.08e-03}}
                 parity_obj["outputs"] = ("colour / depth / weights_sum per ray; `weights` = per-SAMPLE compositing weights [R, S+O]; "
                                          "`sdf` = SDF network at the oracle's sample positions (sdf_abs in unit-sphere units)")
                 parity_obj.update(parity_errors(gpu_outputs(dev, prec, pts=ref32["pts"]), ref32))
