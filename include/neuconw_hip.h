@@ -192,7 +192,11 @@ typedef struct NcwSdfStash {
 } NcwSdfStash;
 
 /* a-2/a-5 forward of the SDF net WITH its analytic input gradient (neuconw.py:263-296):
- * sdf [n], grad [n,3] (= d sdf / d x), plus the stash for the backward.  One launch. */
+ * sdf [n], grad [n,3] (= d sdf / d x), plus the stash for the backward.  One launch.
+ * FORWARD-ONLY form (the reference's validation / novel-view render and vertex colours, rendering/renderer.py:785-916
+ * under no_grad, :951-961; models/neuconw.py:353-376 called without a backward): pass a stash whose t[0] is NULL.  The
+ * outputs are the same bit for bit; of the stash only h[1 .. L-1] (re-read by the adjoint sweep of the SAME launch: it must
+ * exist as scratch, W x 2 B per point and layer) and feat (ncw_color_fwd's input) are written -- no gamma, no t. */
 int ncw_sdf_fwd(const NcwSdfNet* net, int prec, const NcwPoints* pts, int64_t n, float* sdf, float* grad,
                 const NcwSdfStash* stash, void* stream);
 /* First- and second-order backward (SURVEY 8a-2 "parameter-gradient specification"): consumes
@@ -238,7 +242,8 @@ typedef struct NcwColorStash {
 } NcwColorStash;
 
 /* normals [n,3] (the SDF gradient), a [R or n, n_a] appearance rows indexed by the point's ray,
- * feat: stash (rbf blocks) written by ncw_sdf_fwd  ->  rgb [n,3]. */
+ * feat: stash (rbf blocks) written by ncw_sdf_fwd  ->  rgb [n,3].
+ * FORWARD-ONLY form: a stash whose aux1 is NULL (aux_bias stays an input): the same rgb bit for bit, nothing is stored. */
 int ncw_color_fwd(const NcwColorNet* net, int prec, const NcwPoints* pts, int64_t n, const float* normals,
                   const float* a, const void* feat_stash, float* rgb, const NcwColorStash* stash, void* stream);
 /* d_rgb [n,3] -> d_grad[n,3] += d(normals), d_a [R,n_a] += (atomics; zero it first), dfeat stash (rbf),
@@ -282,7 +287,8 @@ typedef struct NcwNerfStash {
 
 /* pts: mode 2 on z_feed (section mid-points, inverted-sphere reparametrisation applied inside), or
  * x4 != NULL: explicit [n,4] points with pts->rays_d / a indexed per point (NeRF.forward API).
- * -> density [n] (raw), rgb [n,3] (raw, no sigmoid). */
+ * -> density [n] (raw), rgb [n,3] (raw, no sigmoid).
+ * FORWARD-ONLY form: a stash whose gp is NULL (aux_bias stays an input): the same outputs bit for bit, nothing is stored. */
 int ncw_nerf_fwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, const float* x4, int64_t n, const float* a,
                  float* density, float* rgb, const NcwNerfStash* stash, void* stream);
 int ncw_nerf_bwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_density,

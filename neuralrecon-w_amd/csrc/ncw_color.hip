@@ -53,14 +53,15 @@ struct ColShapes {
     static constexpr int FCB_TE0 = ncw_first_chunk_bytes<P, RBH, 32 * RBH, RBF + 3, SLOT>();
 };
 
-template <class P, int RBF, int RBH, int RBC, bool SPLIT = false>
-__global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_fwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
-                                                                      const float* __restrict__ normals,
-                                                                      const float* __restrict__ a,
-                                                                      const void* __restrict__ feat_stash,
-                                                                      float* __restrict__ rgb, NcwColorStash st) {
+// TRAIN = false (color_render_kernel): the forward-only render -- the same arithmetic bit for bit, NOTHING is stashed
+// (validation / novel views / vertex colours: rendering/renderer.py:785-916 under no_grad, :951-961 `rgb`).
+template <class P, int RBF, int RBH, int RBC, bool SPLIT, bool TRAIN>
+NCW_DEV void color_fwd_body(const NcwColorNet& net, const NcwPoints& src, int64_t n, const float* __restrict__ normals,
+                            const float* __restrict__ a, const void* __restrict__ feat_stash, float* __restrict__ rgb,
+                            const NcwColorStash& st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
+    auto stp = [](void* p) -> SE* { return TRAIN ? (SE*)p : nullptr; };  // compile-time null: the helpers' `if (st)` folds away
     typedef ColShapes<P, RBF, RBH, RBC> SH;
     NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
     {
         CVec<3> aux1;
         build_aux1<Fast<P>::v>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
-        stash_store<3>((SE*)st.aux1, tile, aux1, lane);
+        if (TRAIN) stash_store<3>((SE*)st.aux1, tile, aux1, lane);
         to_act(aux1a, aux1);
         // per-ray part of the head's first layer evaluated in fp32 by ncw_aux_ray_bias: the AUX1 operand of THIS pass is
         // zero (the stash above keeps the real one for the backward and the weight gradients)
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
     {
         CVec<1> aux2;
         build_aux2(aux2, xs, nrm, lane);
-        stash_store<1>((SE*)st.aux2, tile, aux2, lane);
+        if (TRAIN) stash_store<1>((SE*)st.aux2, tile, aux2, lane);
         to_act(aux2a, aux2);
     }
     // f = xyz_encoding_final(feat)   (no activation, neuconw.py:128,136)
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
         load_bias(f, net.b_f, lane);
         mma_stream_split<SPLIT, RBF, RBF, 32 * RBF, SH::SLOT>(f, fin, ring, (const WE*)net.w_f, net.w_f_lo, SH::FCB_F, net.w_e[0],
                                                          SH::FCB_E0, lane);
-        stash_store<RBF>((SE*)st.f, tile, f, lane);
+        if (TRAIN) stash_store<RBF>((SE*)st.f, tile, f, lane);
         Act<P, RBF> fa;
         to_act(fa, f);
         act_concat<RBF, 3>(cat1, fa, aux1a);
@@ -120,14 +121,14 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
         const int nb = net.n_head > 1 ? SH::FCB_E : SH::FCB_L0;
         mma_stream_split<SPLIT, RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e[0], net.w_e_lo[0], SH::FCB_E0, wn,
                                                                   nb, lane);
-        relu_epilogue<P, RBH>(ea, e, (SE*)st.e[0], tile, lane);
+        relu_epilogue<P, RBH>(ea, e, stp(st.e[0]), tile, lane);
         for (int i = 1; i < net.n_head; ++i) {
             load_bias(e, net.b_e[i], lane);
             const void* wn2 = i + 1 < net.n_head ? net.w_e[i + 1] : net.w_l[0];
             const int nb2 = i + 1 < net.n_head ? SH::FCB_E : SH::FCB_L0;
             mma_stream_split<SPLIT, RBH, RBH, 32 * RBH, SH::SLOT>(e, ea, ring, (const WE*)net.w_e[i], net.w_e_lo[i], SH::FCB_E, wn2, nb2,
                                                              lane);
-            relu_epilogue<P, RBH>(ea, e, (SE*)st.e[i], tile, lane);
+            relu_epilogue<P, RBH>(ea, e, stp(st.e[i]), tile, lane);
         }
     }
     // trunk (neuconw.py:158-166)
@@ -140,13 +141,13 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
         load_bias(x, net.b_l[0], lane);
         mma_stream_split<SPLIT, RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l_lo[0], SH::FCB_L0,
                                                                 net.w_l[1], 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
-        relu_epilogue<P, RBC>(xa, x, (SE*)st.x[0], tile, lane);
+        relu_epilogue<P, RBC>(xa, x, stp(st.x[0]), tile, lane);
     }
     for (int l = 1; l < last; ++l) {
         load_bias(x, net.b_l[l], lane);
         mma_stream_split<SPLIT, RBC, RBC, 32 * RBC, SH::SLOT>(x, xa, ring, (const WE*)net.w_l[l], net.w_l_lo[l], SH::FCB_L, net.w_l[l + 1],
                                                         l + 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
-        relu_epilogue<P, RBC>(xa, x, (SE*)st.x[l], tile, lane);
+        relu_epilogue<P, RBC>(xa, x, stp(st.x[l]), tile, lane);
     }
     CVec<1> o;
     load_bias(o, net.b_l[last], lane);
@@ -157,6 +158,23 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_
         rgb[p * 3 + 1] = sigmoidf_<Fast<P>::v>(o.v[0][1]);
         rgb[p * 3 + 2] = sigmoidf_<Fast<P>::v>(o.v[0][2]);
     }
+}
+
+template <class P, int RBF, int RBH, int RBC, bool SPLIT = false>
+__global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_fwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
+                                                                      const float* __restrict__ normals,
+                                                                      const float* __restrict__ a,
+                                                                      const void* __restrict__ feat_stash,
+                                                                      float* __restrict__ rgb, NcwColorStash st) {
+    color_fwd_body<P, RBF, RBH, RBC, SPLIT, true>(net, src, n, normals, a, feat_stash, rgb, st);
+}
+template <class P, int RBF, int RBH, int RBC, bool SPLIT = false>
+__global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_render_kernel(NcwColorNet net, NcwPoints src, int64_t n,
+                                                                         const float* __restrict__ normals,
+                                                                         const float* __restrict__ a,
+                                                                         const void* __restrict__ feat_stash,
+                                                                         float* __restrict__ rgb, NcwColorStash st) {
+    color_fwd_body<P, RBF, RBH, RBC, SPLIT, false>(net, src, n, normals, a, feat_stash, rgb, st);
 }
 
 template <class P, int RBF, int RBH, int RBC>
@@ -290,19 +308,26 @@ extern "C" int NCW_FN(ncw_color_fwd)(const NcwColorNet* net, int prec, const Ncw
     if (pts->mode == 4) return NCW_E_UNSUPPORTED;  // point selections: background NeRF kernels only
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    const bool render = stash->aux1 == nullptr;  // forward-only render: nothing is stashed (include/neuconw_hip.h, NcwColorStash)
     if (net->w_f_lo != nullptr) {  // forward matrices as hi + lo pairs (NcwColorNet.w_*_lo): the 16-bit widths that ship
         if (prec == NCW_PREC_F32) return NCW_E_BADARG;
         const int key = net->rbf * 10000 + net->rbh * 100 + net->rbc;
         for (int i = 0; i < net->n_head; ++i) if (net->w_e_lo[i] == nullptr) return NCW_E_BADARG;
         for (int l = 0; l < net->n_lin; ++l) if (net->w_l_lo[l] == nullptr) return NCW_E_BADARG;
-        if (key == 20102) NCW_LAUNCH_TILES((color_fwd_kernel<PrecBF16, 2, 1, 2, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
-        else if (key == 20408) NCW_LAUNCH_TILES((color_fwd_kernel<PrecBF16, 2, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
-        else if (key == 80408) NCW_LAUNCH_TILES((color_fwd_kernel<PrecBF16, 8, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
-        else if (key == 160408) NCW_LAUNCH_TILES((color_fwd_kernel<PrecBF16, 16, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
-        else return NCW_E_UNSUPPORTED;
+#define NCW_COLOR_SPLIT_DISPATCH(KERNEL)                                                                                                     \
+        do {                                                                                                                                    \
+            if (key == 20102) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 2, 1, 2, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);        \
+            else if (key == 20408) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 2, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);   \
+            else if (key == 80408) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 8, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);   \
+            else if (key == 160408) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 16, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash); \
+            else return NCW_E_UNSUPPORTED;                                                                                                      \
+        } while (0)
+        if (render) NCW_COLOR_SPLIT_DISPATCH(color_render_kernel);
+        else NCW_COLOR_SPLIT_DISPATCH(color_fwd_kernel);
         return 0;
     }
-    NCW_COLOR_DISPATCH(color_fwd_kernel, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
+    if (render) NCW_COLOR_DISPATCH(color_render_kernel, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
+    else NCW_COLOR_DISPATCH(color_fwd_kernel, *net, *pts, n, normals, a, feat_stash, rgb, *stash);
     return 0;
 }
 

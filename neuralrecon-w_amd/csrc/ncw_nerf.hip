@@ -32,14 +32,14 @@ struct NerfShapes {
     static constexpr int FCB_TPS = ncw_first_chunk_bytes<P, RBN, 32 * RBN, RBN + 3, SLOT>();
 };
 
-template <class P, int RBN, int RBH>
-__global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet net, NcwPoints src,
-                                                                     const float* __restrict__ x4, int64_t n,
-                                                                     const float* __restrict__ a,
-                                                                     float* __restrict__ density, float* __restrict__ rgb,
-                                                                     NcwNerfStash st) {
+// TRAIN = false (nerf_render_kernel): the forward-only render -- the same arithmetic bit for bit, nothing is stashed.
+template <class P, int RBN, int RBH, bool TRAIN>
+NCW_DEV void nerf_fwd_body(const NcwNerfNet& net, const NcwPoints& src, const float* __restrict__ x4, int64_t n,
+                           const float* __restrict__ a, float* __restrict__ density, float* __restrict__ rgb,
+                           const NcwNerfStash& st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
+    auto stp = [](void* p) -> SE* { return TRAIN ? (SE*)p : nullptr; };  // compile-time null: the helpers' `if (st)` folds away
     typedef NerfShapes<P, RBN, RBH> SH;
     NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
@@ -65,14 +65,14 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
     {
         CVec<3> gp;
         freq_encode<3, 4, 10, Fast<P>::v>(gp, p4, lane);
-        stash_store<3>((SE*)st.gp, tile, gp, lane);
+        if (TRAIN) stash_store<3>((SE*)st.gp, tile, gp, lane);
         to_act(gpa, gp);
     }
     Act<P, 3> aux1a;
     {
         CVec<3> aux1;
         build_aux1<Fast<P>::v>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
-        stash_store<3>((SE*)st.aux1, tile, aux1, lane);
+        if (TRAIN) stash_store<3>((SE*)st.aux1, tile, aux1, lane);
         to_act(aux1a, aux1);
         if (st.aux_bias != nullptr) ncw_act_zero3(aux1a);  // the per-ray part of the head comes from ncw_aux_ray_bias (fp32)
     }
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
     load_bias(acc, net.b_p[0], lane);
     next_trunk(0, wn, nb);
     mma_stream<3, RBN, 84, SH::SLOT>(acc, gpa, ring, (const WE*)net.w_p[0], wn, nb, lane);
-    relu_epilogue<P, RBN>(ha, acc, (SE*)st.h[1], tile, lane);
+    relu_epilogue<P, RBN>(ha, acc, stp(st.h[1]), tile, lane);
     for (int i = 1; i < net.D; ++i) {
         load_bias(acc, net.b_p[i], lane);
         next_trunk(i, wn, nb);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
         } else {
             mma_stream<RBN, RBN, 32 * RBN, SH::SLOT>(acc, ha, ring, (const WE*)net.w_p[i], wn, nb, lane);
         }
-        relu_epilogue<P, RBN>(ha, acc, (SE*)st.h[i + 1], tile, lane);
+        relu_epilogue<P, RBN>(ha, acc, stp(st.h[i + 1]), tile, lane);
     }
     // density + feature (nerf.py:170-171)
     {
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
     {
         load_bias(acc, net.b_feat, lane);
         mma_stream<RBN, RBN, 32 * RBN, SH::SLOT>(acc, ha, ring, (const WE*)net.w_feat, net.w_a[0], SH::FCB_A0, lane);
-        stash_store<RBN>((SE*)st.featn, tile, acc, lane);
+        if (TRAIN) stash_store<RBN>((SE*)st.featn, tile, acc, lane);
         Act<P, RBN> fa;
         to_act(fa, acc);
         act_concat<RBN, 3>(cat1, fa, aux1a);
@@ -132,14 +132,14 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
         wn = net.n_head > 1 ? net.w_a[1] : net.w_rgb;
         nb = net.n_head > 1 ? SH::FCB_A : SH::FCB_RGB;
         mma_stream<RBN + 3, RBH, 32 * RBN + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_a[0], wn, nb, lane);
-        relu_epilogue<P, RBH>(ea, e, (SE*)st.e[0], tile, lane);
+        relu_epilogue<P, RBH>(ea, e, stp(st.e[0]), tile, lane);
     }
     for (int i = 1; i < net.n_head; ++i) {
         load_bias(e, net.b_a[i], lane);
         wn = i + 1 < net.n_head ? net.w_a[i + 1] : net.w_rgb;
         nb = i + 1 < net.n_head ? SH::FCB_A : SH::FCB_RGB;
         mma_stream<RBH, RBH, 32 * RBH, SH::SLOT>(e, ea, ring, (const WE*)net.w_a[i], wn, nb, lane);
-        relu_epilogue<P, RBH>(ea, e, (SE*)st.e[i], tile, lane);
+        relu_epilogue<P, RBH>(ea, e, stp(st.e[i]), tile, lane);
     }
     CVec<1> o;
     load_bias(o, net.b_rgb, lane);
@@ -149,6 +149,23 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet 
         rgb[ps * 3 + 1] = o.v[0][1];
         rgb[ps * 3 + 2] = o.v[0][2];
     }
+}
+
+template <class P, int RBN, int RBH>
+__global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_fwd_kernel(NcwNerfNet net, NcwPoints src,
+                                                                     const float* __restrict__ x4, int64_t n,
+                                                                     const float* __restrict__ a,
+                                                                     float* __restrict__ density, float* __restrict__ rgb,
+                                                                     NcwNerfStash st) {
+    nerf_fwd_body<P, RBN, RBH, true>(net, src, x4, n, a, density, rgb, st);
+}
+template <class P, int RBN, int RBH>
+__global__ __launch_bounds__(64 * NCW_WG_WAVES) void nerf_render_kernel(NcwNerfNet net, NcwPoints src,
+                                                                        const float* __restrict__ x4, int64_t n,
+                                                                        const float* __restrict__ a,
+                                                                        float* __restrict__ density, float* __restrict__ rgb,
+                                                                        NcwNerfStash st) {
+    nerf_fwd_body<P, RBN, RBH, false>(net, src, x4, n, a, density, rgb, st);
 }
 
 template <class P, int RBN, int RBH>
@@ -274,7 +291,8 @@ extern "C" int NCW_FN(ncw_nerf_fwd)(const NcwNerfNet* net, int prec, const NcwPo
     // weights-through-LDS kernel below, which serves fp32 and the other widths)
     if (net->rbn == 8 && net->rbh == 4 && prec == NCW_PREC_BF16 && net->n_head >= 1 && net->n_head <= 4)
         return NCW_FN(ncw_nerf_fwd8_launch)(net, *pts, x4, n, a, density, rgb, *stash, st);
-    NCW_NERF_DISPATCH(nerf_fwd_kernel, *net, *pts, x4, n, a, density, rgb, *stash);
+    if (stash->gp == nullptr) NCW_NERF_DISPATCH(nerf_render_kernel, *net, *pts, x4, n, a, density, rgb, *stash);  // forward-only render
+    else NCW_NERF_DISPATCH(nerf_fwd_kernel, *net, *pts, x4, n, a, density, rgb, *stash);
     return 0;
 }
 

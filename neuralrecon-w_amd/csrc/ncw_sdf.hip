@@ -119,10 +119,12 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_infer_kernel(NcwSdfNet 
 // ---------------------------------------------------------------------------------------------
 // forward + analytic input gradient + stash
 // ---------------------------------------------------------------------------------------------
-template <class P, int RB>
-__global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
-                                                                    float* __restrict__ sdf, float* __restrict__ grad,
-                                                                    NcwSdfStash st) {
+// TRAIN = false (sdf_render_kernel): the forward-only render -- the same arithmetic bit for bit; of the stash only h_l (the
+// adjoint sweep's scratch) and feat (the colour network's input) are written: no gamma (recomputed for the skip layer: the
+// same 16-bit / f32 image the stash would have returned), no t_l.
+template <class P, int RB, bool TRAIN>
+NCW_DEV void sdf_fwd_body(const NcwSdfNet& net, const NcwPoints& src, int64_t n, float* __restrict__ sdf, float* __restrict__ grad,
+                          const NcwSdfStash& st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
     typedef SdfShapes<P, RB> SH;
@@ -139,7 +141,8 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet ne
 
     auto reload_gamma = [&](Act<P, 2>& g) {  // gamma lives in the stash between layer 0 and the skip layer
         CVec<2> gm;
-        stash_load<2>(gm, (const SE*)st.gamma, tile, lane);
+        if (TRAIN) stash_load<2>(gm, (const SE*)st.gamma, tile, lane);
+        else freq_encode<2, 3, 6, Fast<P>::v>(gm, xs, lane);
         to_act(g, gm);
     };
     CVec<RB> acc;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet ne
     {
         CVec<2> gam;
         freq_encode<2, 3, 6, Fast<P>::v>(gam, xs, lane);
-        stash_store<2>((SE*)st.gamma, tile, gam, lane);
+        if (TRAIN) stash_store<2>((SE*)st.gamma, tile, gam, lane);
         Act<P, 2> gact;
         to_act(gact, gam);
         mma_stream<2, RB, 39, SH::SLOT>(acc, gact, ring, (const WE*)net.w[0], wn, nbts, lane);
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet ne
             load_sprime_block<P>(sv, (const SE*)st.h[l + 1], tile, RB, rb, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) sv[r] *= a.v[rb][r];
-            stash_store_block((SE*)st.t[l], tile, RB, rb, sv, lane);
+            if (TRAIN) stash_store_block((SE*)st.t[l], tile, RB, rb, sv, lane);
             to_act_block<RB>(ta, rb, sv);
         }
         const WE* wt = (const WE*)net.wt[l];
@@ -243,6 +246,19 @@ __global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet ne
     if (valid && lane < 32) {
         grad[p * 3 + 0] = nx; grad[p * 3 + 1] = ny; grad[p * 3 + 2] = nz;
     }
+}
+
+template <class P, int RB>
+__global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_fwd_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                    float* __restrict__ sdf, float* __restrict__ grad,
+                                                                    NcwSdfStash st) {
+    sdf_fwd_body<P, RB, true>(net, src, n, sdf, grad, st);
+}
+template <class P, int RB>
+__global__ __launch_bounds__(64 * NCW_WG_WAVES) void sdf_render_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                       float* __restrict__ sdf, float* __restrict__ grad,
+                                                                       NcwSdfStash st) {
+    sdf_fwd_body<P, RB, false>(net, src, n, sdf, grad, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -518,7 +534,8 @@ extern "C" int NCW_FN(ncw_sdf_fwd)(const NcwSdfNet* net, int prec, const NcwPoin
 #ifndef NCW_HALF_F16
     if (sdf16f_on(net, prec)) return ncw_sdf_fwd16f_launch(net, *pts, n, sdf, grad, *stash, st);
 #endif
-    NCW_SDF_DISPATCH(sdf_fwd_kernel, *net, *pts, n, sdf, grad, *stash);
+    if (stash->t[0] == nullptr) NCW_SDF_DISPATCH(sdf_render_kernel, *net, *pts, n, sdf, grad, *stash);  // forward-only render
+    else NCW_SDF_DISPATCH(sdf_fwd_kernel, *net, *pts, n, sdf, grad, *stash);
     return 0;
 }
 

@@ -213,7 +213,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_infer16_kernel(NcwSdfNet n
 // grad = J_gamma^T g_gamma.  On entry h_{L-1} of the T tiles is in abuf (BS = 1: plain fragments; BS = 2: the split chain's
 // [tile][unit][hi | lo] buffer, whose hi fragments are read) and r holds the first units of w_feat; abuf is then reused in the
 // plain layout.  SDF_ROW = false: the caller's (split-precision) chain has written sdf already.
-template <int T, int BS, bool SDF_ROW>
+// TRAIN = false: forward-only render -- t_l is not stashed (feat is: the colour network reads it).
+template <int T, int BS, bool SDF_ROW, bool TRAIN>
 NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n, float* __restrict__ sdf, float* __restrict__ grad,
                           const NcwSdfStash& st, s16_lfrag* abuf, s16_lfrag* gbuf, S16W& r, f32x16 (&acc)[2][T], int lane, int wave,
                           int64_t tile0) {
@@ -255,7 +256,7 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
                 const f32x16& aa = j ? a1 : a0;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) sv[q] *= aa[q];
-                stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
+                if (TRAIN) stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
                 s16_store_units(abuf, t, wave + 8 * j, sv, lane);
             }
     }
@@ -276,7 +277,7 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
                 f32x16 sv = s16_sprime((const SE*)st.h[l], (size_t)(tile0 + t), wave + 8 * j, lane);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) sv[q] *= acc[j][t][q];
-                stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
+                if (TRAIN) stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
                 s16_store_units(abuf, t, wave + 8 * j, sv, lane);
             }
     }
@@ -325,10 +326,11 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
 // The gamma output blocks (16, 17) of the transposed skip layer and the two blocks of W_0^T are 2 blocks x T tiles
 // jobs: wave w < 2 T takes block (w & 1) of tile (w >> 1) and keeps that g_gamma block to the end (2 T <= 8).
 // ------------------------------------------------------------------------------------------------
-template <int T>
-__global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
-                                                                  float* __restrict__ sdf, float* __restrict__ grad,
-                                                                  NcwSdfStash st) {
+// TRAIN = false (sdf_render16_kernel): forward-only render -- bit for bit the same outputs; of the stash only h_l (the adjoint
+// sweep's scratch) and feat are written.
+template <int T, bool TRAIN>
+NCW_DEV void sdf_fwd16_body(const NcwSdfNet& net, const NcwPoints& src, int64_t n, float* __restrict__ sdf, float* __restrict__ grad,
+                            const NcwSdfStash& st) {
     typedef ncw_h16 SE;
     static_assert(2 * T <= S16_WAVES, "one gamma job per wave");
     S16_LDS_DECL();
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net
         xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
         CVec<2> gam;
         freq_encode<2, 3, 6, true>(gam, xs, lane);
-        stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        if (TRAIN) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
         Act<PrecBF16, 2> ga;
         to_act(ga, gam);
 #pragma unroll
@@ -386,7 +388,20 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net
                 s16_store_units(abuf, t, wave + 8 * j, y, lane);
             }
     }
-    s16_fwd_tail<T, 1, true>(net, src, n, sdf, grad, st, abuf, gbuf, r, acc, lane, wave, tile0);
+    s16_fwd_tail<T, 1, true, TRAIN>(net, src, n, sdf, grad, st, abuf, gbuf, r, acc, lane, wave, tile0);
+}
+
+template <int T>
+__global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwd16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                  float* __restrict__ sdf, float* __restrict__ grad,
+                                                                  NcwSdfStash st) {
+    sdf_fwd16_body<T, true>(net, src, n, sdf, grad, st);
+}
+template <int T>
+__global__ __launch_bounds__(64 * S16_WAVES) void sdf_render16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                     float* __restrict__ sdf, float* __restrict__ grad,
+                                                                     NcwSdfStash st) {
+    sdf_fwd16_body<T, false>(net, src, n, sdf, grad, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -601,8 +616,9 @@ NCW_DEV void s16s_mma(f32x16 (&acc)[2][S16S_T], S16WS& r, const void* w, const v
 }
 
 // value chain: leaves h_{L-1} (hi | lo) of the 2 tiles in sbuf, the first units of w_feat are NOT prefetched (the caller's
-// plain ring does that).  STASH: gamma, h_1 .. h_{L-1} (fp16 roundings = the hi parts).
-template <bool STASH>
+// plain ring does that).  STASH 2: gamma, h_1 .. h_{L-1} (fp16 roundings = the hi parts); 1 (forward-only render): h_l only, the
+// adjoint sweep's scratch; 0 (sdf_infer): nothing.
+template <int STASH>
 NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t n, int64_t tile0, s16_lfrag* sbuf, s16_lfrag* gsbuf,
                               int lane, int wave, float* __restrict__ sdf, const NcwSdfStash& st) {
     typedef ncw_h16 SE;
@@ -616,7 +632,7 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
         xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
         CVec<2> gam;
         freq_encode<2, 3, 6, false>(gam, xs, lane);  // sinf / cosf: the hardware v_sin / v_cos are not fp32-accurate
-        if (STASH) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        if (STASH == 2) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             bf16x8 hi, lo;
@@ -634,7 +650,7 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
             for (int j = 0; j < 2; ++j) {
                 const f32x16 y = s16_softplus(acc[j][t]);
                 const int ob = wave + 8 * j;
-                if (STASH) stash_store_block_keep((SE*)st.h[l_out], (size_t)(tile0 + t), 16, ob, y, lane);
+                if (STASH >= 1) stash_store_block_keep((SE*)st.h[l_out], (size_t)(tile0 + t), 16, ob, y, lane);
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     bf16x8 hi, lo;
@@ -706,18 +722,19 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_inferS16_kernel(NcwSdfNet 
                                                                      float* __restrict__ sdf) {
     S16S_LDS_DECL();
     NcwSdfStash none = {};
-    s16s_value_chain<false>(net, src, n, tile0, sbuf, gsbuf, lane, wave, sdf, none);
+    s16s_value_chain<0>(net, src, n, tile0, sbuf, gsbuf, lane, wave, sdf, none);
 }
 
+template <bool TRAIN>  // false: forward-only render (no gamma / t_l stash)
 __global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwdS16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
                                                                    float* __restrict__ sdf, float* __restrict__ grad, NcwSdfStash st) {
     S16S_LDS_DECL();
-    s16s_value_chain<true>(net, src, n, tile0, sbuf, gsbuf, lane, wave, sdf, st);
+    s16s_value_chain<(TRAIN ? 2 : 1)>(net, src, n, tile0, sbuf, gsbuf, lane, wave, sdf, st);
     // the plain tail: feature rows from the hi fragments (BS = 2), adjoint sweep in the plain layout over the same LDS
     S16W r;
     f32x16 acc[2][S16S_T];
     s16_prefetch(r, net.w_feat, 16, wave, lane);
-    s16_fwd_tail<S16S_T, 2, false>(net, src, n, sdf, grad, st, sbuf, gsbuf, r, acc, lane, wave, tile0);
+    s16_fwd_tail<S16S_T, 2, false, TRAIN>(net, src, n, sdf, grad, st, sbuf, gsbuf, r, acc, lane, wave, tile0);
 }
 #endif  // NCW_HALF_F16
 
@@ -762,6 +779,7 @@ int NCW_FN(ncw_sdf_infer16_launch)(const NcwSdfNet* net, const NcwPoints& src, i
 
 int NCW_FN(ncw_sdf_fwd16_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
                                  const NcwSdfStash& stash, hipStream_t st) {
+    if (stash.t[0] == nullptr) S16_LAUNCH(sdf_render16_kernel, *net, src, n, sdf, grad, stash);  // forward-only render
     S16_LAUNCH(sdf_fwd16_kernel, *net, src, n, sdf, grad, stash);
 }
 
@@ -783,8 +801,12 @@ int ncw_sdf_inferS16_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int6
 int ncw_sdf_fwdS16_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
                               const NcwSdfStash& stash, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
-    hipLaunchKernelGGL(sdf_fwdS16_kernel, dim3((unsigned)((tiles + S16S_T - 1) / S16S_T)), dim3(64 * S16_WAVES), 0, st, *net, src, n,
-                       sdf, grad, stash);
+    if (stash.t[0] == nullptr)  // forward-only render
+        hipLaunchKernelGGL(sdf_fwdS16_kernel<false>, dim3((unsigned)((tiles + S16S_T - 1) / S16S_T)), dim3(64 * S16_WAVES), 0, st, *net,
+                           src, n, sdf, grad, stash);
+    else
+        hipLaunchKernelGGL(sdf_fwdS16_kernel<true>, dim3((unsigned)((tiles + S16S_T - 1) / S16S_T)), dim3(64 * S16_WAVES), 0, st, *net,
+                           src, n, sdf, grad, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }

@@ -133,7 +133,8 @@ NCW_DEV void f_store_gamma(f_lf* gbuf, int tw, const CVec<2>& g, int lane) {
 
 // forward chain shared by sdf_infer and sdf_fwd: gamma -> layers 0 .. L-2; leaves h_{L-1} in abuf and the first units of
 // `w_after` (the sdf row is read directly; w_feat for sdf_fwd) in the ring.  STASH: gamma, h_1 .. h_{L-1}.
-template <bool STASH>
+// STASH 2: gamma + h_l (training); 1: h_l only (forward-only render: the adjoint sweep's scratch); 0: nothing (sdf_infer)
+template <int STASH>
 NCW_DEV void f_forward_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t n, int64_t tile0, f_lf* abuf, f_lf* gbuf, FW& r,
                              f32x16 (&acc)[2][F_T], const void* w_after, int lane, int wave, const NcwSdfStash& st) {
     constexpr int T = F_T;
@@ -146,7 +147,7 @@ NCW_DEV void f_forward_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t
         xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
         CVec<2> gam;
         freq_encode<2, 3, 6, false>(gam, xs, lane);
-        if (STASH) stash_store<2>((float*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        if (STASH == 2) stash_store<2>((float*)st.gamma, (size_t)(tile0 + wave), gam, lane);
         f_store_gamma(gbuf, wave, gam, lane);
     }
     {   // layer 0: K = 39 (the F_GU gamma units)
@@ -159,7 +160,7 @@ NCW_DEV void f_forward_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x16 y = f_softplus(acc[j][t]);
-                if (STASH) stash_store_block_keep((float*)st.h[1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
+                if (STASH >= 1) stash_store_block_keep((float*)st.h[1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
                 f_store_units(abuf, t, wave + 8 * j, y, lane);
             }
     }
@@ -176,7 +177,7 @@ NCW_DEV void f_forward_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x16 y = f_softplus(acc[j][t]);
-                if (STASH) stash_store_block_keep((float*)st.h[l + 1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
+                if (STASH >= 1) stash_store_block_keep((float*)st.h[l + 1], (size_t)(tile0 + t), 16, wave + 8 * j, y, lane);
                 f_store_units(abuf, t, wave + 8 * j, y, lane);
             }
     }
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(64 * F_WAVES) void sdf_infer16f_kernel(NcwSdfNet ne
     FW r;
     f32x16 acc[2][T];
     NcwSdfStash none = {};
-    f_forward_chain<false>(net, src, n, tile0, abuf, gbuf, r, acc, net.w[1], lane, wave, none);  // (w_after unused: any valid matrix)
+    f_forward_chain<0>(net, src, n, tile0, abuf, gbuf, r, acc, net.w[1], lane, wave, none);  // (w_after unused: any valid matrix)
     ncw_lds_barrier();
     if (wave < T) {  // sdf row
         CVec<1> o;
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(64 * F_WAVES) void sdf_infer16f_kernel(NcwSdfNet ne
 // The gamma output blocks (16, 17) of the transposed skip layer and the two blocks of W_0^T are 2 blocks x T tiles jobs:
 // wave w < 2 T takes block (w & 1) of tile (w >> 1) and keeps that g_gamma block to the end.
 // ------------------------------------------------------------------------------------------------
+template <bool TRAIN>  // false: forward-only render -- the same outputs bit for bit; no gamma / t_l stash
 __global__ __launch_bounds__(64 * F_WAVES) void sdf_fwd16f_kernel(NcwSdfNet net, NcwPoints src, int64_t n, float* __restrict__ sdf,
                                                                  float* __restrict__ grad, NcwSdfStash st) {
     typedef float SE;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(64 * F_WAVES) void sdf_fwd16f_kernel(NcwSdfNet net,
     const bool gjob = wave < 2 * T;
     FW r;
     f32x16 acc[2][T];
-    f_forward_chain<true>(net, src, n, tile0, abuf, gbuf, r, acc, net.w_feat, lane, wave, st);
+    f_forward_chain<(TRAIN ? 2 : 1)>(net, src, n, tile0, abuf, gbuf, r, acc, net.w_feat, lane, wave, st);
     // ---- feature rows (r = first units of w_feat) and sdf row; then the adjoint's first vector ----------------------
     {
         const float wt1_0 = f_ld(net.wt[L - 1], 16, wave, 0, lane), wt1_1 = f_ld(net.wt[L - 1], 16, wave + 8, 0, lane);
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(64 * F_WAVES) void sdf_fwd16f_kernel(NcwSdfNet net,
                 const f32x16& aa = j ? a1 : a0;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) sv[q] *= aa[q];
-                stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
+                if (TRAIN) stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
                 f_store_units(abuf, t, wave + 8 * j, sv, lane);
             }
     }
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(64 * F_WAVES) void sdf_fwd16f_kernel(NcwSdfNet net,
                 f32x16 sv = f_sprime((const SE*)st.h[l], (size_t)(tile0 + t), wave + 8 * j, lane);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) sv[q] *= acc[j][t][q];
-                stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
+                if (TRAIN) stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
                 f_store_units(abuf, t, wave + 8 * j, sv, lane);
             }
     }
@@ -453,7 +455,10 @@ int ncw_sdf_infer16f_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t 
 }
 int ncw_sdf_fwd16f_launch(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
                           hipStream_t st) {
-    hipLaunchKernelGGL(sdf_fwd16f_kernel, F_GRID(n), dim3(64 * F_WAVES), 0, st, *net, src, n, sdf, grad, stash);
+    if (stash.t[0] == nullptr)  // forward-only render
+        hipLaunchKernelGGL(sdf_fwd16f_kernel<false>, F_GRID(n), dim3(64 * F_WAVES), 0, st, *net, src, n, sdf, grad, stash);
+    else
+        hipLaunchKernelGGL(sdf_fwd16f_kernel<true>, F_GRID(n), dim3(64 * F_WAVES), 0, st, *net, src, n, sdf, grad, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }

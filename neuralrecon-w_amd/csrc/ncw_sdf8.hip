@@ -51,6 +51,9 @@ NCW_DEV void sb_store_units(sb_lfrag* buf, int t, int ob, const f32x16& v, int l
     buf[(t * 16 + 2 * ob + 1) * 64 + lane] = o.f[1];
 }
 
+// TRAIN = false: forward-only render -- bit for bit the same outputs; of the stash only h_l (the adjoint sweep's scratch) and
+// feat (the colour network's input) are written, not gamma, not t_l (include/neuconw_hip.h, NcwSdfStash).
+template <bool TRAIN>
 __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
                                                                 float* __restrict__ sdf, float* __restrict__ grad,
                                                                 NcwSdfStash st) {
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
         xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
         CVec<2> gam;
         freq_encode<2, 3, 6, true>(gam, xs, lane);
-        stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        if (TRAIN) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
         Act<PrecBF16, 2> ga;
         to_act(ga, gam);
 #pragma unroll
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
             load_sprime_block_bf16(sv, (const SE*)st.h[L - 1], (size_t)(tile0 + t), 8, wave, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) sv[r] *= a0[r];
-            stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 8, wave, sv, lane);
+            if (TRAIN) stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 8, wave, sv, lane);
             sb_store_units(out, t, wave, sv, lane);
         }
 #pragma unroll
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sdf_fwdB_kernel(NcwSdfNet net, 
                 load_sprime_block_bf16(sv, (const SE*)st.h[l], (size_t)(tile0 + tp + j), 8, wave, lane);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sv[r] *= acc[r];
-                stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + tp + j), 8, wave, sv, lane);
+                if (TRAIN) stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + tp + j), 8, wave, sv, lane);
                 sb_store_units(out, tp + j, wave, sv, lane);
             }
         }
@@ -294,6 +297,8 @@ NCW_DEV void inverted_sphere8(const float (&x)[3], float (&p4)[4]) {  // rendere
     p4[0] = x[0] / r; p4[1] = x[1] / r; p4[2] = x[2] / r; p4[3] = 1.0f / r;
 }
 
+// TRAIN = false: forward-only render -- nothing is stashed (st.gp == NULL selects it; st.aux_bias stays an input).
+template <bool TRAIN>
 __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net, NcwPoints src, const float* __restrict__ x4,
                                                                  int64_t n, const float* __restrict__ a,
                                                                  float* __restrict__ density, float* __restrict__ rgb,
@@ -331,14 +336,16 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
         if (lane < 32) rbuf[wave * 32 + lane] = (int)ray;
         CVec<3> gp;
         freq_encode<3, 4, 10, true>(gp, p4, lane);
-        stash_store<3>((SE*)st.gp, (size_t)(tile0 + wave), gp, lane);
+        if (TRAIN) stash_store<3>((SE*)st.gp, (size_t)(tile0 + wave), gp, lane);
         Act<PrecBF16, 3> gpa;
         to_act(gpa, gp);
 #pragma unroll
         for (int q = 0; q < 6; ++q) xbuf[(wave * 6 + q) * 64 + lane] = gpa.f[q];
-        CVec<3> aux1;
-        build_aux1<true>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
-        stash_store<3>((SE*)st.aux1, (size_t)(tile0 + wave), aux1, lane);  // re-read for the head (same bf16 values)
+        if (TRAIN) {
+            CVec<3> aux1;
+            build_aux1<true>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
+            stash_store<3>((SE*)st.aux1, (size_t)(tile0 + wave), aux1, lane);  // re-read for the head (same bf16 values)
+        }
     }
     bf16x8 wa[16], wb[16], wx[6];
     auto bias_of = [&](const float* bp, int ob) {
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
 #pragma unroll
             for (int q = 0; q < 6; ++q) acc = NCW_MFMA_H(w0[q], xbuf[(t * 6 + q) * 64 + lane], acc, 0, 0, 0);
             const f32x16 y = relu16(acc);
-            stash_store_block((SE*)st.h[1], (size_t)(tile0 + t), 8, wave, y, lane);
+            if (TRAIN) stash_store_block((SE*)st.h[1], (size_t)(tile0 + t), 8, wave, y, lane);
             sb_store_units(abuf0, t, wave, y, lane);
         }
     }
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x16 y = relu16(j ? acc1 : acc0);
-                stash_store_block((SE*)st.h[i + 1], (size_t)(tile0 + tp + j), 8, wave, y, lane);
+                if (TRAIN) stash_store_block((SE*)st.h[i + 1], (size_t)(tile0 + tp + j), 8, wave, y, lane);
                 sb_store_units(out, tp + j, wave, y, lane);
             }
         }
@@ -415,9 +422,15 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
         const sb_lfrag* in = cur ? abuf1 : abuf0;
         sb_lfrag* out = cur ? abuf0 : abuf1;
         if (wave < SB_TILES) {
-            {
+            if (TRAIN || st.aux_bias == nullptr) {  // (with the per-ray fp32 head columns the AUX1 operand is not multiplied)
                 CVec<3> aux1;
-                stash_load<3>(aux1, (const SE*)st.aux1, (size_t)(tile0 + wave), lane);
+                if (TRAIN) {
+                    stash_load<3>(aux1, (const SE*)st.aux1, (size_t)(tile0 + wave), lane);
+                } else {  // nothing was stashed: rebuild it (the 16-bit image below is the one the stash would have held)
+                    const int64_t ray = rbuf[wave * 32 + (lane & 31)];
+                    const float dir[3] = {src.rays_d[ray * 3 + 0], src.rays_d[ray * 3 + 1], src.rays_d[ray * 3 + 2]};
+                    build_aux1<true>(aux1, dir, a + ray * net.n_a, net.n_a, lane);
+                }
                 Act<PrecBF16, 3> aux1a;
                 to_act(aux1a, aux1);
 #pragma unroll
@@ -439,8 +452,10 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
                 acc0 = NCW_MFMA_H(wa[q], in[(tp * 16 + q) * 64 + lane], acc0, 0, 0, 0);
                 acc1 = NCW_MFMA_H(wa[q], in[((tp + 1) * 16 + q) * 64 + lane], acc1, 0, 0, 0);
             }
-            stash_store_block((SE*)st.featn, (size_t)(tile0 + tp), 8, wave, acc0, lane);
-            stash_store_block((SE*)st.featn, (size_t)(tile0 + tp + 1), 8, wave, acc1, lane);
+            if (TRAIN) {
+                stash_store_block((SE*)st.featn, (size_t)(tile0 + tp), 8, wave, acc0, lane);
+                stash_store_block((SE*)st.featn, (size_t)(tile0 + tp + 1), 8, wave, acc1, lane);
+            }
             sb_store_units(out, tp, wave, acc0, lane);
             sb_store_units(out, tp + 1, wave, acc1, lane);
         }
@@ -482,8 +497,10 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_fwdB_kernel(NcwNerfNet net
             }
         }
         const f32x16 y0 = relu16(acc0), y1 = relu16(acc1);
-        stash_store_block((SE*)st.e[i], (size_t)(tile0 + ta), 4, hb, y0, lane);
-        stash_store_block((SE*)st.e[i], (size_t)(tile0 + tb), 4, hb, y1, lane);
+        if (TRAIN) {
+            stash_store_block((SE*)st.e[i], (size_t)(tile0 + ta), 4, hb, y0, lane);
+            stash_store_block((SE*)st.e[i], (size_t)(tile0 + tb), 4, hb, y1, lane);
+        }
         sb_store_units(out, ta, hb, y0, lane);
         sb_store_units(out, tb, hb, y1, lane);
 #pragma unroll
@@ -726,8 +743,12 @@ __global__ __launch_bounds__(64 * SB_WAVES) void nerf_bwdB_kernel(NcwNerfNet net
 int NCW_FN(ncw_sdf_fwd8_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad, const NcwSdfStash& stash,
                         hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
-    hipLaunchKernelGGL(sdf_fwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src,
-                       n, sdf, grad, stash);
+    if (stash.t[0] == nullptr)  // forward-only render
+        hipLaunchKernelGGL(sdf_fwdB_kernel<false>, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st,
+                           *net, src, n, sdf, grad, stash);
+    else
+        hipLaunchKernelGGL(sdf_fwdB_kernel<true>, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st,
+                           *net, src, n, sdf, grad, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }
@@ -735,8 +756,12 @@ int NCW_FN(ncw_sdf_fwd8_launch)(const NcwSdfNet* net, const NcwPoints& src, int6
 int NCW_FN(ncw_nerf_fwd8_launch)(const NcwNerfNet* net, const NcwPoints& src, const float* x4, int64_t n, const float* a, float* density,
                          float* rgb, const NcwNerfStash& stash, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
-    hipLaunchKernelGGL(nerf_fwdB_kernel, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st, *net, src,
-                       x4, n, a, density, rgb, stash);
+    if (stash.gp == nullptr)  // forward-only render
+        hipLaunchKernelGGL(nerf_fwdB_kernel<false>, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st,
+                           *net, src, x4, n, a, density, rgb, stash);
+    else
+        hipLaunchKernelGGL(nerf_fwdB_kernel<true>, dim3((unsigned)((tiles + SB_TILES - 1) / SB_TILES)), dim3(64 * SB_WAVES), 0, st,
+                           *net, src, x4, n, a, density, rgb, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }

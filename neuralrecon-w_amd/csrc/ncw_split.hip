@@ -92,10 +92,11 @@ NCW_DEV void ss_load_sprime(f32x16& sv, const ncw_h16* __restrict__ st_h, size_t
 
 // ------------------------------------------------------------------------------------------------
 // The value chain: gamma (exact sin / cos) -> layers 0 .. L-2 (Softplus, f32 epilogue, hi + lo split) -> sdf row.
-// Leaves h_{L-1} (hi | lo) of the 128 points in abuf.  STASH: also writes the activation stash of ncw_sdf_fwd
-// (gamma, h_1 .. h_{L-1}: the fp16 roundings, i.e. the hi parts -- what the plain kernel stashes).
+// Leaves h_{L-1} (hi | lo) of the 128 points in abuf.  STASH 2: also writes the activation stash of ncw_sdf_fwd
+// (gamma, h_1 .. h_{L-1}: the fp16 roundings, i.e. the hi parts -- what the plain kernel stashes); STASH 1 (forward-only
+// render): h_l only, the scratch the adjoint sweep of the same kernel re-reads; STASH 0 (sdf_infer): nothing.
 // ------------------------------------------------------------------------------------------------
-template <bool STASH>
+template <int STASH>
 NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t n, int64_t tile0, ss_lfrag* abuf, ss_lfrag* gbuf,
                             int lane, int wave, float* __restrict__ sdf, const NcwSdfStash& st) {
     typedef ncw_h16 SE;
@@ -108,7 +109,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
         CVec<2> gam;
         freq_encode<2, 3, 6, false>(gam, xs, lane);  // sinf / cosf: the hardware v_sin / v_cos are not fp32-accurate
-        if (STASH) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        if (STASH == 2) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             bf16x8 hi, lo;
@@ -129,7 +130,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
             f32x16 yv;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[t][r], y, s); yv[r] = y; }
-            if (STASH) stash_store_block_keep((SE*)st.h[l_out], (size_t)(tile0 + t), 8, wave, yv, lane);
+            if (STASH >= 1) stash_store_block_keep((SE*)st.h[l_out], (size_t)(tile0 + t), 8, wave, yv, lane);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 bf16x8 hi, lo;
@@ -308,7 +309,7 @@ NCW_DEV void s2_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
         CVec<2> gam;
         freq_encode<2, 3, 6, false>(gam, xs, lane);  // sinf / cosf: the hardware v_sin / v_cos are not fp32-accurate
-        if (STASH) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        if (STASH == 2) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             bf16x8 hi, lo;
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_inferS_kernel(NcwSdfNet net
     const int lane = ncw_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     NcwSdfStash none = {};
-    ss_value_chain<false>(net, src, n, (int64_t)blockIdx.x * SS_TILES, abuf, gbuf, lane, wave, sdf, none);
+    ss_value_chain<0>(net, src, n, (int64_t)blockIdx.x * SS_TILES, abuf, gbuf, lane, wave, sdf, none);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -449,6 +450,10 @@ NCW_DEV void sb_store_units(sb_lfrag* buf, int t, int ob, const f32x16& v, int l
     buf[(t * 16 + 2 * ob + 1) * 64 + lane] = o.f[1];
 }
 
+// TRAIN = false: the forward-only render (validation / novel views / vertex colours, rendering/renderer.py:785-916 under
+// no_grad): the same arithmetic bit for bit, but of the stash only h_l (re-read by the adjoint sweep below) and feat (the
+// colour network's input) are written -- not gamma, not t_l.
+template <bool TRAIN>
 __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
                                                                 float* __restrict__ sdf, float* __restrict__ grad,
                                                                 NcwSdfStash st) {
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, 
     const int L = net.n_layers;
     const int64_t tile0 = (int64_t)blockIdx.x * SS_TILES;
     const int jb = wave & 1, jt = wave >> 1;  // this wave's gamma job of the adjoint sweep: block jb of tile jt
-    ss_value_chain<true>(net, src, n, tile0, sbuf, gbuf, lane, wave, sdf, st);
+    ss_value_chain<(TRAIN ? 2 : 1)>(net, src, n, tile0, sbuf, gbuf, lane, wave, sdf, st);
     // ---- feature rows (plain fp16: the colour network reads them from the fp16 stash): W_feat . h_hi ----------------
     bf16x8 wa[16], wb[16];
     {
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, 
             ss_load_sprime(sv, (const SE*)st.h[L - 1], (size_t)(tile0 + t), 8, wave, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) sv[r] *= a0[r];
-            stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 8, wave, sv, lane);
+            if (TRAIN) stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 8, wave, sv, lane);
             sb_store_units(out, t, wave, sv, lane);
         }
 #pragma unroll
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, 
                 ss_load_sprime(sv, (const SE*)st.h[l], (size_t)(tile0 + tp + j), 8, wave, lane);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sv[r] *= acc[r];
-                stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + tp + j), 8, wave, sv, lane);
+                if (TRAIN) stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + tp + j), 8, wave, sv, lane);
                 sb_store_units(out, tp + j, wave, sv, lane);
             }
         }
@@ -611,7 +616,10 @@ int ncw_sdf_fwdS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t 
                             const NcwSdfStash& stash, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
     const dim3 grid((unsigned)((tiles + SS_TILES - 1) / SS_TILES));
-    hipLaunchKernelGGL(sdf_fwdS_kernel, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
+    if (stash.t[0] == nullptr)  // forward-only render (include/neuconw_hip.h, NcwSdfStash)
+        hipLaunchKernelGGL(sdf_fwdS_kernel<false>, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
+    else
+        hipLaunchKernelGGL(sdf_fwdS_kernel<true>, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
     NCW_CHECK_LAUNCH();
     return 0;
 }

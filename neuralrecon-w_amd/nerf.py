@@ -100,8 +100,10 @@ class NeRF(_PackedNet):
         other widths / the reproducible d_a_rows path)."""
         return True
 
-    def fwd_stash(self, pts, n, prec, a, x4=None, select=None):
-        """select = (z, O): pts are the R x (S + O) mode-2 samples of z_feed, z [R, S] the primary samples; evaluate only the
+    def fwd_stash(self, pts, n, prec, a, x4=None, select=None, train=True):
+        """train=False: the forward-only render -- nothing is stashed (NcwNerfStash.gp == NULL selects the render kernels); the same
+        density / rgb bit for bit.
+        select = (z, O): pts are the R x (S + O) mode-2 samples of z_feed, z [R, S] the primary samples; evaluate only the
         columns the compositor can use -- i < S where primary sample i is outside the unit sphere, and the O outside
         samples (ncw_bg_select).  density / rgb stay
         dense [n] (zero where skipped: the compositor selects, never multiplies, there); the stashes are compact and the
@@ -109,6 +111,9 @@ class NeRF(_PackedNet):
         dev = self._first_param().device
         plan = self.packed(prec)
         RBN, RBH = self.W // 32, self.W // 64
+
+        def build_render():
+            return dict(arena=StashArena(dev, prec, n).allocate(), ids={}, stash=L.NcwNerfStash())
 
         def build():
             ar = StashArena(dev, prec, n)
@@ -129,7 +134,8 @@ class NeRF(_PackedNet):
                     getattr(st, k)[i] = ar.ptr(v)
             return dict(arena=ar, ids=ids, stash=st)
 
-        ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev)), build)
+        ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev), bool(train)),
+                                                                             build if train else build_render)
         ar, ids, st = ent["arena"], ent["ids"], ent["stash"]
         sel_count = None
         if select is not None:
@@ -224,6 +230,6 @@ class NeRF(_PackedNet):
         prec = default_prec() if prec is None else prec
         n = input_pts.shape[0]
         pts = points_struct(x=input_pts[:, :3].contiguous(), rays_d=input_views.contiguous().float())
-        density, rgb, c = self.fwd_stash(pts, n, prec, embedding_a, x4=input_pts)
+        density, rgb, c = self.fwd_stash(pts, n, prec, embedding_a, x4=input_pts, train=False)
         StashCache.release(c["lease"])
         return density.reshape(n, 1), rgb

@@ -272,11 +272,26 @@ class SDFNetwork(nn.Module):
         return out.reshape(-1, 1)
 
     # ---- training path: forward with input gradient, backward, weight gradients ---------------------
-    def fwd_stash(self, pts, n, prec):
-        """ncw_sdf_fwd: returns (sdf [n], grad [n,3], ctx).  ctx carries the activation stash."""
+    def fwd_stash(self, pts, n, prec, train=True):
+        """ncw_sdf_fwd: returns (sdf [n], grad [n,3], ctx).  ctx carries the activation stash.
+        train=False: the forward-only render (validation / novel views / vertex colours: rendering/renderer.py:785-916 under
+        no_grad, :951-961): the same outputs bit for bit, but the arena holds only what the launch itself re-reads -- h_l, the
+        scratch of the analytic adjoint sweep -- and `feat`, the colour network's input: (L - 1 + 1) x W x 2 B per point instead
+        of the training stash's 21 KB (NcwSdfStash.t[0] == NULL selects the kernels that store nothing else)."""
         dev = self.lin0.bias.device
         plan = self.packed(prec)
         RB, Lm = self.d_hidden // 32, self.n_lin
+
+        def build_render():
+            ar = StashArena(dev, prec, n)
+            ids = dict(feat=ar.new(RB))
+            ids["h"] = {l: ar.new(RB) for l in range(1, Lm)}
+            ar.allocate()
+            st = L.NcwSdfStash()
+            st.feat = ar.ptr(ids["feat"])
+            for l, i in ids["h"].items():
+                st.h[l] = ar.ptr(i)
+            return dict(arena=ar, ids=ids, stash=st)
 
         def build():
             ar = StashArena(dev, prec, n)
@@ -295,7 +310,8 @@ class SDFNetwork(nn.Module):
                     getattr(st, k)[l] = ar.ptr(i)
             return dict(arena=ar, ids=ids, stash=st)
 
-        ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev)), build)
+        ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev), bool(train)),
+                                                                             build if train else build_render)
         ar, ids, st = ent["arena"], ent["ids"], ent["stash"]
         sdf = torch.empty(n, device=dev, dtype=torch.float32)
         grad = torch.empty(n, 3, device=dev, dtype=torch.float32)
@@ -457,10 +473,15 @@ class RenderingNetwork(_PackedNet):
         plan.net, plan.slots = net, sl
         return plan
 
-    def fwd_stash(self, pts, n, prec, normals, a, feat_ptr):
+    def fwd_stash(self, pts, n, prec, normals, a, feat_ptr, train=True):
+        """train=False: the forward-only render -- NOTHING is stashed (NcwColorStash.aux1 == NULL selects color_render_kernel);
+        the same rgb bit for bit."""
         dev = self._first_param().device
         plan = self.packed(prec)
         RBF, RBH, RBC = self.d_feature // 32, self.head_channels // 32, self.d_hidden // 32
+
+        def build_render():
+            return dict(arena=StashArena(dev, prec, n).allocate(), ids={}, stash=L.NcwColorStash())
 
         def build():
             ar = StashArena(dev, prec, n)
@@ -478,7 +499,8 @@ class RenderingNetwork(_PackedNet):
                     getattr(st, k)[i] = ar.ptr(v)
             return dict(arena=ar, ids=ids, stash=st)
 
-        ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev)), build)
+        ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev), bool(train)),
+                                                                             build if train else build_render)
         ar, ids, st = ent["arena"], ent["ids"], ent["stash"]
         rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
         normals = normals.contiguous().float()
@@ -579,7 +601,7 @@ class NeuconW(nn.Module):
     def gradient(self, x, prec=None):
         prec = default_infer_prec() if prec is None else prec
         xf = x.reshape(-1, 3).float().contiguous()
-        _, grad, c = self.sdf_net.fwd_stash(points_struct(x=xf), xf.shape[0], prec)
+        _, grad, c = self.sdf_net.fwd_stash(points_struct(x=xf), xf.shape[0], prec, train=False)
         StashCache.release(c["lease"])
         return grad
 
@@ -594,8 +616,8 @@ class NeuconW(nn.Module):
         dirs = x[..., 3:6].reshape(n, 3).float().contiguous()
         a = x[..., 6:].reshape(n, -1).float().contiguous()
         pts = points_struct(x=xyz, rays_d=dirs)
-        sdf, grad, sctx = self.sdf_net.fwd_stash(pts, n, prec)
-        rgb, cctx = self.color_net.fwd_stash(pts, n, prec, grad, a, sctx["arena"].ptr(sctx["ids"]["feat"]))
+        sdf, grad, sctx = self.sdf_net.fwd_stash(pts, n, prec, train=False)
+        rgb, cctx = self.color_net.fwd_stash(pts, n, prec, grad, a, sctx["arena"].ptr(sctx["ids"]["feat"]), train=False)
         StashCache.release(sctx["lease"])
         StashCache.release(cctx["lease"])
         inv_s = self.deviation_network.inv_s().reshape(1, 1)

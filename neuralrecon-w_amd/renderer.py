@@ -28,8 +28,12 @@ class _RenderFn(torch.autograd.Function):
     """render_core_outside + render_core (renderer.py:157-228, 570-783) as one autograd node."""
 
     @staticmethod
-    def forward(ctx, rdr, rays_o, rays_d, z, z_out, sample_dist, cos_anneal, background_rgb, a_embedded, variance,
+    def forward(ctx, rdr, train, rays_o, rays_d, z, z_out, sample_dist, cos_anneal, background_rgb, a_embedded, variance,
                 *params):
+        # train: somebody may come back for a backward (grad mode on and a differentiable input: decided by render(), since
+        # inside forward() grad mode is always off and needs_input_grad ignores it).  False = the forward-only render of the
+        # reference's validation / novel-view path (lightning_modules/neuconw_system.py:404-458 under no_grad): the MLP
+        # launches stash nothing but the SDF network's h_l scratch + feat (5 KB instead of 36 KB per sample).
         prec = rdr.prec
         neuconw, nerf = rdr.neuconw, rdr.nerf
         R, S = z.shape
@@ -63,19 +67,19 @@ class _RenderFn(torch.autograd.Function):
                 main = torch.cuda.current_stream(dev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select)
+                    density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select, train=train)
                 # allocated under the side stream, consumed by the compositor on the main stream after the join below: tell
                 # the caching allocator, so that freeing them can never hand the memory out while the main stream still reads it
                 density.record_stream(main)
                 bg_rgb.record_stream(main)
             else:
-                density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select)
+                density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select, train=train)
             density, bg_rgb = density.view(R, M), bg_rgb.view(R, M, 3)
         try:
             pts_in = points_struct(rays_o=rays_o, rays_d=rays_d, z=z, sample_dist=sample_dist, mode=2)
-            sdf, grad, sctx = neuconw.sdf_net.fwd_stash(pts_in, R * S, prec)
+            sdf, grad, sctx = neuconw.sdf_net.fwd_stash(pts_in, R * S, prec, train=train)
             feat_ptr = sctx["arena"].ptr(sctx["ids"]["feat"])
-            rgb, cctx = neuconw.color_net.fwd_stash(pts_in, R * S, prec, grad, a_det, feat_ptr)
+            rgb, cctx = neuconw.color_net.fwd_stash(pts_in, R * S, prec, grad, a_det, feat_ptr, train=train)
         finally:  # the main stream ALWAYS rejoins the side stream (also when the SDF / colour chain raised)
             if use_bg and rdr.use_bg_stream:
                 torch.cuda.current_stream(dev).wait_stream(rdr._bg_stream(dev))  # join before the compositor
@@ -94,7 +98,8 @@ class _RenderFn(torch.autograd.Function):
         ctx.mark_non_differentiable(*extras)
         # the leases live exactly as long as this autograd node: returned by backward(), or when the node is dropped
         ctx.guard = LeaseGuard([c["lease"] for c in (sctx, cctx, nctx) if c is not None])
-        if not any(ctx.needs_input_grad):  # inference: nobody will come back for the stashes
+        ctx.train = train
+        if not train:  # forward-only render: nothing was stashed, nobody comes back
             ctx.guard.release()
         return (o["color"], o["weights_sum"], o["depth"], o["eik"][0]) + extras
 
@@ -104,6 +109,9 @@ class _RenderFn(torch.autograd.Function):
         neuconw, nerf = rdr.neuconw, rdr.nerf
         prec = rdr.prec
         dev = ctx.inv_s.device
+        if not ctx.train:
+            raise RuntimeError("NeuconWRenderer: backward through a forward-only render (it ran under torch.no_grad(), or no "
+                               "input required a gradient): nothing was stashed")
         ctx.guard.consume()
         # fp16 mode: the per-point adjoints are rounded to fp16 inside the MLP backward kernels (MFMA operands, delta
         # stashes), whose normal range ends at 6e-5 -- the loss's 1/(3R) alone puts them below it.  The compositor
@@ -212,7 +220,7 @@ class _RenderFn(torch.autograd.Function):
             d_a.mul_(sc_inv)
             d_var = d_var * sc_inv
         ctx.guard.release()
-        return (None, None, None, None, None, None, None, None, d_a, d_var) + tuple(out)
+        return (None, None, None, None, None, None, None, None, None, d_a, d_var) + tuple(out)
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -529,9 +537,12 @@ class NeuconWRenderer:
                 raise ValueError("background_rgb must hold ONE colour (3 values; every reference call site passes "
                                  "torch.ones/zeros([1, 3])): got shape %s" % (tuple(background_rgb.shape),))
             bgc = background_rgb.reshape(3)
-        outs = _RenderFn.apply(self, rays_o, rays_d, z_vals, z_vals_outside, sample_dist,
+        params = self._params()
+        variance = self.neuconw.deviation_network.variance
+        train = torch.is_grad_enabled() and (a_embedded.requires_grad or variance.requires_grad or any(p.requires_grad for p in params))
+        outs = _RenderFn.apply(self, bool(train), rays_o, rays_d, z_vals, z_vals_outside, sample_dist,
                                cos_anneal_ratio if torch.is_tensor(cos_anneal_ratio) else float(cos_anneal_ratio), bgc,
-                               a_embedded, self.neuconw.deviation_network.variance, *self._params())
+                               a_embedded, variance, *params)
         (color, wsum, depth, eik_num, color_sphere, color_bg, weights, cdf, inside, normals, sdf, gradients, mid_z,
          dists, eik_den, inv_s, s_val, weights_max) = outs
         weights_sum = wsum.unsqueeze(-1)

@@ -388,8 +388,8 @@ def resume_state(optimizer, renderer=None, epoch=0, step_in_epoch=0, generator_s
           "cuda_rng_state": torch.cuda.get_rng_state(optimizer.fp.flat_grad.device).clone()
           if hasattr(optimizer, "fp") and optimizer.fp.flat_grad.is_cuda else None,
           "cpu_rng_state": torch.get_rng_state().clone()}
-    if hasattr(optimizer, "state"):  # FlatAdam: device-resident NcwAdamState {step, good, skipped, ...}
-        s_ = optimizer.state.detach().cpu()
+    if torch.is_tensor(getattr(optimizer, "state", None)):  # FlatAdam: device-resident NcwAdamState {step, good, skipped, ...}
+        s_ = optimizer.state.detach().cpu()   # (torch.optim.Adam also has `.state`: a dict -- nothing to record for it)
         st.update(adam_good=int(s_[1]), adam_skipped=int(s_[2]))
     ls = getattr(renderer, "loss_scale", None)
     if ls is not None:
@@ -399,7 +399,7 @@ def resume_state(optimizer, renderer=None, epoch=0, step_in_epoch=0, generator_s
 
 def apply_resume_state(st, optimizer, renderer=None):
     """Restores the optimiser-side entries of `resume_state`; returns (epoch, step_in_epoch, generator_state)."""
-    if hasattr(optimizer, "state") and "adam_good" in st:
+    if torch.is_tensor(getattr(optimizer, "state", None)) and "adam_good" in st:
         optimizer.state[1] = int(st["adam_good"])
         optimizer.state[2] = int(st["adam_skipped"])
     ls = getattr(renderer, "loss_scale", None)

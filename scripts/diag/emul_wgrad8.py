@@ -26,6 +26,7 @@ ap.add_argument("--R", type=int, default=16)
 ap.add_argument("--W", type=int, default=256)
 ap.add_argument("--variance", type=float, default=0.3)
 ap.add_argument("--vjit", type=float, default=0.05)
+ap.add_argument("--short", action="store_true", help="only the modes of the R-scaling study (NOTEBOOK R5.1)")
 args = ap.parse_args()
 
 CFG = dict(n_outside=4, up_sample_steps=2, s_val_base=3, render_bg=True, trim_sphere=True, mesh_mask_list=["sky"],
@@ -175,6 +176,8 @@ for k, g in ref.items():
 print("R %d  %d+%d  variance %.1f; largest gradient per network:" % (args.R, args.ns, args.ni, args.variance), gmax)
 variants = [("exact", "exact"), ("f16", "f16"), ("f16", "bf16"), ("f16", "e4m3:32:32"), ("f16", "e5m2:32:32"), ("e4m3:32:32", "e4m3:32:32"),
             ("f16", "i8:32:1"), ("f16", "i8:32:32"), ("f16", "i8:1:32"), ("f16", "i8:1:256"), ("f16", "i8:4:4"), ("i8:1:32", "i8:1:32")]
+if args.short:
+    variants = [("f16", "f16"), ("bf16", "bf16"), ("f16", "e4m3:32:32"), ("e4m3:32:32", "e4m3:32:32"), ("e5m2:32:32", "e5m2:32:32"), ("i8:1:32", "i8:1:32")]
 for mx, my in variants:
     MODE["x"], MODE["y"] = mx, my
     g = grads(sd0, rays, ts, label, rgbs, True)

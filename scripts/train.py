@@ -122,6 +122,9 @@ def main():
         cur = C.lr_at_epoch(cfg, lr, epoch_, args.num_epochs)
         return {"last_epoch": int(epoch_), "_step_count": int(epoch_) + 1, "_last_lr": [cur], "base_lrs": [lr], "kind": sched_kind}
 
+    # bound before the loop: a checkpoint whose epoch is already >= --num_epochs (or a loop whose body never runs) still
+    # writes last.ckpt below
+    epoch, in_epoch, gen_state0 = first_epoch, skip, gen.get_state()
     for epoch in range(first_epoch, args.num_epochs):
         if hasattr(step_fn.opt, "lr"):  # utils/__init__.py:45-61: the scheduler steps once per epoch
             step_fn.opt.lr = C.lr_at_epoch(cfg, lr, epoch, args.num_epochs)

@@ -28,7 +28,8 @@ def perturb_weights(neuconw, g_jit=0.1, v_jit=0.0, seed=11):
                 p.add_((v_jit * float(p.abs().mean()) * torch.randn(p.shape, generator=gen)).to(p.device))
 
 
-FLIP_ROW_TOL = 0.15
+FLIP_ROW_TOL = 0.15      # fp16: measured 8.3e-2 (GPU and CPU emulation agree to three digits), see embedding_grad_err
+FLIP_ROW_TOL_BF16 = 0.6  # bf16: 8x the rounding step of fp16, several flips per row; bounded, not skipped (measured: see test log)
 # Weight-gradient tensors of the ReLU networks (colour network, background NeRF) in the 16-bit modes of a 16-ray composed step: a
 # pre-activation within ~1e-4 of zero flips its mask under SOME combinations of fp16 roundings and not under others, and one
 # flipped background sample moves a bias / weight gradient by up to ~1e-2 of the network's largest gradient.  Measured on the CPU
@@ -47,15 +48,19 @@ def is_relu_tensor(k):
     return k.startswith("nerf.") or k.startswith("neuconw.color_net.") or k.startswith("embedding_a.")
 
 
-def embedding_grad_err(got, ref, scale):
+def embedding_grad_err(got, ref, scale, exact=False):
     """Error of the appearance-embedding gradient [n_vocab, n_a], per ROW, relative to `scale` (its largest entry):
-    -> (worst row with ONE row set aside, that row's error).  A row is the sum over ONE ray's samples of ReLU-masked terms; at
+    -> (worst row with ONE row set aside, that row's error).  exact=True (the fp32 parity mode: no 16-bit rounding, hence no
+    flipped mask to excuse) scores the WHOLE tensor: -> (worst row, 0.0) -- a d_a indexing / scatter bug on a single ray must
+    not hide behind the set-aside row.  A row is the sum over ONE ray's samples of ReLU-masked terms; at
     16 rays a single pre-activation of the background NeRF within 1e-4 of zero carries ~10 % of a row, and which side of zero
     it lands on depends on the combination of roundings: rounding the NeRF's weights to fp16 ALONE moves this gradient by
     8.3e-2, all of round 3's roundings together by 1.7e-3 (scripts/diag/emul_embgrad.py, CPU; the GPU reproduces the emulated
     8.34e-2 to three digits).  One flipped row (bounded by FLIP_ROW_TOL) is therefore scored apart from the rest, which must
     meet the tensor tolerance like every other parameter."""
     rows = (got.double() - ref.double()).abs().amax(dim=1) / scale
+    if exact:
+        return float(rows.max()), 0.0
     r = int(rows.argmax())
     rest = float(torch.cat([rows[:r], rows[r + 1:]]).max()) if rows.numel() > 1 else 0.0
     return rest, float(rows[r])
@@ -90,7 +95,7 @@ def trained_weights(W, ns, ni, seed, v_jit, steps, lr=1e-3, R=128):
 
 
 def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=True, cos_anneal=0.3, sdf_split=None,
-             train_steps=0):
+             train_steps=0, forward_extras=True):
     """-> dict(errs={color, depth, weights_sum, gradient_error}, loss, loss_ref, grad_worst, inv_s).
     Gradient errors are scaled by the largest gradient of their network (the fp32 reference's own gradients of ~1e-7
     tensors carry ~1e-1 relative noise: tests/test_gpu_fullsize.py)."""
@@ -103,6 +108,12 @@ def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=Tru
         sd_t = trained_weights(W, ns, ni, seed, v_jit, train_steps)
         from tests._build import load_golden_weights
         load_golden_weights({k: v.cuda() for k, v in sd_t.items()}, emb, neuconw, nerf)
+    if not forward_extras:
+        # the round-3 program: no per-ray fp32 head columns, no hi + lo colour weights -- the forward then computes exactly the
+        # function the (single-rounded fp16) backward differentiates.  Set before the first forward: the plan is built once.
+        neuconw.color_net.ray_bias = False
+        neuconw.color_net.weight_split = False
+        nerf.ray_bias = False
     if sdf_split is not None:  # None = the product default (split-precision SDF value path in the fp16 mode at W = 256)
         neuconw.sdf_net.sdf_split = bool(sdf_split)
     with torch.no_grad():
@@ -148,8 +159,8 @@ def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=Tru
             if g is None:
                 continue
             if k == "embedding_a.weight":
-                e, res["embedding_flip_row"] = embedding_grad_err(params[k].grad.cpu(), g, scale[net_of(k)])
-                assert prec == 1 or res["embedding_flip_row"] < FLIP_ROW_TOL, res["embedding_flip_row"]  # (bf16: own tolerances)
+                e, res["embedding_flip_row"] = embedding_grad_err(params[k].grad.cpu(), g, scale[net_of(k)], exact=(prec == 0))
+                assert res["embedding_flip_row"] < (FLIP_ROW_TOL_BF16 if prec == 1 else FLIP_ROW_TOL), res["embedding_flip_row"]
             else:
                 e = float((params[k].grad.cpu().double() - g.double()).abs().max()) / scale[net_of(k)]
             res["grad_errs"][k] = e

@@ -92,10 +92,12 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
         if g is None:
             continue
         if k == "embedding_a.weight":  # per row, one ReLU-flipped row set aside (tests/_parity.embedding_grad_err)
-            from tests._parity import FLIP_ROW_TOL, embedding_grad_err
+            from tests._parity import FLIP_ROW_TOL, FLIP_ROW_TOL_BF16, embedding_grad_err
 
-            e, flip = embedding_grad_err(params[k].grad.cpu(), g, scale[net_of(k)])
-            assert flip < FLIP_ROW_TOL, (k, flip)
+            # fp32: the whole tensor is scored (nothing set aside); bf16 has its own explicit bound
+            e, flip = embedding_grad_err(params[k].grad.cpu(), g, scale[net_of(k)], exact=(prec_name == "f32"))
+            print("embedding_a.weight (%s): rest %.2e, set-aside row %.2e" % (prec_name, e, flip))
+            assert flip < (FLIP_ROW_TOL_BF16 if prec_name == "bf16" else FLIP_ROW_TOL), (k, flip)
         else:
             e = float((params[k].grad.cpu().double() - g.double()).abs().max()) / scale[net_of(k)]
         worst = max(worst, e)
@@ -183,6 +185,27 @@ def test_train_step_vs_oracle_after_training(prec_name):
         assert e < (tol_eik if k == "gradient_error" else tol_out), (k, e)
     assert g_rest < tol_grad, g_rest
     assert g_var < tol_var, g_var
+
+
+@pytest.mark.parametrize("train_steps,variance", [(0, 0.3), (40, 0.6)])
+def test_fp16_backward_consistent_with_forward_keeps_round3_bounds(train_steps, variance):
+    """Round 4 made the fp16 FORWARD more accurate than the function its backward differentiates (per-ray fp32 head columns,
+    colour weights as hi + lo pairs: tests/_parity.RELU_FLIP_TOL, the 0.12 bound of d(loss)/d(variance)).  With those two
+    forward-only refinements switched off the backward is the exact derivative of the rounded forward again, and every
+    tensor must meet the bounds the tests had BEFORE they were widened: ReLU-network tensors under the tensor tolerance
+    itself (no RELU_FLIP_TOL), d(variance) under 2e-2."""
+    import neuralrecon_w_amd as nw
+    from tests._parity import run_case
+
+    r = run_case(256, 64, 64, nw.PREC_F16, 16, variance=variance, train_steps=train_steps, forward_extras=False)
+    VAR = "neuconw.deviation_network.variance"
+    tol_grad = 3e-3 if train_steps == 0 else 1.1e-2  # F16_TOL[(64, 64)] / round 3's measured 1.0e-2 on trained weights
+    g_var = r["grad_errs"].get(VAR, 0.0)
+    print("fp16, forward extras off, %d steps, variance %.1f:" % (train_steps, variance), {k: "%.2e" % v for k, v in r["errs"].items()},
+          "grads %.2e, ReLU-network tensors %.2e, d variance %.2e, set-aside row %.2e" % (r["grad_worst"], r["grad_worst_relu"], g_var,
+                                                                                          r.get("embedding_flip_row", 0.0)))
+    assert r["grad_worst"] < tol_grad and r["grad_worst_relu"] < tol_grad, r["grad_errs"]
+    assert g_var < 2e-2, g_var
 
 
 def test_plain_fp16_value_path():

@@ -45,7 +45,12 @@ def test_ray_voxel_near_far_vs_bruteforce(level):
     assert bool((far >= near).all())
 
 
-def test_render_with_fine_octree_window_and_boundary_samples():
+# (W, precision, rays, tol per-ray outputs, tol per-sample tensors).  f32: the W = 64 networks of round 1; f16: the HEADLINE
+# networks (W = 256: the split-precision SDF value path exists there) in the timed dtype, at the fp16 output tolerance of
+# tests/test_gpu_fullsize.py (F16_TOL[(16, 16)][0] = 1.2e-4) -- config 3 in the precision `bench.py --config voxel` times.
+@pytest.mark.parametrize("W,prec_name,R,tol_out,tol_sample", [(64, "f32", 96, 2e-4, 2e-3), (256, "f32", 48, 2e-4, 2e-3),
+                                                              (256, "f16", 48, 1.2e-4, 2e-3)])
+def test_render_with_fine_octree_window_and_boundary_samples(W, prec_name, R, tol_out, tol_sample):
     """sampler narrowed to surface +- SAMPLE_RANGE voxels, 10 boundary samples (renderer.py:415-456, 549-566)."""
     import neuralrecon_w_amd as nw
     from neuralrecon_w_amd import voxel
@@ -53,26 +58,33 @@ def test_render_with_fine_octree_window_and_boundary_samples():
 
     level = 6
     occ = _shell(level, 0.5, 0.05)
-    emb, neuconw, nerf, rdr = build_system(prec=nw.PREC_F32, n_samples=16, n_importance=16, boundary_samples=10,
-                                           sample_range=4, seed=11)
+    prec = {"f32": nw.PREC_F32, "f16": nw.PREC_F16}[prec_name]
+    big = dict(n_a=48, n_vocab=100, nerf_w=256, color_hidden=256, head=128) if W == 256 else {}
+    emb, neuconw, nerf, rdr = build_system(W=W, prec=prec, n_samples=16, n_importance=16, boundary_samples=10,
+                                           sample_range=4, seed=11, **big)
     with torch.no_grad():
         for n, p in neuconw.named_parameters():
             if n.endswith("weight_g"):
                 p.mul_(1.0 + 0.05 * torch.randn_like(p))
     vs = 2.0 / (1 << level)
     rdr.fine_octree_data = voxel.occupancy_from_dense(occ.cuda(), torch.zeros(3), 1.0, voxel_size=vs)
-    R = 96
     rays, ts, label, rgbs = synth_rays(R, 8, 64)
     out = rdr.render(rays.cuda(), ts.cuda(), label.cuda(), perturb_overwrite=0, background_rgb=torch.zeros(1, 3).cuda(),
                      cos_anneal_ratio=0.5)
-    sd = state_dict_cpu(emb, neuconw, nerf, torch.float32)
+    odt = torch.float32 if prec_name == "f32" and W == 64 else torch.float64  # fp64 arbitrates at the headline width
+    sd = state_dict_cpu(emb, neuconw, nerf, odt)
     cfg = dict(n_samples=16, n_importance=16, n_outside=4, up_sample_steps=2, s_val_base=3, render_bg=True,
                trim_sphere=True, mesh_mask_list=["sky"], depth_loss=True, skip_in=(4,), multires=6, multires_view=4,
                boundary_samples=10, sample_range=4, radius=1.0)
     fine = dict(occ=occ, scene_origin=torch.zeros(3), scale=1.0, voxel_size=vs)
-    ref = O.render(sd, cfg, rays, ts, label, 0.5, torch.zeros(1, 3), fine_octree=fine)
+    ref = O.render(sd, cfg, rays.to(odt), ts, label, 0.5, torch.zeros(1, 3, dtype=odt), fine_octree=fine)
     assert out["weights"].shape == ref["weights"].shape == (R, 16 + 16 + 10 + 4)
-    for k in ("color", "depth", "weights_sum", "gradient_error", "mask_error", "sfm_depth_loss", "color_bg"):
-        assert rel_err(out[k].detach().cpu(), ref[k]) < 2e-4, (k, rel_err(out[k].detach().cpu(), ref[k]))
+    errs = {k: rel_err(out[k].detach().cpu(), ref[k]) for k in ("color", "depth", "weights_sum", "gradient_error", "mask_error",
+                                                                "sfm_depth_loss", "color_bg", "weights", "cdf_fine", "gradients")}
+    print("voxel-guided render W=%d %s:" % (W, prec_name), {k: "%.2e" % v for k, v in errs.items()})
+    for k in ("color", "depth", "weights_sum", "mask_error", "sfm_depth_loss", "color_bg"):
+        assert errs[k] < tol_out, (k, errs[k])
+    # the eikonal term comes from the plain-fp16 adjoint sweep (normals 4e-4): F16_TOL[(16, 16)][2]
+    assert errs["gradient_error"] < (5e-4 if prec_name == "f16" else tol_out), errs["gradient_error"]
     for k in ("weights", "cdf_fine", "gradients"):
-        assert rel_err(out[k].detach().cpu(), ref[k]) < 2e-3, (k, rel_err(out[k].detach().cpu(), ref[k]))
+        assert errs[k] < tol_sample, (k, errs[k])
