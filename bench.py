@@ -159,10 +159,37 @@ def _oracle_setup(sample_rays, seed, variance=None):
 # reference (rendering/renderer.py render + NeuconWLoss + backward through the double forward + autograd.grad, ~9 M_sdf per
 # sample against the oracle's 6) was calibrated once where both exist (this repo's build container, 8 host threads, the same
 # 256 rays): scripts/diag/port_over_reference.py -> profiles/r04/port_over_reference.json.  None until measured.
-PORT_OVER_REFERENCE = {"value": 1.24, "measured": "profiles/r04/port_over_reference.json: the unmodified reference 1.74 s/step vs the oracle 1.40 s/step on the same 256 rays, 8 threads", "meaning": "reference time / port time: the reference's CPU throughput is this factor BELOW cpu_baseline.value"}
+RECORDED_FILE = os.path.join(ROOT, "profiles", "r04", "port_over_reference.json")
 
 
-def cpu_baseline(sample_rays=256, repeats=3, max_threads=32, seed=1000):
+def recorded_calibration():
+    """Numbers that can only be measured where /root/reference exists (the build container): read at run time from the committed
+    file scripts/diag/port_over_reference.py wrote -- never constants in this script -- and tagged as RECORDED, not measured in
+    this run.  -> (port_over_reference dict or None, reference-fp32-vs-fp64 dict or None)."""
+    try:
+        with open(RECORDED_FILE) as fh:
+            d = json.load(fh)
+        t = d["timing"]
+        por = {"value": round(t["port_over_reference"], 4), "recorded_not_measured_in_this_run": True,
+               "source": os.path.relpath(RECORDED_FILE, ROOT),
+               "measured": "the unmodified reference %.2f s/step vs the oracle %.2f s/step on the same %d rays of this batch"
+                           % (t["reference_s_per_step"], t["oracle_s_per_step"], d["rays"]),
+               "calibration_threads": d["threads"], "calibration_host_cpu_count": d["cpu_count"],
+               "note": "calibrated on ANOTHER box with %d threads; this run's cpu_baseline uses `cores` threads of this box"
+                       % d["threads"],
+               "meaning": "reference time / port time: the reference's CPU throughput is this factor BELOW cpu_baseline.value"}
+        r = d.get("reference_fp32_on_the_timed_batch_256_rays", {})
+        keys = ("colour", "depth", "weights_sum", "weights")
+        ref = {"recorded_not_measured_in_this_run": True, "source": os.path.relpath(RECORDED_FILE, ROOT)}
+        for name, k in (("inv_s_20", "variance_0.3"), ("inv_s_403", "variance_0.6"), ("trained_40_steps_inv_s_403", "trained_40_steps")):
+            if k in r:
+                ref[name] = {q: float("%.3g" % r[k][q]) for q in keys if q in r[k]}
+        return por, (ref if len(ref) > 2 else None)
+    except Exception:
+        return None, None
+
+
+def cpu_baseline(sample_rays=256, repeats=3, max_threads=32, seed=1000, full_batch=True):
     """The CPU oracle (oracle/neuconw_oracle.py, pinned to the real reference by tests/golden) timed on
     this box's host cores on a bounded sample of the same workload (same nets, same sampler shape).
     Returns (cpu_baseline dict, reference outputs of that sample for the `parity` object)."""
@@ -186,8 +213,28 @@ def cpu_baseline(sample_rays=256, repeats=3, max_threads=32, seed=1000):
     ref = {k: out[k].detach() for k in ("color", "depth", "weights_sum", "weights", "z_vals", "gradients", "cdf_fine")}
     ref["loss"] = float(loss.detach())
     ref["sdf"], ref["pts"] = _oracle_sdf_at_samples(sd, rays, ref["z_vals"])
+    # BASELINE.md 3 quotes the CPU path on the FULL 1024-ray batch: one un-warmed pass over all of it (the 256-ray sample above is
+    # the repeated, median-of-3 figure; per ray-sample the CPU is slower at 1024 rays -- BASELINE.md 2: 10.1 k vs 14.1 k -- so
+    # the sample flatters the CPU side).  Skipped when the sample says it would take more than ~40 s.
+    full = None
+    if full_batch and t * (R_PER_GPU / sample_rays) < 40.0:
+        try:
+            del out, loss
+            sd_f, cfg_f, (rays_f, ts_f, label_f, rgbs_f) = _oracle_setup(R_PER_GPU, seed)
+            sd_f = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd_f.items()}
+            t0 = time.perf_counter()
+            out_f = O.render(sd_f, cfg_f, rays_f, ts_f, label_f, 0.5, torch.zeros(1, 3))
+            loss_f = O.neuconw_loss(out_f, rgbs_f, cfg_f)
+            torch.autograd.grad(loss_f, [v for v in sd_f.values() if v.requires_grad], allow_unused=True)
+            tf = time.perf_counter() - t0
+            full = {"value": R_PER_GPU * S / tf, "unit": "ray-samples/s", "seconds": round(tf, 2), "rays": R_PER_GPU, "passes": 1,
+                    "note": "all %d rays of the timed batch, ONE pass, no warm-up (BASELINE.md 3)" % R_PER_GPU}
+            del out_f, loss_f, sd_f
+        except Exception as e:  # (host memory: ~10 GB of autograd state at 1024 rays)
+            full = {"value": None, "error": "%r" % (e,)}
     return {"value": sample_rays * S / t, "unit": "ray-samples/s", "cores": cores, "kind": "port", "repeats": repeats,
-            "port_over_reference": PORT_OVER_REFERENCE,
+            "full_batch": full,
+            "port_over_reference": recorded_calibration()[0],
             "sample": "the first %d rays of the timed %d-ray batch x %d samples (BASELINE.md 3), same networks / sampler, "
                       "fp32 torch-CPU oracle (the analytic-adjoint restatement: 6 M_sdf per sample where the reference's "
                       "double forward + autograd.grad spends ~9 M_sdf, SURVEY 8d -- this flatters the CPU side slightly), "
@@ -207,17 +254,22 @@ def _oracle_sdf_at_samples(sd, rays, z):
     return sdf, pts
 
 
-def oracle_outputs(sample_rays=256, seed=1000, variance=None, state=None):
+def oracle_outputs(sample_rays=256, seed=1000, variance=None, state=None, voxel=False):
     """Forward-only oracle evaluation of the same sample (fp64), optionally at another variance (inv_s = exp(10 variance))
-    or with another state_dict (`state`: the trained-weights point)."""
+    or with another state_dict (`state`: the trained-weights point); voxel: configs[2] (coarse + fine level-7 shell octree)."""
     from oracle import neuconw_oracle as O
 
     sd, cfg, (rays, ts, label, rgbs) = _oracle_setup(sample_rays, seed, variance)
     if state is not None:
         sd = dict(state)
     sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    octs = {}
+    if voxel:
+        oct_ = dict(occ=voxel_shell(7, device="cpu"), scene_origin=torch.zeros(3, dtype=torch.float64), scale=1.0, voxel_size=2.0 / 128)
+        octs = dict(coarse_octree=oct_, fine_octree=oct_)
+        cfg = dict(cfg, boundary_samples=10, sample_range=16, radius=1.0, voxel_size=2.0 / 128)
     with torch.no_grad():
-        out = O.render(sd, cfg, rays.double(), ts, label, 0.5, torch.zeros(1, 3, dtype=torch.float64))
+        out = O.render(sd, cfg, rays.double(), ts, label, 0.5, torch.zeros(1, 3, dtype=torch.float64), **octs)
         loss = O.neuconw_loss(out, rgbs.double(), cfg)
     ref = {k: out[k] for k in ("color", "depth", "weights_sum", "weights", "z_vals", "gradients", "cdf_fine")}
     ref["loss"] = float(loss)
@@ -250,10 +302,28 @@ def trained_state(dev, steps=40, sample_rays=256, seed=1000, lr=1e-3, variance=0
     return _state_dict_of(emb, neuconw, nerf)
 
 
-def gpu_outputs(dev, prec, sample_rays=256, seed=1000, variance=None, pts=None, state=None):
+def voxel_setup(rdr, dev):
+    """BASELINE configs[2] on a renderer: level-7 shell occupancy as coarse octree (ray near/far) AND fine octree (+-16-voxel
+    sampling window, 10 boundary samples).  -> the oracle's (coarse_octree, fine_octree, cfg additions)."""
+    from neuralrecon_w_amd import voxel
+
+    occ = voxel_shell(7, device=dev)
+    vs = 2.0 / 128
+    rdr.nerf_far_override, rdr.voxel_size = True, vs
+    rdr.octree_data = voxel.occupancy_from_dense(occ, torch.zeros(3), 1.0, voxel_size=vs)
+    rdr.fine_octree_data = voxel.occupancy_from_dense(occ, torch.zeros(3), 1.0, voxel_size=vs)
+    rdr.sample_range, rdr.boundary_samples = 16, 10
+    oct_ = dict(occ=occ.cpu(), scene_origin=torch.zeros(3), scale=1.0, voxel_size=vs)
+    return oct_, oct_, dict(boundary_samples=10, sample_range=16, radius=1.0, voxel_size=vs)
+
+
+def gpu_outputs(dev, prec, sample_rays=256, seed=1000, variance=None, pts=None, state=None, z_override=None, voxel=False):
     """The product's render + loss of the same sample, same (initial, or `state`) weights, in the TIMED precision,
-    deterministic sampling (perturb 0) like the oracle leg; `pts`: where to evaluate the SDF network (the oracle's samples)."""
+    deterministic sampling (perturb 0) like the oracle leg; `pts`: where to evaluate the SDF network (the oracle's samples);
+    `z_override`: the oracle's own primary sample depths (the MLPs + compositor at FIXED positions); `voxel`: configs[2]."""
     emb, neuconw, nerf, rdr = build_models(dev, prec)
+    if voxel:
+        voxel_setup(rdr, dev)
     if state is not None:
         with torch.no_grad():
             emb.weight.copy_(state["embedding_a.weight"])
@@ -265,7 +335,7 @@ def gpu_outputs(dev, prec, sample_rays=256, seed=1000, variance=None, pts=None, 
     rays, ts, label, rgbs = [t[:sample_rays] for t in synth_batch(R_PER_GPU, seed, dev)]
     with torch.no_grad():
         out = rdr.render(rays, ts, label, perturb_overwrite=0, background_rgb=torch.zeros(1, 3, device=dev),
-                         cos_anneal_ratio=0.5)
+                         cos_anneal_ratio=0.5, _z_override=z_override)
         loss = loss_fn_torch(out, rgbs)
     got = {k: out[k].detach().cpu() for k in ("color", "depth", "weights_sum", "weights", "gradients", "cdf_fine")}
     got["loss"] = float(loss)
@@ -311,7 +381,7 @@ def pmc_kernel_name(raw):
     return k.split("(")[0] if "(" in k else k
 
 
-def pmc_traffic(argv_inner, steps_inner, timeout=240, env=None):
+def pmc_traffic(argv_inner, steps_inner, timeout=240, env=None, split=False):
     """HBM traffic measured WITH this run: two rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass:
     MI355X_MICROARCH.md, PMC slots) of a short inner run of this script.  Returns ({kernel: bytes per launch},
     bytes per step over all kernels) or (None, None).  FETCH_SIZE is doubled (the guide's gfx950 rule for wide
@@ -350,11 +420,15 @@ def pmc_traffic(argv_inner, steps_inner, timeout=240, env=None):
             return None, None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    out, total = {}, 0.0
+    out, total, tf, tw = {}, 0.0, 0.0, 0.0
     for k, c in per_kernel.items():
         b = (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0
         total += b
+        tf += 2.0 * c.get("FETCH_SIZE", 0.0) * 1024.0
+        tw += c.get("WRITE_SIZE", 0.0) * 1024.0
         out[k] = b / max(launches[k], 1)
+    if split:  # (fetch bytes, write bytes) per step
+        return out, (tf / max(steps_inner, 1), tw / max(steps_inner, 1))
     return out, total / max(steps_inner, 1)
 
 
@@ -454,6 +528,35 @@ def bench_grid512(args, nw, L, dev, world, rank):
         plain = {"ms_per_sweep": (time.perf_counter() - t1) * 1e3, "note": "NEUCONW_SDF_SPLIT=0: one fp16 rounding per operand, "
                  "SDF error 4-6e-4 (moves the zero level set by a tenth of a 512^3 voxel) instead of 5-9e-7"}
         net.sdf_split = None
+    # ---- parity of the timed sweep: a random sub-lattice of rank 0's slice against the fp64 oracle (utils/visualization.py:46-50:
+    # linspace^3, 'ij' order, x slowest); with --prec f16 this is the split-precision value chain the product defaults to
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline:
+        try:
+            from oracle import neuconw_oracle as O
+
+            sweep()
+            torch.cuda.synchronize()
+            n_s = 32768
+            gsel = torch.Generator().manual_seed(7)
+            idx = torch.randint(0, count, (n_s,), generator=gsel)
+            lin = torch.linspace(lo[0], hi[0], dim, dtype=torch.float64)
+            gi = idx + start
+            pts = torch.stack([lin[gi // (dim * dim)], lin[(gi // dim) % dim], lin[gi % dim]], -1)
+            sd = {"sdf_net." + k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+            t_or = time.perf_counter()
+            with torch.no_grad():
+                ref = O.sdf_net(sd, pts, with_grad=False)[0]
+            t_or = time.perf_counter() - t_or
+            got = out[idx.to(dev)].cpu().double()
+            parity = {"dtype": args.prec, "points": n_s, "of": "rank 0's slice of the 512^3 lattice, random sub-lattice (seed 7)",
+                      "oracle": "fp64 torch-CPU oracle (oracle/neuconw_oracle.py sdf_net) at the lattice coordinates of utils/visualization.py:46-50",
+                      "sdf_abs": float("%.3g" % float((got - ref).abs().max())),
+                      "sdf": float("%.3g" % float((got - ref).abs().max() / ref.abs().max())),
+                      "value_path": "split-precision fp16 (hi + lo operands)" if (prec == nw.PREC_F16 and net.split_value(prec)) else args.prec,
+                      "oracle_points_per_s_%d_threads" % torch.get_num_threads(): round(n_s / t_or, 1)}
+        except Exception as e:
+            parity = {"dtype": args.prec, "error": "failed: %r" % (e,)}
     macs = {256: 459008, 512: 1835520}[W]
     pts_s = total * K / dt
     peak = PEAK_BF16_TFLOPS if prec != nw.PREC_F32 else 157.3  # fp16 MFMA peak = bf16 peak
@@ -472,7 +575,116 @@ def bench_grid512(args, nw, L, dev, world, rank):
             "roofline": {"kernel": "ncw_sdf_infer_points", "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                          "algorithmic_mflop_per_point": round(2.0 * macs / 1e6, 3)},
-            "cpu_baseline": None}))
+            "parity": parity, "cpu_baseline": None}))
+
+
+def bench_render(args, nw, L, dev, world, rank):
+    """Secondary row `--config render`: the FORWARD-ONLY render of the reference's validation / novel-view path
+    (lightning_modules/neuconw_system.py:404-458 -> rendering/renderer.py:785-916 under no_grad): sampler + the three MLPs'
+    stash-free kernels + compositor on the headline networks, 1024 rays x (64 + 64) samples per pass (and one
+    4096-ray chunk), next to the TRAINING forward of the same batch (grad mode on: full stash)."""
+    prec = {"bf16": nw.PREC_BF16, "f16": nw.PREC_F16, "f32": nw.PREC_F32}[args.prec]
+    emb, neuconw, nerf, rdr = build_models(dev, prec)
+    rdr.bg_dense = not args.bg_eliminate
+    R = args.rays
+    rays, ts, label, rgbs = synth_batch(R, 1000 + rank, dev)
+    bg = torch.zeros(1, 3, device=dev)
+    S = N_SAMPLES + N_IMPORTANCE
+
+    def fwd_only(r=rays, t=ts, l=label):
+        with torch.no_grad():
+            return rdr.render(r, t, l, background_rgb=bg, cos_anneal_ratio=0.5, perturb_overwrite=0)
+
+    def fwd_train():
+        return rdr.render(rays, ts, label, background_rgb=bg, cos_anneal_ratio=0.5, perturb_overwrite=0)
+
+    def timed(fn, k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            o = fn()
+            del o
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k
+
+    for _ in range(args.warmup):
+        fwd_only()
+    if world > 1:
+        dist.barrier()
+    dt = timed(fwd_only, args.steps)
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if args.inner:
+        if rank == 0:
+            print(json.dumps({"inner": True, "ms_per_step": dt * 1e3}))
+        return
+    for _ in range(3):
+        o = fwd_train()
+        del o
+    dt_train = timed(fwd_train, args.steps)
+    same = None
+    a_, b_ = fwd_train(), fwd_only()
+    same = all(torch.equal(a_[k].detach(), b_[k]) for k in ("color", "depth", "weights", "weights_sum", "gradients", "cdf_fine", "color_bg"))
+    del a_, b_
+    # per-kernel HIP-event times of both forms (one stream)
+    two, rdr.use_bg_stream = rdr.use_bg_stream, False
+    per = {}
+    for name, fn in (("forward_only", fwd_only), ("training_forward", fwd_train)):
+        L.PROFILE = {}
+        for _ in range(3):
+            o = fn()
+            del o
+        torch.cuda.synchronize()
+        prof, L.PROFILE = L.PROFILE, None
+        prof = {(k[:-4] if k.endswith("_f16") else k): v for k, v in prof.items()}
+        per[name] = {k: round(sum(a.elapsed_time(b) for a, b in v) / 3, 4) for k, v in sorted(prof.items())}
+    rdr.use_bg_stream = two
+    arena = {}
+    for nm, mod in (("sdf", neuconw.sdf_net), ("colour", neuconw.color_net), ("background", nerf)):
+        for key, e in mod.__dict__["_stash_cache"]._e.items():
+            arena["%s_%s_mb" % (nm, "training" if key[-1] else "forward_only")] = round(e["arena"].buf.numel() / 1e6, 2)
+    # one 4096-ray chunk (the validation loop renders an image in chunks)
+    r4, t4, l4, _ = synth_batch(4096, 77, dev)
+    for _ in range(2):
+        fwd_only(r4, t4, l4)
+    dt4 = timed(lambda: fwd_only(r4, t4, l4), max(2, args.steps // 4))
+    traffic = None
+    if not args.no_pmc and rank == 0:
+        inner = ["--inner", "--config", "render", "--gpus", "1", "--steps", "3", "--warmup", "2", "--prec", args.prec, "--rays", str(R),
+                 "--no-cpu-baseline", "--no-pmc"] + (["--bg-eliminate"] if args.bg_eliminate else [])
+        per_kernel, step_bytes = pmc_traffic(inner, 5, timeout=240, split=True)
+        if per_kernel:
+            traffic = {"fetch_gb_per_render": round(step_bytes[0] / 1e9, 3), "write_gb_per_render": round(step_bytes[1] / 1e9, 3),
+                       "note": "rocprofv3 --pmc passes of this row (FETCH_SIZE x 2 per the gfx950 rule; WRITE_SIZE as counted); the writes "
+                               "are the SDF network's h_l scratch (re-read by its own adjoint sweep: 8 x 512 B per sample = 0.54 GB) + feat",
+                       "kernel_mb_per_launch": {k[:48]: round(v / 1e6, 1) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1])[:8]}}
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline:
+        try:
+            ref = oracle_outputs()
+            parity = {"dtype": args.prec, "rays": 256, "oracle": "fp64 oracle, first 256 rays of the batch, inv_s 20",
+                      "bitwise_equal_to_training_forward": bool(same)}
+            parity.update(parity_errors(gpu_outputs(dev, prec, pts=ref["pts"]), ref))
+        except Exception as e:
+            parity = {"error": "failed: %r" % (e,), "bitwise_equal_to_training_forward": bool(same)}
+    if rank == 0:
+        mlp = ("ncw_sdf_fwd", "ncw_color_fwd", "ncw_nerf_fwd")
+        print(json.dumps({
+            "metric": "ray-samples/sec (forward-only render) at %d rays x %d samples [secondary: validation / novel-view path]" % (R, S),
+            "value": world * R * S / dt, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec,
+            "data": "synthetic",
+            "config": {"workload": "forward-only render (torch.no_grad): sampler + SDF / colour / background MLPs (stash-free kernels) + "
+                                   "compositor, %d rays x (%d + %d) samples, headline networks, background %s"
+                                   % (R, N_SAMPLES, N_IMPORTANCE, "on every sample" if rdr.bg_dense else "eliminated where dead"),
+                       "rays_per_gpu": R, "samples_per_ray": S},
+            "training_forward_ms": dt_train * 1e3, "forward_only_over_training_forward": round(dt / dt_train, 4),
+            "mlp_forward_ms": {k: round(sum(per[k].get(m, 0.0) for m in mlp), 4) for k in per},
+            "per_kernel_ms": per, "stash_arena": arena, "chunk_4096_rays_ms": dt4 * 1e3,
+            "chunk_4096_rays_value": 4096 * S / dt4, "traffic": traffic, "parity": parity, "roofline": None, "cpu_baseline": None}))
 
 
 def main():
@@ -491,9 +703,10 @@ def main():
                     help="secondary: time the MAIN leg with dead-background elimination (the product default) instead of "
                          "evaluating the background NeRF on every sample like the reference; marked in the metric name")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 parity-mode timing (`parity_mode`)")
+    ap.add_argument("--save-trained-state", default=None, help="write the trained-weights parity point's state_dict here (.pt)")
     ap.add_argument("--inner", action="store_true", help="(internal) the short run the PMC passes profile: timing loop only")
     ap.add_argument("--grid-width", type=int, default=None, choices=[256, 512], help="--config grid512: SDF width (default 512)")
-    ap.add_argument("--config", default="headline", choices=["headline", "shipped", "voxel", "grid512"],
+    ap.add_argument("--config", default="headline", choices=["headline", "shipped", "voxel", "grid512", "render"],
                     help="headline = BASELINE.json configs[1] (the metric's shape).  Secondary rows, never the reported "
                          "metric: shipped = the reference's yaml shape (W=512 SDF, 8+16 samples); voxel = configs[2] "
                          "(headline + level-7 shell occupancy: voxel near/far, +-16-voxel window, 10 boundary samples); "
@@ -571,6 +784,11 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    if args.config == "render":
+        bench_render(args, nw, L, dev, world, rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     prec = {"bf16": nw.PREC_BF16, "f16": nw.PREC_F16, "f32": nw.PREC_F32}[args.prec]
     R = args.rays
     bg = torch.zeros(1, 3, device=dev)
@@ -588,14 +806,7 @@ def main():
         if sdf_split is not None:  # None = the product default (fp16: split-precision SDF value path, csrc/ncw_split.hip)
             neuconw_.sdf_net.sdf_split = sdf_split
         if args.config == "voxel":  # configs[2]: coarse octree -> ray near/far; fine octree -> +-SAMPLE_RANGE window + boundary samples
-            from neuralrecon_w_amd import voxel
-
-            occ = voxel_shell(7, device=dev)
-            vs = 2.0 / 128
-            rdr_.nerf_far_override, rdr_.voxel_size = True, vs
-            rdr_.octree_data = voxel.occupancy_from_dense(occ, torch.zeros(3), 1.0, voxel_size=vs)
-            rdr_.fine_octree_data = voxel.occupancy_from_dense(occ, torch.zeros(3), 1.0, voxel_size=vs)
-            rdr_.sample_range, rdr_.boundary_samples = 16, 10
+            voxel_setup(rdr_, dev)
         train_ = nw.TrainStep(rdr_, [emb_, neuconw_, nerf_], loss_fn, lr=1e-4 * world * R / 4096.0, eps=1e-7, clip=0.99,
                               world_size=world, capture=args.graph, capture_warmup=3)
 
@@ -853,24 +1064,49 @@ def main():
         # ---- measured error of the program that was timed: the GPU render + loss of the oracle leg's 256 rays (same
         # batch, same initial weights, deterministic sampling) in the TIMED dtype, against the oracle -- at the initial
         # operating point (variance 0.3, inv_s 20) and where NeuS trains (variance 0.6: inv_s = exp(6) = 403)
+        if args.config == "voxel":  # configs[2] in the TIMED dtype against the fp64 oracle with the same coarse + fine octree
+            try:
+                ref_v = oracle_outputs(voxel=True)
+                parity_obj = {"dtype": args.prec, "rays": 256, "measure": "max|gpu - oracle| / max|oracle| (loss: absolute)",
+                              "oracle": "fp64 oracle with the same level-7 shell occupancy as coarse (ray near / far) and fine (+-16-voxel "
+                                        "window, 10 boundary samples) octree; kaolin's ray / voxel query itself is UNPINNED (restated)"}
+                parity_obj.update(parity_errors(gpu_outputs(dev, prec, pts=ref_v["pts"], voxel=True), ref_v))
+                ref_vt = oracle_outputs(variance=0.6, voxel=True)
+                parity_obj["at_inv_s_403"] = parity_errors(gpu_outputs(dev, prec, variance=0.6, pts=ref_vt["pts"], voxel=True), ref_vt)
+                if prec != nw.PREC_F32:
+                    parity_obj["f32_mode"] = parity_errors(gpu_outputs(dev, nw.PREC_F32, pts=ref_v["pts"], voxel=True), ref_v)
+            except Exception as e:
+                parity_obj = {"dtype": args.prec, "error": "failed: %r" % (e,)}
         if ref32 is not None and args.config in ("headline", "shipped"):
             try:
                 parity_obj = {"dtype": args.prec, "rays": 256, "measure": "max|gpu - oracle| / max|oracle| (loss: absolute)",
                               "oracle": "fp32 torch-CPU oracle of the cpu_baseline leg (inv_s 20); fp64 oracle at inv_s 403"}
                 # what the UNMODIFIED reference's own fp32 arithmetic differs from the fp64 oracle by on these same 256 rays
                 # (build container, scripts/diag/port_over_reference.py family -> profiles/r04/port_over_reference.json)
-                parity_obj["reference_fp32_vs_fp64_oracle_same_rays"] = {
-                    "inv_s_20": {"colour": 1.09e-05, "depth": 1.73e-06, "weights_sum": 1.08e-05, "weights": 8.27e-04},
-                    "inv_s_403": {"colour": 2.57e-04, "depth": 2.74e-04, "weights_sum": 2.54e-04, "weights": 1.08e-03}}
+                parity_obj["reference_fp32_vs_fp64_oracle_same_rays"] = recorded_calibration()[1]
                 parity_obj["outputs"] = ("colour / depth / weights_sum per ray; `weights` = per-SAMPLE compositing weights [R, S+O]; "
                                          "`sdf` = SDF network at the oracle's sample positions (sdf_abs in unit-sphere units)")
                 parity_obj.update(parity_errors(gpu_outputs(dev, prec, pts=ref32["pts"]), ref32))
+                # the comparison that isolates the MLPs + compositor from the discrete sampler: the GPU evaluates the ORACLE's own
+                # primary sample depths (render(_z_override=...)); per-SAMPLE `weights` are index-aligned here by construction
+                fz = parity_errors(gpu_outputs(dev, prec, z_override=ref32["z_vals"]), ref32)
+                parity_obj["fixed_z"] = {k: fz[k] for k in ("colour", "depth", "weights_sum", "weights", "gradients", "cdf_fine") if k in fz}
+                parity_obj["fixed_z"]["note"] = ("GPU MLPs + compositor at the oracle's z_vals (no sampler in the comparison): the "
+                                                 "per-sample `weights` figure the north star's 1e-4 applies to")
                 ref_t = oracle_outputs(variance=0.6)
                 parity_obj["at_inv_s_403"] = parity_errors(gpu_outputs(dev, prec, variance=0.6, pts=ref_t["pts"]), ref_t)
+                fz = parity_errors(gpu_outputs(dev, prec, variance=0.6, z_override=ref_t["z_vals"]), ref_t)
+                parity_obj["at_inv_s_403"]["fixed_z"] = {k: fz[k] for k in ("colour", "depth", "weights_sum", "weights") if k in fz}
                 # trained weights: 40 fp32 TrainSteps on these rays, then variance 0.6 (tests/test_gpu_fullsize.py)
                 st_tr = trained_state(dev)
+                if args.save_trained_state:  # for scripts/diag/reference_on_trained_state.py (the reference's own fp32 on these weights)
+                    os.makedirs(os.path.dirname(os.path.abspath(args.save_trained_state)), exist_ok=True)
+                    torch.save(st_tr, args.save_trained_state)
                 ref_tr = oracle_outputs(state=st_tr)
                 parity_obj["trained_40_steps_inv_s_403"] = parity_errors(gpu_outputs(dev, prec, pts=ref_tr["pts"], state=st_tr), ref_tr)
+                fz = parity_errors(gpu_outputs(dev, prec, state=st_tr, z_override=ref_tr["z_vals"]), ref_tr)
+                parity_obj["trained_40_steps_inv_s_403"]["fixed_z"] = {k: fz[k] for k in ("colour", "depth", "weights_sum", "weights",
+                                                                                          "colour_rays_above_1e-4") if k in fz}
                 if prec != nw.PREC_F32:
                     parity_obj["f32_mode"] = parity_errors(gpu_outputs(dev, nw.PREC_F32, pts=ref32["pts"]), ref32)
                     parity_obj["f32_mode_at_inv_s_403"] = parity_errors(gpu_outputs(dev, nw.PREC_F32, variance=0.6, pts=ref_t["pts"]), ref_t)

@@ -404,6 +404,12 @@ int ncw_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  * loss_scale: device float[2] = {scale, 1 / scale} (read by NcwCompositeGrad.grad_scale_dev / NcwUnpackDesc.grad_mul_dev) or
  * NULL; growth_interval 0 = never grow.  lr_dev: device scalar overriding `lr` (schedulers under graph replay) or NULL.
  * The reference's recipe has no counterpart for the scale (fp32 training, train.py:48-62). */
+/* total_norm of torch.nn.utils.clip_grad_norm_ (train.py:61) over ONE flat fp32 buffer (16-byte aligned): norm[0] = ||grad||_2.
+ * One launch, fixed summation order (run-to-run reproducible), non-finite entries propagate.  scratch: device floats,
+ * ncw_grad_norm_scratch_floats() of them, ZERO-FILLED ONCE by the caller (it holds the kernel's re-arming ticket). */
+int64_t ncw_grad_norm_scratch_floats(void);
+int ncw_grad_norm(const float* grad, int64_t n, float* scratch, float* norm, void* stream);
+
 typedef struct NcwAdamState {
     int32_t step;      /* applied (non-skipped) steps: Adam's t */
     int32_t good;      /* consecutive finite steps since the last scale change */

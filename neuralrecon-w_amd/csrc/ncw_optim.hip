@@ -128,6 +128,64 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, fl
     }
 }
 
+// ---- 2-norm of the flat gradient buffer (the `total_norm` of clip_grad_norm_, train.py:61) as ONE launch with a FIXED
+// summation order: NORM_BLOCKS blocks reduce contiguous, 16-byte-aligned chunks (lane-strided f32x4 loads, a wavefront shuffle
+// tree, the four wave partials through LDS) into scratch[block]; the last block to arrive (a device ticket) adds the partials in
+// block order, takes the square root and re-arms the ticket.  Run-to-run reproducible (no float atomics), non-finite inputs
+// propagate (the fp16 loss-scale guard of adam_prep_kernel reads the result).
+constexpr int NORM_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void grad_norm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ scratch,
+                                                        float* __restrict__ norm) {
+    __shared__ float wsum[4];
+    __shared__ int last;
+    const int64_t quads = (n + 3) / 4;
+    const int64_t per = (quads + NORM_BLOCKS - 1) / NORM_BLOCKS;
+    const int64_t q0 = (int64_t)blockIdx.x * per, q1 = q0 + per < quads ? q0 + per : quads;
+    float acc = 0.f;
+    for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) {
+        const int64_t i = q * 4;
+        if (i + 4 <= n) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+            acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        } else {
+            for (int64_t j = i; j < n; ++j) acc += g[j] * g[j];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scratch[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        __threadfence();
+        unsigned* ticket = reinterpret_cast<unsigned*>(scratch + NORM_BLOCKS);
+        last = (atomicAdd(ticket, 1u) == NORM_BLOCKS - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // the 256 partials in block order: lane-strided pairs, then the same shuffle tree (fixed order)
+    float t = __builtin_nontemporal_load(scratch + threadIdx.x);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        norm[0] = sqrtf((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+        *reinterpret_cast<unsigned*>(scratch + NORM_BLOCKS) = 0u;  // re-armed for the next launch (stream order)
+    }
+}
+
+extern "C" int64_t ncw_grad_norm_scratch_floats(void) { return NORM_BLOCKS + 4; }
+
+extern "C" int ncw_grad_norm(const float* grad, int64_t n, float* scratch, float* norm, void* stream) {
+    if (!grad || !scratch || !norm || n < 0 || ((uintptr_t)grad & 15) != 0) return NCW_E_BADARG;
+    hipLaunchKernelGGL(grad_norm_kernel, dim3(NORM_BLOCKS), dim3(256), 0, (hipStream_t)stream, grad, n, scratch, norm);
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int ncw_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, NcwAdamState* state,
                                  const float* total_norm, float lr, const float* lr_dev, float beta1, float beta2, float eps,
                                  float max_norm, float* loss_scale, int growth_interval, float scale_min, float scale_max,

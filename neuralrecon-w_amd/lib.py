@@ -194,6 +194,8 @@ _PROTOS = {
     "ncw_abi_version": (C.c_int, []),
     "ncw_source_hash": (C.c_char_p, []),
     "ncw_device_info": (C.c_int, [C.c_char_p, C.c_int]),
+    "ncw_grad_norm_scratch_floats": (C.c_int64, []),
+    "ncw_grad_norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ncw_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ncw_unpack_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ncw_sdf_infer": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

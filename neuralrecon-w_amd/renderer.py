@@ -500,7 +500,9 @@ class NeuconWRenderer:
         ps += [p for n, p in nf.named_parameters() if not n.startswith("views_linears")]
         return ps
 
-    def render(self, rays, ts, label, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0, _rand=None):
+    def render(self, rays, ts, label, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0, _rand=None, _z_override=None):
+        """_rand / _z_override are test hooks: the sampler's uniforms, and primary sample depths [R, S] that replace the sampler's
+        (parity of the MLPs + compositor at FIXED sample positions, bench.py `parity.fixed_z`)."""
         device = rays.device
         if not rays.is_cuda:
             raise L.NeuconwHipError("NeuconWRenderer.render: rays are not on a GPU; the hot path has no CPU fallback")
@@ -531,6 +533,9 @@ class NeuconWRenderer:
             a_embedded = emb_a(ts)
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
         n_samples, z_vals, z_vals_outside, sample_dist = self.sparse_sampler(rays_o, rays_d, near, far, perturb, _rand)
+        if _z_override is not None:
+            assert tuple(_z_override.shape) == tuple(z_vals.shape), (tuple(_z_override.shape), tuple(z_vals.shape))
+            z_vals = _z_override.to(device=device, dtype=torch.float32).contiguous()
         bgc = None
         if background_rgb is not None:
             if background_rgb.numel() != 3:

@@ -172,7 +172,16 @@ class FlatAdam:
             raise L.NeuconwHipError("FlatAdam: parameters are not on a GPU; there is no CPU fallback")
         b1, b2 = self.betas
         need_norm = self.clip is not None or self.loss_scale is not None
-        norm = torch.linalg.vector_norm(fp.flat_grad) if need_norm else None
+        norm = None
+        if need_norm:  # ||flat_grad||_2 as one fixed-order launch (ncw_grad_norm) instead of ATen's reduction kernels
+            lib = L.get_lib()
+            if self.__dict__.get("_norm_scratch") is None:
+                self._norm_scratch = torch.zeros(int(lib.ncw_grad_norm_scratch_floats()), device=fp.flat_grad.device, dtype=torch.float32)
+                self._norm = torch.empty(1, device=fp.flat_grad.device, dtype=torch.float32)
+            norm = self._norm
+            L.check(lib.ncw_grad_norm(L.ptr(fp.flat_grad), fp.flat_grad.numel(), L.ptr(self._norm_scratch), L.ptr(norm),
+                                      L.stream_ptr(fp.flat_grad.device)), "ncw_grad_norm")
+            norm = norm[0]
         L.check(L.get_lib().ncw_adam_step_dev(
             L.ptr(fp.flat.data), L.ptr(fp.flat_grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), fp.flat_grad.numel(),
             L.ptr(self.state), L.ptr(norm), self.lr, L.ptr(self.lr_dev), b1, b2, self.eps,

@@ -157,3 +157,30 @@ def test_captured_step_follows_lr_schedule():
     moved = float((train.fp.flat.detach() - p0).abs().max())
     assert 1e-4 < moved <= 2e-3 * 1.5, moved  # an Adam step is <= ~lr per element
     assert abs(train.opt.lr - 2e-3) < 1e-12 and abs(float(train.opt.lr_dev) - 2e-3) < 1e-9
+
+
+@pytest.mark.parametrize("n", [4, 1001, 262144, 2088895])
+def test_grad_norm_launch_matches_torch_and_rearms(n):
+    """ncw_grad_norm (FlatAdam's total_norm, train.py:61 clip_grad_norm_): one launch, fixed order -- equal to torch's norm to fp32
+    rounding, bitwise repeatable, re-armed after every launch, non-finite entries propagate."""
+    import ctypes as C
+
+    from neuralrecon_w_amd import lib as L
+
+    lib = L.get_lib()
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n + 4, generator=g) * 3e-3).cuda()[:n]  # (a 16-byte aligned view)
+    scratch = torch.zeros(int(lib.ncw_grad_norm_scratch_floats()), device="cuda")
+    out = torch.empty(1, device="cuda")
+    vals = []
+    for _ in range(3):
+        L.check(lib.ncw_grad_norm(L.ptr(x), n, L.ptr(scratch), L.ptr(out), L.stream_ptr(x.device)), "ncw_grad_norm")
+        vals.append(float(out))
+    ref = float(torch.linalg.vector_norm(x.double()))
+    assert vals[0] == vals[1] == vals[2] and abs(vals[0] - ref) <= 2e-6 * ref, (vals, ref)
+    x[n // 2] = float("inf")
+    L.check(lib.ncw_grad_norm(L.ptr(x), n, L.ptr(scratch), L.ptr(out), L.stream_ptr(x.device)), "ncw_grad_norm")
+    assert float(out) == float("inf")
+    x[n // 2] = float("nan")
+    L.check(lib.ncw_grad_norm(L.ptr(x), n, L.ptr(scratch), L.ptr(out), L.stream_ptr(x.device)), "ncw_grad_norm")
+    assert float(out) != float(out)
