@@ -132,6 +132,13 @@ typedef struct NcwSdfNet {
      * 173-179, rendering/renderer.py:624-632) -- so the 5e-4 of a plain fp16 evaluation is 0.2 in the sigmoid's argument there.
      * The adjoint / backward passes and the feature rows stay plain fp16. */
     const void* w_lo[NCW_MAX_LAYERS];
+    /* wt_lo[l] = the rounding residuals of the TRANSPOSED matrices wt[l] (same packed layout), or all NULL.  When present (fp16,
+     * W = 256) the analytic adjoint sweep of ncw_sdf_fwd -- the normals -- takes its WEIGHTS as hi + lo pairs (W_hi^T t + W_lo^T t,
+     * two MFMAs per product; t stays single fp16): the compositor multiplies the normal's component along the ray by
+     * dist * inv_s inside the sigmoid (rendering/renderer.py:600-632), and on trained weights the plain-fp16 adjoint sweep was
+     * what put single rays above 1e-4 (scripts/diag/emul_timed_batch.py: worst rays 1.5e-4 -> 3.7e-5).  Forward only: the stash
+     * t_l, ncw_sdf_bwd and the weight gradients are unchanged. */
+    const void* wt_lo[NCW_MAX_LAYERS];
 } NcwSdfNet;
 
 /* a-2 `sdf(x)` (neuconw.py:281-282): x [n,3] f32 -> sdf [n] f32.  No grad, last layer 1 row. */

@@ -595,6 +595,174 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdS_kernel(NcwSdfNet net, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// sdf_fwd with the ADJOINT SWEEP'S WEIGHTS AS hi + lo PAIRS (NcwSdfNet.wt_lo; round 5).  The normals n = grad sdf leave this
+// kernel for the compositor, which multiplies their component along the ray by dist * inv_s inside the sigmoid
+// (rendering/renderer.py:600-632): on TRAINED weights (inv_s 403) the single-rounded fp16 adjoint sweep -- 4e-4 on the normals --
+// was what put single rays of the timed batch above 1e-4 (scripts/diag/emul_timed_batch.py: 6 of 256 rays -> the sweep's weight
+// rounding alone; with W^T = W_hi^T + W_lo^T the worst rays drop 1.5e-4 -> 3.7e-5, t_l may stay single fp16).
+// Structure: the value chain and the feature rows as in sdf_fwdS_kernel; in the sweep every B fragment read from LDS feeds FOUR
+// MFMAs (hi and lo slice x two tiles); the layer's two 16-unit slices (128 registers) are reloaded IN PLACE for the next layer
+// during the layer's last tile pair (unit q of wt[l-1] into the registers unit q of wt[l] has just left), so there is no second
+// prefetch set.  The stash t_l, the LDS layout and everything ncw_sdf_bwd reads are unchanged (forward only).
+// ------------------------------------------------------------------------------------------------
+template <bool TRAIN>
+__global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdSA_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
+                                                                 float* __restrict__ sdf, float* __restrict__ grad,
+                                                                 NcwSdfStash st) {
+    typedef ncw_h16 SE;
+    __shared__ __attribute__((aligned(16))) char lds[SS_ACT + SS_GAM];
+    ss_lfrag* const sbuf = (ss_lfrag*)(ncw_lchar*)lds;
+    ss_lfrag* const gbuf = sbuf + SS_ACT / 16;
+    const int lane = ncw_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int L = net.n_layers;
+    const int64_t tile0 = (int64_t)blockIdx.x * SS_TILES;
+    const int jb = wave & 1, jt = wave >> 1;  // this wave's gamma job of the adjoint sweep: block jb of tile jt
+    ss_value_chain<(TRAIN ? 2 : 1)>(net, src, n, tile0, sbuf, gbuf, lane, wave, sdf, st);
+    auto stride_of = [&](int l) { return l == net.skip_layer ? 10 : (l == 0 ? 2 : 8); };
+    bf16x8 wa[16], wl[16];  // hi / lo slice (output block = wave) of the current adjoint layer's transposed matrix
+    // ---- feature rows (plain fp16: the colour network reads them from the fp16 stash): W_feat . h_hi ----------------
+    {
+        sb_load_slice<16>(wl, net.w_feat, 8, wave, 0, lane);  // (wl is free until the sweep starts)
+        const bf16x8 wt1 = ss_gload(net.wt[L - 1], (size_t)wave, lane);      // W_{L-1}^T: unit 0, block = wave
+        const bf16x8 wt1l = ss_gload(net.wt_lo[L - 1], (size_t)wave, lane);  // ... and its residual
+        if (L - 2 >= 1) sb_load_slice<16>(wa, net.wt[L - 2], stride_of(L - 2), wave, 0, lane);
+        const f32x16 bias = ss_bias(net.b_feat, wave, lane);
+        const ss_lfrag* const ain = sbuf + lane;
+#pragma unroll
+        for (int tp = 0; tp < SS_TILES; tp += 2) {
+            f32x16 acc0 = bias, acc1 = bias;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0 = NCW_MFMA_H(wl[q], ain[((tp * 16 + q) * 2) * 64], acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wl[q], ain[(((tp + 1) * 16 + q) * 2) * 64], acc1, 0, 0, 0);
+            }
+            stash_store_block((SE*)st.feat, (size_t)(tile0 + tp), 8, wave, acc0, lane);
+            stash_store_block((SE*)st.feat, (size_t)(tile0 + tp + 1), 8, wave, acc1, lane);
+        }
+        if (L - 2 >= 1) sb_load_slice<16>(wl, net.wt_lo[L - 2], stride_of(L - 2), wave, 0, lane);
+        // ---- adjoint start: a_{L-2} = W_{L-1}^T e_0 (hi + lo; the same for every point); t_{L-2} = a * phi'(z_{L-2}) ----
+        bf16x8 e0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) e0f[e] = (ncw_h16)0.f;
+        e0f[0] = (ncw_h16)(lane < 32 ? 1.f : 0.f);
+        f32x16 a0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0[r] = 0.f;
+        a0 = NCW_MFMA_H(wt1, e0f, a0, 0, 0, 0);
+        a0 = NCW_MFMA_H(wt1l, e0f, a0, 0, 0, 0);
+        ncw_lds_barrier();  // every wave is done with the split buffer (feature rows, sdf row): the plain buffers alias it
+        sb_lfrag* out = (sb_lfrag*)sbuf;  // abuf0
+#pragma unroll
+        for (int t = 0; t < SS_TILES; ++t) {
+            f32x16 sv;
+            ss_load_sprime(sv, (const SE*)st.h[L - 1], (size_t)(tile0 + t), 8, wave, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] *= a0[r];
+            if (TRAIN) stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 8, wave, sv, lane);
+            sb_store_units(out, t, wave, sv, lane);
+        }
+    }
+    sb_lfrag* const abuf0 = (sb_lfrag*)sbuf;
+    sb_lfrag* const abuf1 = abuf0 + SB_ACT / 16;
+    int cur = 0;  // t_{L-2} lives in abuf0
+    f32x16 gg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gg[r] = 0.f;
+    // gamma job: gg += (W^T)[block ob of `w` / `wlo`] . t (tile jt), hi + lo, in two 8-unit chunks (64 temporary registers)
+    auto gamma_job = [&](const void* w, const void* wlo, int stride, int ob, const sb_lfrag* in) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bf16x8 th[8], tl[8];
+            sb_load_slice<8>(th, w, stride, ob, 8 * c, lane);
+            sb_load_slice<8>(tl, wlo, stride, ob, 8 * c, lane);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bf16x8 b = in[(jt * 16 + 8 * c + q) * 64 + lane];
+                gg = NCW_MFMA_H(th[q], b, gg, 0, 0, 0);
+                gg = NCW_MFMA_H(tl[q], b, gg, 0, 0, 0);
+            }
+        }
+    };
+    // ---- adjoint layers l = L-2 .. 1: t_{l-1} = ((W_hi^T + W_lo^T) t_l) * phi'(z_{l-1}) ------------------------------------
+    for (int l = L - 2; l >= 1; --l) {
+        const bool skip = (l == net.skip_layer);
+        const bool more = l - 1 >= 1;           // a further 8-block layer follows: its slices replace this layer's in place
+        const void* nh = more ? net.wt[l - 1] : nullptr;
+        const void* nl = more ? net.wt_lo[l - 1] : nullptr;
+        const int nstride = more ? stride_of(l - 1) : 8;
+        ncw_lds_barrier();  // t_l complete in abuf[cur]
+        const sb_lfrag* in = cur ? abuf1 : abuf0;
+        sb_lfrag* out = cur ? abuf0 : abuf1;
+#pragma unroll
+        for (int tp = 0; tp < SS_TILES; tp += 2) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bf16x8 b0 = in[(tp * 16 + q) * 64 + lane], b1 = in[((tp + 1) * 16 + q) * 64 + lane];
+                acc0 = NCW_MFMA_H(wa[q], b0, acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wa[q], b1, acc1, 0, 0, 0);
+                acc0 = NCW_MFMA_H(wl[q], b0, acc0, 0, 0, 0);
+                acc1 = NCW_MFMA_H(wl[q], b1, acc1, 0, 0, 0);
+                if (tp == SS_TILES - 2 && more) {  // the last use of unit q in this layer: the next layer's unit q takes its registers
+                    wa[q] = ss_gload(nh, (size_t)q * nstride + wave, lane);
+                    wl[q] = ss_gload(nl, (size_t)q * nstride + wave, lane);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16& acc = j ? acc1 : acc0;
+                f32x16 sv;
+                ss_load_sprime(sv, (const SE*)st.h[l], (size_t)(tile0 + tp + j), 8, wave, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[r] *= acc[r];
+                if (TRAIN) stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + tp + j), 8, wave, sv, lane);
+                sb_store_units(out, tp + j, wave, sv, lane);
+            }
+        }
+        if (skip) gamma_job(net.wt[l], net.wt_lo[l], 10, 8 + jb, in);  // the gamma columns of the transposed skip layer: out-blocks 8, 9
+        cur ^= 1;
+    }
+    // ---- adjoint layer 0: g_gamma += W_0^T t_0 (2 out-blocks), then grad = J_gamma^T g_gamma -----------------------
+    ncw_lds_barrier();
+    gamma_job(net.wt[0], net.wt_lo[0], 2, jb, cur ? abuf1 : abuf0);
+    int64_t p = (tile0 + jt) * 32 + (lane & 31), ray;
+    const bool valid = p < n;
+    if (!valid) p = n - 1;
+    float xs[3];
+    load_point(src, p, xs, ray);
+    xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f0 = 32 * jb + ncw_feat_of(r, 0);
+        if (f0 >= 39) continue;  // (block 1 holds features 32..38 only)
+        int comp;
+        const float dv = freq_feature_deriv<3, 6, false>(xs, f0 + 4 * h, comp);  // sinf / cosf like the value chain's gamma
+        const float c = gg[r] * dv;
+        nx += comp == 0 ? c : 0.f;
+        ny += comp == 1 ? c : 0.f;
+        nz += comp == 2 ? c : 0.f;
+    }
+    nx = half_pair_sum(nx); ny = half_pair_sum(ny); nz = half_pair_sum(nz);
+    // combine the two blocks of a tile (waves 2 jt and 2 jt + 1) through LDS (the gamma region is free now)
+    typedef __attribute__((address_space(3))) float lfloat;
+    lfloat* part = (lfloat*)gbuf;
+    if (jb == 1 && lane < 32) {
+        part[(jt * 32 + lane) * 3 + 0] = nx; part[(jt * 32 + lane) * 3 + 1] = ny; part[(jt * 32 + lane) * 3 + 2] = nz;
+    }
+    ncw_lds_barrier();
+    if (jb == 0 && lane < 32 && valid) {
+        grad[p * 3 + 0] = nx + part[(jt * 32 + lane) * 3 + 0];
+        grad[p * 3 + 1] = ny + part[(jt * 32 + lane) * 3 + 1];
+        grad[p * 3 + 2] = nz + part[(jt * 32 + lane) * 3 + 2];
+    }
+}
+
 }  // namespace
 
 // Measured per 131,072 points on MI355X (scripts/diag/split_check.py; plain fp16 kernels: 0.160 / 0.558 ms):
@@ -616,10 +784,16 @@ int ncw_sdf_fwdS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t 
                             const NcwSdfStash& stash, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
     const dim3 grid((unsigned)((tiles + SS_TILES - 1) / SS_TILES));
-    if (stash.t[0] == nullptr)  // forward-only render (include/neuconw_hip.h, NcwSdfStash)
-        hipLaunchKernelGGL(sdf_fwdS_kernel<false>, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
-    else
-        hipLaunchKernelGGL(sdf_fwdS_kernel<true>, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
+    bool adj = net->n_layers >= 3;  // the adjoint sweep with hi + lo weights: every transposed residual must be there
+    for (int l = 0; l < net->n_layers; ++l) adj = adj && net->wt_lo[l] != nullptr;
+    const bool render = stash.t[0] == nullptr;  // forward-only render (include/neuconw_hip.h, NcwSdfStash)
+    if (adj) {
+        if (render) hipLaunchKernelGGL(sdf_fwdSA_kernel<false>, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
+        else hipLaunchKernelGGL(sdf_fwdSA_kernel<true>, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
+    } else {
+        if (render) hipLaunchKernelGGL(sdf_fwdS_kernel<false>, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
+        else hipLaunchKernelGGL(sdf_fwdS_kernel<true>, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
+    }
     NCW_CHECK_LAUNCH();
     return 0;
 }

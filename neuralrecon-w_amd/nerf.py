@@ -151,6 +151,13 @@ class NeRF(_PackedNet):
             L.check(L.get_lib().ncw_bg_select(pts.rays_o, pts.rays_d, L.ptr(z_prim), pts.sample_dist, n // (S_ + O_), S_, O_,
                                               L.ptr(ent["sel_idx"]), L.ptr(ent["sel_offs"]), L.ptr(sel_count),
                                               L.stream_ptr(dev)), "ncw_bg_select")
+            if train:  # the weight-gradient launch plans its split-K with the observed share (no synchronisation: stash.SelectionProbe)
+                from .stash import SelectionProbe
+
+                probe = self.__dict__.setdefault("_sel_probe", SelectionProbe())
+                probe.observe(sel_count, n)
+                # before anything has been observed: the outside samples + ~5 % of the primary ones
+                ent["sel_plan"] = probe.bucket((O_ + 0.05 * S_) / float(S_ + O_))
             keep_src = pts
             pts = points_struct(mode=4, idx=ent["sel_idx"], count=sel_count)
             pts.rays_o, pts.rays_d, pts.z, pts.sample_dist = keep_src.rays_o, keep_src.rays_d, keep_src.z, keep_src.sample_dist

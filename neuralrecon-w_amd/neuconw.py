@@ -178,7 +178,7 @@ class SDFNetwork(nn.Module):
     def plan(self, prec):
         dev = self.lin0.bias.device
         split = self.split_value(prec)
-        key = (prec, str(dev), split)
+        key = (prec, str(dev), split, self.__dict__.get("adj_split"))
         p = self._plans.get(key)
         if p is not None:
             return p
@@ -187,7 +187,13 @@ class SDFNetwork(nn.Module):
         skip = self.skip_in[0] if self.skip_in else -1
         plan = PackPlan(dev, prec)
         net = L.NcwSdfNet()
-        slots, lo = {}, {}
+        slots, lo, lo_t = {}, {}, {}
+        # the adjoint sweep's transposed residuals (NcwSdfNet.wt_lo): W = 256 only (csrc/ncw_split.hip sdf_fwdS); NEUCONW_SDF_ADJ_SPLIT=0
+        # / .adj_split = False = single-rounded weights in the adjoint sweep (round 4's kernels)
+        adj = self.__dict__.get("adj_split")
+        if adj is None:
+            adj = os.environ.get("NEUCONW_SDF_ADJ_SPLIT", "1") not in ("0", "")
+        adj = bool(adj) and split and RB == 8
         for l in range(Lm):
             v, g, b = _wvb(getattr(self, "lin%d" % l))
             n_out, n_in = v.shape
@@ -208,6 +214,9 @@ class SDFNetwork(nn.Module):
                 if split:
                     lo[l] = plan.new_matrix(RB, rb_in)
                     plan.add_pack(v, g, None, lo[l], None, segs, scale=scale, residual=True)
+                if adj:
+                    lo_t[l] = plan.new_matrix(rb_in, RB)
+                    plan.add_pack(v, g, None, lo_t[l], None, segs, transpose=True, scale=scale, residual=True)
             else:  # last Linear: row 0 = sdf, rows 1..W = feature vector (neuconw.py:279)
                 m, bs = plan.new_matrix(1, RB), plan.new_bias(1)
                 mt = plan.new_matrix(RB, 1)
@@ -225,9 +234,14 @@ class SDFNetwork(nn.Module):
                 if split:
                     lo[l] = plan.new_matrix(1, RB)
                     plan.add_pack(v, g, None, lo[l], None, segs, row0=0, nrows=1, residual=True)
+                if adj:
+                    lo_t[l] = plan.new_matrix(RB, 1)
+                    plan.add_pack(v, g, None, lo_t[l], None, segs, row0=0, nrows=1, transpose=True, residual=True)
         plan.finalize()
         for l, m_lo in lo.items():
             net.w_lo[l] = plan.mat_ptr(m_lo)
+        for l, m_lo in lo_t.items():
+            net.wt_lo[l] = plan.mat_ptr(m_lo)
         for l in range(Lm):
             s = slots[l]
             net.w[l], net.b[l], net.wt[l] = plan.mat_ptr(s[0]), plan.bias_ptr(s[1]), plan.mat_ptr(s[2])

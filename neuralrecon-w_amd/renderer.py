@@ -175,8 +175,11 @@ class _RenderFn(torch.autograd.Function):
         # every weight-gradient product of the step (SDF, colour, background NeRF) in ONE launch; the product
         # list only depends on the (cached) stash arenas: build it once per lease combination
         sel = nctx.get("sel_count") if ctx.use_bg else None
+        # the selection's expected share of the background samples (observed a step or two ago, stash.SelectionProbe): the
+        # product table is re-planned when it leaves its bucket
+        sel_frac, sel_bucket = nctx["lease"].get("sel_plan", (None, None)) if sel is not None else (None, None)
         tag = (cctx["arena"].buf.data_ptr(), nctx["arena"].buf.data_ptr() if ctx.use_bg else None, prec,
-               None if sel is None else sel.data_ptr())
+               None if sel is None else sel.data_ptr(), sel_bucket)
         batch = sctx["lease"].get("wgrad_batch")
         if batch is None or batch.tag != tag:
             batch = WgradBatch(dev, prec, R * S)
@@ -184,7 +187,7 @@ class _RenderFn(torch.autograd.Function):
             neuconw.sdf_net.add_wgrads(sctx, batch)
             neuconw.color_net.add_wgrads(cctx, batch)
             if ctx.use_bg:
-                b_bg = WgradBatch(dev, prec, R * (comp.S + comp.O), n_dev=nctx.get("sel_count"))
+                b_bg = WgradBatch(dev, prec, R * (comp.S + comp.O), n_dev=nctx.get("sel_count"), sel_fraction=sel_frac)
                 nerf.add_wgrads(nctx, b_bg)
                 batch.extend(b_bg)
             sctx["lease"]["wgrad_batch"] = batch

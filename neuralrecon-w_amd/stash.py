@@ -66,18 +66,22 @@ class WgradBatch:
     TARGET_WGS = int(os.environ.get("NCW_WGRAD_TARGET_WGS", "768"))  # (env: tuning hook of scripts/diag/wgrad_rounds.sh)
     SEL_FRACTION = 0.125
 
-    def __init__(self, device, prec, n_points, n_dev=None):
+    def __init__(self, device, prec, n_points, n_dev=None, sel_fraction=None):
         """n_dev: device int32[1] -- the products cover only the first min(n_points, n_dev[0]) points of their stashes (a
-        selection made on the device, NcwPoints mode 4; 16-bit tiled launch only)."""
+        selection made on the device, NcwPoints mode 4; 16-bit tiled launch only).  sel_fraction: the fraction of n_points the
+        selection is EXPECTED to hold (the split-K plan balances the launch with it; the kernel clamps to the real count):
+        the renderer passes what it last observed (renderer.SelectionProbe), SEL_FRACTION otherwise."""
         self.device = torch.device(device)
         self.prec = prec
         self.n = int(n_points)
         self.n_dev = 0 if n_dev is None else int(n_dev.data_ptr())
         self._keep_dev = n_dev
+        self.sel_fraction = float(self.SEL_FRACTION if sel_fraction is None else sel_fraction)
         self.items = []
 
     def add(self, x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr=0, n=None):
-        self.items.append((x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr, self.n if n is None else int(n), self.n_dev))
+        self.items.append((x_ptr, rbx, y_ptr, rby, dense_ptr, ld, dbias_ptr, self.n if n is None else int(n), self.n_dev,
+                           self.sel_fraction if self.n_dev else 1.0))
 
     def extend(self, other):
         """Take over another batch's products (they keep their own point count)."""
@@ -98,7 +102,7 @@ class WgradBatch:
         if hit is None:
             xb, yb = (4, 4) if tile is None else ((4, 8) if tile == 0 else (8, 8))
             descs, prefix = [], [0]
-            for (x, rbx, y, rby, dense, ld, db, ni, ndev), ksp in zip(items, ksplits):
+            for (x, rbx, y, rby, dense, ld, db, ni, ndev, _frac), ksp in zip(items, ksplits):
                 d = L.NcwWgradDesc()
                 d.x, d.y, d.dense, d.dbias = x, y, dense, db
                 d.rbx, d.rby, d.ld = rbx, rby, ld
@@ -127,10 +131,12 @@ class WgradBatch:
                 # a quad costs the same whatever its real block count (missing blocks are re-reads of a
                 # valid one, L2 hits): weighting by HBM bytes instead measured 1.55 ms vs 1.02 ms per step
                 tiles = (it[7] + 31) // 32
-                # a product sized on the device (dead-background elimination) is planned at SEL_FRACTION of its stash:
-                # the split only balances the launch, the kernel clamps to the real count (95 % of the primary samples
-                # of the bench batch are inside the sphere: 7 % of the S + O samples remain)
-                return max(1, int(tiles * self.SEL_FRACTION)) if it[8] else tiles
+                # a product sized on the device (dead-background elimination) is planned at the selection's EXPECTED share of
+                # its stash (it[9]: observed by the renderer, stash.SelectionProbe): the split only balances the launch, the
+                # kernel clamps to the real count.  (Round 5: a fixed 12.5 % under-planned the shipped 8 + 16 shape -- 18 % of
+                # its samples are selected -- whose 17 single-workgroup background products then ran 1.5x longer than the rest:
+                # weight-gradient launch 0.87 ms dense, 1.09 ms with the elimination; NOTEBOOK R5.4.)
+                return max(1, int(tiles * it[9] + 0.999)) if it[8] else tiles
             total = sum(cost(it) * quads(it) for it in items)
             per_wg = max(1.0, total / self.TARGET_WGS)
             ksplits = []
@@ -215,3 +221,37 @@ class LeaseGuard:
             self.release()
         except Exception:
             pass
+
+
+class SelectionProbe:
+    """How many samples the dead-background elimination keeps (device int32[1], renderer / nerf.fwd_stash), observed WITHOUT a
+    device->host synchronisation: every forward copies the count into one of two pinned words (non-blocking) behind an event;
+    a later forward harvests whichever copy has completed.  `fraction` (count / n) is therefore a step or two old -- it only
+    steers the split-K plan of the weight-gradient launch, which clamps to the real count on the device."""
+
+    def __init__(self):
+        self.bufs = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.evs, self.ns, self.i, self.fraction = [None, None], [0, 0], 0, None
+
+    def observe(self, count_dev, n_points):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        for j in (0, 1):
+            if self.evs[j] is not None and self.evs[j].query():
+                self.fraction = float(self.bufs[j][0]) / max(1, self.ns[j])
+                self.evs[j] = None
+        i = self.i
+        if self.evs[i] is None:
+            self.bufs[i].copy_(count_dev, non_blocking=True)
+            self.evs[i] = torch.cuda.Event()
+            self.evs[i].record()
+            self.ns[i] = int(n_points)
+            self.i ^= 1
+
+    def bucket(self, default):
+        """(fraction to plan with, its bucket): re-planning happens when the observed share leaves a +-12 % bucket."""
+        import math
+
+        f = default if self.fraction is None else min(1.0, max(self.fraction, 1e-3))
+        b = round(math.log(f) / math.log(1.25))
+        return 1.25 ** b, b

@@ -42,13 +42,17 @@ def split(x, dt=H):
     return hi + rnd(x - hi, dt)
 
 
-MODE = {"nin": None, "nda": None, "nw": None, "nact": None, "tail": None, "cin": None, "clay": None, "cw": None, "cin_f": None, "cin_da": None, "cin_p": None}   # None = exact; rnd / split
+MODE = {"tail_feat": None, "tail_adj": None, "adj_t": None, "adj_w": None, "adj_s": None, "nin": None, "nda": None, "nw": None, "nact": None, "tail": None, "cin": None, "clay": None, "cw": None, "cin_f": None, "cin_da": None, "cin_p": None}   # None = exact; rnd / split
 
 
 def q(x, key):
     f = MODE[key]
     if key.startswith("cin_") and f is None:
         f = MODE["cin"]
+    if key.startswith("tail_") and f is None:
+        f = MODE["tail"]
+    if key in ("adj_t", "adj_w") and f is None:
+        f = MODE["tail_adj"] if MODE["tail_adj"] is not None else MODE["tail"]
     return x if f is None else f(x)
 
 
@@ -63,7 +67,7 @@ def sdf_net_e(sd, x, prefix="sdf_net.", skip_in=(4,), multires=6, scale=1.0, wit
         if l in skip_in:
             h = torch.cat([h, gamma], 1) / math.sqrt(2.0)
         if l == L - 1:  # sdf row exact (split path), feature rows in the tail precision
-            z = torch.cat([F.linear(h, W[:1], b[:1]), F.linear(q(h, "tail"), q(W[1:], "tail"), b[1:])], 1)
+            z = torch.cat([F.linear(h, W[:1], b[:1]), F.linear(q(h, "tail_feat"), q(W[1:], "tail_feat"), b[1:])], 1)
         else:
             z = F.linear(h, W, b)
         zs.append(z)
@@ -79,15 +83,18 @@ def sdf_net_e(sd, x, prefix="sdf_net.", skip_in=(4,), multires=6, scale=1.0, wit
     t[:, 0] = 1.0
     for l in range(L - 1, -1, -1):
         if l < L - 1:
-            t = t * O.softplus100_d1(zs[l])
-        qq = q(t, "tail") @ q(Ws[l], "tail")
+            if MODE["adj_s"] is not None:  # phi'(z) recomputed from the STASHED (rounded) post-activation: 1 - exp(-100 h16(h))
+                t = t * (1.0 - torch.exp(-100.0 * MODE["adj_s"](O.softplus100(zs[l]))))
+            else:
+                t = t * O.softplus100_d1(zs[l])
+        qq = q(t, "adj_t") @ q(Ws[l], "adj_w")
         if l in skip_in:
             qq = qq / math.sqrt(2.0)
             g_gamma = g_gamma + qq[:, -n_gamma:]
             qq = qq[:, :-n_gamma]
         t = qq
     g_gamma = g_gamma + t
-    grad = O.freq_encode_jacobian_t_times(xs, multires, q(g_gamma, "tail"))
+    grad = O.freq_encode_jacobian_t_times(xs, multires, q(g_gamma, "tail_adj"))
     return sdf, feat, grad
 
 

@@ -1,0 +1,132 @@
+"""CPU (build container): the fp16 mode's colour error on the TIMED batch at the trained-weights parity point of bench.py
+(`parity.trained_40_steps_inv_s_403`: 40 fp32 TrainSteps on the first 256 rays of the timed batch, variance 0.6), from the
+state_dict the GPU run saved (`bench.py --save-trained-state`).  Two questions:
+  (1) which fp16 rounding puts single rays above 1e-4 -- the kernels' roundings are injected into the fp64 oracle one
+      candidate fix at a time (scripts/diag/emul_color16.py's emulation), per-ray distribution over the 256 rays;
+  (2) how far the UNMODIFIED reference in fp32 is from the fp64 oracle on exactly these weights and rays (the "—" of DESIGN 4),
+      when /root/reference is importable.
+
+    python scripts/diag/emul_timed_batch.py gpurun_out/r05a/trained_state_bench.pt [--rays 256] [--no-reference]
+"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+state_path = sys.argv[1]
+n_rays = int(sys.argv[sys.argv.index("--rays") + 1]) if "--rays" in sys.argv else 256
+with_ref = "--no-reference" not in sys.argv and "--only-new" not in sys.argv
+argv_keep = list(sys.argv)
+sys.argv = [sys.argv[0], "--steps", "0"]
+src = open(os.path.join(ROOT, "scripts", "diag", "emul_color16.py")).read().split("emb, neuconw, nerf, _ = build_system")[0]
+ns = {"__file__": os.path.join(ROOT, "scripts", "diag", "emul_color16.py"), "__name__": "defs"}
+exec(compile(src, "defs", "exec"), ns)
+O, rnd, split, MODE = ns["O"], ns["rnd"], ns["split"], ns["MODE"]
+sys.argv = [argv_keep[0]]
+import bench  # noqa: E402
+
+torch.set_num_threads(8)
+sd0, cfg, (rays, ts, label, rgbs) = bench._oracle_setup(n_rays, 1000)
+state = torch.load(state_path, map_location="cpu")
+sd = {k: (v.double() if v.is_floating_point() else v) for k, v in state.items()}
+print("variance in the saved state: %.3f (inv_s %.0f)" % (float(sd["neuconw.deviation_network.variance"]),
+                                                          float(torch.exp(10 * sd["neuconw.deviation_network.variance"]))))
+
+
+def run(modes):
+    for k in MODE:
+        MODE[k] = modes.get(k)
+    keep = O.sdf_net, O.color_net, O.nerf_net
+    if modes:
+        O.sdf_net, O.color_net, O.nerf_net = ns["sdf_net_e"], ns["color_net_e"], ns["nerf_net_e"]
+    try:
+        with torch.no_grad():
+            return O.render(sd, cfg, rays.double(), ts, label, 0.5, torch.zeros(1, 3, dtype=torch.float64))
+    finally:
+        O.sdf_net, O.color_net, O.nerf_net = keep
+
+
+ref = run({})
+scale = float(ref["color"].abs().max())
+
+
+def per_ray(c):
+    return (c["color"] - ref["color"]).abs().amax(-1) / scale
+
+
+ident = lambda x: x  # noqa: E731
+base = {"tail": rnd, "cin": rnd, "cw": split, "clay": rnd, "cin_da": ident, "nw": rnd, "nact": rnd, "nin": rnd, "nda": ident}
+cases_all = [("the round-4 kernels (colour weights hi+lo, per-ray head columns fp32)", base),
+         ("+ nerf weights hi+lo", dict(base, nw=split)),
+         ("+ nerf gamma(p) hi+lo", dict(base, nin=split)),
+         ("+ nerf weights + gamma(p) hi+lo", dict(base, nw=split, nin=split)),
+         ("+ nerf everything hi+lo (weights, gamma(p), activations)", dict(base, nw=split, nin=split, nact=split)),
+         ("+ colour inputs (feat, points, normals) hi+lo", dict(base, cin=split)),
+         ("+ colour activations hi+lo", dict(base, clay=split)),
+         ("+ colour inputs + activations hi+lo (whole colour net split)", dict(base, cin=split, clay=split)),
+         ("+ SDF tail (feature rows + adjoint sweep) hi+lo", dict(base, tail=split)),
+         ("+ feature rows only hi+lo (tail_feat)", dict(base, tail=None, tail_feat=split, tail_adj=rnd)),
+         ("+ adjoint sweep only hi+lo (tail_adj: normals)", dict(base, tail=None, tail_feat=rnd, tail_adj=split)),
+         ("+ adjoint hi+lo, phi' from the fp16 stash of h (the kernel's form)", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_s=rnd)),
+         ("+ adjoint: t hi+lo, W^T single (2 MFMAs), phi' from fp16 h", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_w=rnd, adj_s=rnd)),
+         ("+ adjoint: W^T hi+lo, t single (2 MFMAs), phi' from fp16 h", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_t=rnd, adj_s=rnd)),
+         ("+ kernel-form adjoint + nerf weights hi+lo", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_s=rnd, nw=split)),
+         ("+ kernel-form adjoint + nerf weights + gamma(p) hi+lo", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_s=rnd, nw=split, nin=split)),
+         ("+ kernel-form adjoint + nerf all hi+lo", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_s=rnd, nw=split, nin=split, nact=split)),
+         ("+ kernel-form adjoint + nerf all + colour inputs hi+lo", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_s=rnd, nw=split, nin=split, nact=split, cin=split)),
+         ("+ tail + nerf weights hi+lo", dict(base, tail=split, nw=split)),
+         ("+ tail + nerf gamma(p) hi+lo", dict(base, tail=split, nin=split)),
+         ("+ tail + nerf activations hi+lo", dict(base, tail=split, nact=split)),
+         ("+ tail + nerf weights + gamma(p) hi+lo", dict(base, tail=split, nw=split, nin=split)),
+         ("+ tail + colour inputs hi+lo", dict(base, tail=split, cin=split)),
+         ("+ tail + whole colour net hi+lo", dict(base, tail=split, cin=split, clay=split)),
+         ("+ tail + colour net + nerf hi+lo (everything)", dict(base, tail=split, cin=split, clay=split, nw=split, nin=split, nact=split))]
+cases = [c for c in cases_all if ("--only-new" not in argv_keep) or ("kernel" in c[0] or "adjoint:" in c[0] or "round-4" in c[0])]
+res = {}
+worst_rays = None
+for name, m in cases:
+    out = run(m)
+    pr = per_ray(out)
+    if worst_rays is None:
+        worst_rays = torch.topk(pr, 6).indices.tolist()
+        print("worst rays of the current kernels:", [(i, "%.2e" % float(pr[i])) for i in worst_rays])
+        inside = out["inside_sphere"].double().mean(-1)
+        print("  their weights_sum:", ["%.3f" % float(out["weights_sum"].reshape(-1)[i]) for i in worst_rays],
+              " colour_bg share:", ["%.3f" % float(out["color_bg"][i].abs().max()) for i in worst_rays])
+    res[name] = {"max": float(pr.max()), "p99": float(torch.quantile(pr, 0.99)), "rays_above_1e-4": int((pr > 1e-4).sum()),
+                 "depth": float((out["depth"] - ref["depth"]).abs().max() / ref["depth"].abs().max())}
+    print("%-66s max %.2e  p99 %.2e  rays > 1e-4: %d / %d   at the worst rays: %s" % (
+        name, res[name]["max"], res[name]["p99"], res[name]["rays_above_1e-4"], n_rays,
+        " ".join("%.1e" % float(pr[i]) for i in worst_rays[:4])), flush=True)
+
+ref32 = None
+if with_ref and os.path.isdir("/root/reference"):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from oracle import ref_import  # noqa: E402
+    import make_golden as G  # noqa: E402
+
+    rns = ref_import.load()
+    emb, neuconw, nerf, rdr = G.build_reference(rns, bench.W_SDF, 8, (4,), n_a=bench.N_A, n_vocab=state["embedding_a.weight"].shape[0], nerf_w=256,
+                                                color_hidden=256, head=128, seed=0, n_samples=bench.N_SAMPLES, n_importance=bench.N_IMPORTANCE)
+    with torch.no_grad():
+        emb.weight.copy_(state["embedding_a.weight"])
+        neuconw.load_state_dict({k[len("neuconw."):]: v for k, v in state.items() if k.startswith("neuconw.")}, strict=False)
+        nerf.load_state_dict({k[len("nerf."):]: v for k, v in state.items() if k.startswith("nerf.")})
+    # (grad mode on: the reference's SDFNetwork.gradient is an autograd.grad call)
+    o32 = rdr.render(rays, ts, label, perturb_overwrite=0, background_rgb=torch.zeros(1, 3), cos_anneal_ratio=0.5)
+    o32 = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in o32.items()}
+    pr = (o32["color"].double() - ref["color"]).abs().amax(-1) / scale
+    rel = lambda a, b: float((a.double().reshape(-1) - b.reshape(-1)).abs().max() / b.abs().max())  # noqa: E731
+    ref32 = {"colour": rel(o32["color"], ref["color"]), "depth": rel(o32["depth"], ref["depth"]),
+             "weights_sum": rel(o32["weights_sum"], ref["weights_sum"]), "weights": rel(o32["weights"], ref["weights"]),
+             "colour_p99": float(torch.quantile(pr, 0.99)), "rays_above_1e-4": int((pr > 1e-4).sum())}
+    print("the UNMODIFIED reference in fp32 vs the fp64 oracle on these weights / rays:", {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in ref32.items()})
+out_path = os.path.join(ROOT, "profiles", "r05", "emul_timed_batch%s.json" % ("_kernel_form" if "--only-new" in argv_keep else ""))
+os.makedirs(os.path.dirname(out_path), exist_ok=True)
+with open(out_path, "w") as fh:
+    json.dump({"state": os.path.relpath(os.path.abspath(state_path), ROOT), "rays": n_rays, "emulated_fp16_candidates": res,
+               "reference_fp32_vs_fp64_oracle_trained_40_steps": ref32}, fh, indent=1)
+print("wrote", out_path)

@@ -29,7 +29,7 @@ def perturb_weights(neuconw, g_jit=0.1, v_jit=0.0, seed=11):
 
 
 FLIP_ROW_TOL = 0.15      # fp16: measured 8.3e-2 (GPU and CPU emulation agree to three digits), see embedding_grad_err
-FLIP_ROW_TOL_BF16 = 0.6  # bf16: 8x the rounding step of fp16, several flips per row; bounded, not skipped (measured: see test log)
+FLIP_ROW_TOL_BF16 = 0.16  # bf16: bounded, not skipped -- measured 5.0e-2 .. 7.7e-2 on MI355X (gpurun_out/r05a/new_tests.log): 2x
 # Weight-gradient tensors of the ReLU networks (colour network, background NeRF) in the 16-bit modes of a 16-ray composed step: a
 # pre-activation within ~1e-4 of zero flips its mask under SOME combinations of fp16 roundings and not under others, and one
 # flipped background sample moves a bias / weight gradient by up to ~1e-2 of the network's largest gradient.  Measured on the CPU

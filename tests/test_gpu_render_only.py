@@ -50,7 +50,7 @@ def test_no_grad_render_is_bitwise_the_training_forward(W, prec_name, ns, ni, bg
     k_fwd = next(k for k in sizes if k[-1] is False)
     tiles = ((R * S + 31) // 32 + 23) // 24 * 24
     assert sizes[k_fwd] == 9 * (W // 32) * tiles * 1024 * esz          # 8 hidden activations + feat
-    assert sizes[k_train] > 4 * sizes[k_fwd]
+    assert sizes[k_train] > 3.5 * sizes[k_fwd]                           # (34 W / 32 + 6 blocks per tile against 9 W / 32)
     for mod in (neuconw.color_net, nerf):
         sz = _arena_bytes(mod)
         assert max(v for k, v in sz.items() if k[-1] is False) <= 256, sz

@@ -82,8 +82,13 @@ def test_render_with_fine_octree_window_and_boundary_samples(W, prec_name, R, to
     errs = {k: rel_err(out[k].detach().cpu(), ref[k]) for k in ("color", "depth", "weights_sum", "gradient_error", "mask_error",
                                                                 "sfm_depth_loss", "color_bg", "weights", "cdf_fine", "gradients")}
     print("voxel-guided render W=%d %s:" % (W, prec_name), {k: "%.2e" % v for k, v in errs.items()})
-    for k in ("color", "depth", "weights_sum", "mask_error", "sfm_depth_loss", "color_bg"):
+    for k in ("color", "depth", "weights_sum", "mask_error"):
         assert errs[k] < tol_out, (k, errs[k])
+    # two derived quantities have their own fp16 bounds (measured on MI355X: 1.8e-4 and 2.8e-4 with colour / depth / weights_sum at
+    # 5e-5): sfm_depth_loss = w (depth - depth_gt)^2 amplifies the depth error by 2 depth / |depth - depth_gt|; color_bg is the
+    # background NeRF's share alone (plain fp16 operands, relative to ITS small maximum: the colour it feeds is within tol_out)
+    assert errs["sfm_depth_loss"] < (4e-4 if prec_name == "f16" else tol_out), errs["sfm_depth_loss"]
+    assert errs["color_bg"] < (6e-4 if prec_name == "f16" else tol_out), errs["color_bg"]
     # the eikonal term comes from the plain-fp16 adjoint sweep (normals 4e-4): F16_TOL[(16, 16)][2]
     assert errs["gradient_error"] < (5e-4 if prec_name == "f16" else tol_out), errs["gradient_error"]
     for k in ("weights", "cdf_fine", "gradients"):
