@@ -362,6 +362,13 @@ int NCW_FN(ncw_sdf_inferC_launch)(const NcwSdfNet* net, const NcwPoints& src, in
     if (epi == 1) hipLaunchKernelGGL((sdf_inferC_kernel<1, 1>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
     else if (epi == 2) hipLaunchKernelGGL((sdf_inferC_kernel<1, 2>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
     else hipLaunchKernelGGL((sdf_inferC_kernel<1, 0>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
+#elif defined(NCW_PROBE_BUILD)
+    // round-5 A/B (scripts/diag/pp_nb2.py, probe library only): NCW_PP_NB = 2 -> four 512-register waves, two output blocks each
+    // (every B fragment feeds two MFMAs: half the LDS reads); with `-mllvm -amdgpu-mfma-vgpr-form` on this file the accumulators
+    // stay in VGPRs and the weight slices go to AGPRs (MFMA srcA)
+    static const int nb = getenv("NCW_PP_NB") ? atoi(getenv("NCW_PP_NB")) : 1;
+    if (nb == 2) hipLaunchKernelGGL((sdf_inferC_kernel<2, 0>), grid, dim3(64 * PP_WAVES / 2), 0, st, *net, src, n, sdf);
+    else hipLaunchKernelGGL((sdf_inferC_kernel<1, 0>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
 #else
     hipLaunchKernelGGL((sdf_inferC_kernel<1, 0>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
 #endif

@@ -154,10 +154,14 @@ class NeRF(_PackedNet):
             if train:  # the weight-gradient launch plans its split-K with the observed share (no synchronisation: stash.SelectionProbe)
                 from .stash import SelectionProbe
 
-                probe = self.__dict__.setdefault("_sel_probe", SelectionProbe())
-                probe.observe(sel_count, n)
+                probe = self.__dict__.get("_sel_probe")
+                if probe is None and not torch.cuda.is_current_stream_capturing():  # (pinned words: not allocatable under capture)
+                    probe = self._sel_probe = SelectionProbe()
+                if probe is not None:
+                    probe.observe(sel_count, n)
                 # before anything has been observed: the outside samples + ~5 % of the primary ones
-                ent["sel_plan"] = probe.bucket((O_ + 0.05 * S_) / float(S_ + O_))
+                default = (O_ + 0.05 * S_) / float(S_ + O_)
+                ent["sel_plan"] = probe.bucket(default) if probe is not None else ent.get("sel_plan", (default, None))
             keep_src = pts
             pts = points_struct(mode=4, idx=ent["sel_idx"], count=sel_count)
             pts.rays_o, pts.rays_d, pts.z, pts.sample_dist = keep_src.rays_o, keep_src.rays_d, keep_src.z, keep_src.sample_dist

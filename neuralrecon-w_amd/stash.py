@@ -229,6 +229,8 @@ class SelectionProbe:
     a later forward harvests whichever copy has completed.  `fraction` (count / n) is therefore a step or two old -- it only
     steers the split-K plan of the weight-gradient launch, which clamps to the real count on the device."""
 
+    OVERPLAN = float(os.environ.get("NCW_SEL_OVERPLAN", "1.6"))
+
     def __init__(self):
         self.bufs = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
         self.evs, self.ns, self.i, self.fraction = [None, None], [0, 0], 0, None
@@ -253,5 +255,10 @@ class SelectionProbe:
         import math
 
         f = default if self.fraction is None else min(1.0, max(self.fraction, 1e-3))
+        # planned share = OVERPLAN x observed: the background products are the LAST of the launch, and workgroups that turn out
+        # shorter than planned drain the tail faster than exactly balanced ones (measured at the headline shape, 7.5 % selected:
+        # planned at 7.5 % the launch takes 0.80 ms, at 12.5 % 0.69 ms; under-planning -- 12.5 % for the 18 % of the shipped
+        # shape -- costs 1.09 against 0.87 ms).  NCW_SEL_OVERPLAN: tuning hook of scripts/r05.
+        f = min(1.0, f * self.OVERPLAN)
         b = round(math.log(f) / math.log(1.25))
         return 1.25 ** b, b
