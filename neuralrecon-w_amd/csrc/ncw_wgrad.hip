@@ -378,7 +378,12 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const NcwWgradDesc* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (XB * qi + ib) * 32 + ncw_feat_of(r, lane >> 5);
+#if defined(NCW_PROBE_BUILD) && defined(NCW_EXP_WGRAD_STORE)
+                // TIMING PROBE ONLY (wrong results): what the split-K flush would cost as plain stores instead of f32 atomics
+                __builtin_nontemporal_store(acc[a][b][r], (float*)&D.dense[(size_t)row * D.ld + col]);
+#else
                 atomicAdd((float*)&D.dense[(size_t)row * D.ld + col], acc[a][b][r]);
+#endif
             }
         }
         if (do_bias) {
