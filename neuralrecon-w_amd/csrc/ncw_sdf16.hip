@@ -71,6 +71,31 @@ NCW_DEV void s16_mma(f32x16 (&acc)[2][T], S16W& r, const void* w, int rb_stride,
     }
 }
 
+// the same with the weights as hi + lo pairs (`w` / `wlo`: a packed matrix and its residual matrix, two register rings): every
+// B fragment read from LDS feeds FOUR MFMAs (NcwSdfNet.wt_lo: the adjoint sweep of the fp16 mode, ncw_split.hip sdf_fwdSA_kernel)
+template <int T, int NU>
+NCW_DEV void s16_mma_hl(f32x16 (&acc)[2][T], S16W& r, S16W& rl, const void* w, const void* wlo, int rb_stride, int wave,
+                        const s16_lfrag* in, int lane) {
+#pragma unroll
+    for (int q = 0; q < NU; ++q) {
+        const bf16x8 a0 = r.f[q % S16_D][0], a1 = r.f[q % S16_D][1], l0 = rl.f[q % S16_D][0], l1 = rl.f[q % S16_D][1];
+        if (q + S16_D < NU) {
+            r.f[q % S16_D][0] = s16_ld(w, rb_stride, wave, q + S16_D, lane);
+            r.f[q % S16_D][1] = s16_ld(w, rb_stride, wave + 8, q + S16_D, lane);
+            rl.f[q % S16_D][0] = s16_ld(wlo, rb_stride, wave, q + S16_D, lane);
+            rl.f[q % S16_D][1] = s16_ld(wlo, rb_stride, wave + 8, q + S16_D, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const bf16x8 b = in[(t * S16_KU + q) * 64 + lane];
+            acc[0][t] = NCW_MFMA_H(a0, b, acc[0][t], 0, 0, 0);
+            acc[1][t] = NCW_MFMA_H(a1, b, acc[1][t], 0, 0, 0);
+            acc[0][t] = NCW_MFMA_H(l0, b, acc[0][t], 0, 0, 0);
+            acc[1][t] = NCW_MFMA_H(l1, b, acc[1][t], 0, 0, 0);
+        }
+    }
+}
+
 // the 3 gamma k-units (32..34) of the forward-orientation skip layer against gbuf (units 0..2 of a tile)
 template <int T>
 NCW_DEV void s16_mma_gamma(f32x16 (&acc)[2][T], const void* w, int wave, const s16_lfrag* gbuf, int lane) {
@@ -214,7 +239,9 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_infer16_kernel(NcwSdfNet n
 // [tile][unit][hi | lo] buffer, whose hi fragments are read) and r holds the first units of w_feat; abuf is then reused in the
 // plain layout.  SDF_ROW = false: the caller's (split-precision) chain has written sdf already.
 // TRAIN = false: forward-only render -- t_l is not stashed (feat is: the colour network reads it).
-template <int T, int BS, bool SDF_ROW, bool TRAIN>
+// ADJ: the sweep's transposed weights as hi + lo pairs (net.wt_lo; round 5 -- the normals are multiplied by dist * inv_s inside the
+// compositor's sigmoid: ncw_split.hip sdf_fwdSA_kernel has the measurements).
+template <int T, int BS, bool SDF_ROW, bool TRAIN, bool ADJ = false>
 NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n, float* __restrict__ sdf, float* __restrict__ grad,
                           const NcwSdfStash& st, s16_lfrag* abuf, s16_lfrag* gbuf, S16W& r, f32x16 (&acc)[2][T], int lane, int wave,
                           int64_t tile0) {
@@ -222,6 +249,7 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
     const int L = net.n_layers;
     const int jb = wave & 1, jt = wave >> 1;
     const bool gjob = wave < 2 * T;
+    S16W rl;  // the residual matrices' register ring (ADJ)
     // ---- feature layer (r = first units of w_feat) and sdf row; then the adjoint's first vector ------------------
     {
         const bf16x8 wt1_0 = s16_ld(net.wt[L - 1], 16, wave, 0, lane), wt1_1 = s16_ld(net.wt[L - 1], 16, wave + 8, 0, lane);
@@ -230,6 +258,7 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
         s16_fill<T>(acc, b0, b1);
         s16_mma<T, S16_KU, BS>(acc, r, net.w_feat, 16, wave, abuf, lane);
         if (L - 2 >= 1) s16_prefetch(r, net.wt[L - 2], (L - 2 == net.skip_layer) ? 18 : 16, wave, lane);
+        if (ADJ && L - 2 >= 1) s16_prefetch(rl, net.wt_lo[L - 2], (L - 2 == net.skip_layer) ? 18 : 16, wave, lane);
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -246,7 +275,11 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
 #pragma unroll
         for (int e = 0; e < 8; ++e) e0f[e] = (ncw_h16)0.f;
         e0f[0] = (ncw_h16)(lane < 32 ? 1.f : 0.f);
-        const f32x16 a0 = NCW_MFMA_H(wt1_0, e0f, s16_zero(), 0, 0, 0), a1 = NCW_MFMA_H(wt1_1, e0f, s16_zero(), 0, 0, 0);
+        f32x16 a0 = NCW_MFMA_H(wt1_0, e0f, s16_zero(), 0, 0, 0), a1 = NCW_MFMA_H(wt1_1, e0f, s16_zero(), 0, 0, 0);
+        if (ADJ) {
+            a0 = NCW_MFMA_H(s16_ld(net.wt_lo[L - 1], 16, wave, 0, lane), e0f, a0, 0, 0, 0);
+            a1 = NCW_MFMA_H(s16_ld(net.wt_lo[L - 1], 16, wave + 8, 0, lane), e0f, a1, 0, 0, 0);
+        }
         ncw_lds_barrier();  // the feature layer and the sdf row have read h_{L-1}: overwrite abuf with t_{L-2}
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -266,9 +299,14 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
         const bool skip = (l == net.skip_layer);
         ncw_lds_barrier();  // t_l complete in abuf
         s16_fill<T>(acc, s16_zero(), s16_zero());
-        s16_mma<T, S16_KU>(acc, r, net.wt[l], skip ? 18 : 16, wave, abuf, lane);
+        if (ADJ) s16_mma_hl<T, S16_KU>(acc, r, rl, net.wt[l], net.wt_lo[l], skip ? 18 : 16, wave, abuf, lane);
+        else s16_mma<T, S16_KU>(acc, r, net.wt[l], skip ? 18 : 16, wave, abuf, lane);
         if (l - 1 >= 1) s16_prefetch(r, net.wt[l - 1], (l - 1 == net.skip_layer) ? 18 : 16, wave, lane);
-        if (skip && gjob) s16_mma1<S16_KU>(gg, net.wt[l], 18, 16 + jb, abuf, jt, lane);  // gamma columns of the skip layer
+        if (ADJ && l - 1 >= 1) s16_prefetch(rl, net.wt_lo[l - 1], (l - 1 == net.skip_layer) ? 18 : 16, wave, lane);
+        if (skip && gjob) {  // gamma columns of the skip layer
+            s16_mma1<S16_KU>(gg, net.wt[l], 18, 16 + jb, abuf, jt, lane);
+            if (ADJ) s16_mma1<S16_KU>(gg, net.wt_lo[l], 18, 16 + jb, abuf, jt, lane);
+        }
         ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -288,6 +326,7 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
     const bool valid = gjob && p < n;
     if (gjob) {
         s16_mma1<S16_KU>(gg, net.wt[0], 2, jb, abuf, jt, lane);
+        if (ADJ) s16_mma1<S16_KU>(gg, net.wt_lo[0], 2, jb, abuf, jt, lane);
         if (p >= n) p = n - 1;
         float xs[3];
         load_point(src, p, xs, ray);
@@ -298,7 +337,7 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
             const int f0 = 32 * jb + ncw_feat_of(q, 0);
             if (f0 >= 39) continue;  // (block 1 holds features 32..38 only)
             int comp;
-            const float dv = freq_feature_deriv<3, 6, true>(xs, f0 + 4 * h, comp);
+            const float dv = freq_feature_deriv<3, 6, !ADJ>(xs, f0 + 4 * h, comp);  // (ADJ: sinf / cosf like the split value chain's gamma)
             const float c = gg[q] * dv;
             nx += comp == 0 ? c : 0.f;
             ny += comp == 1 ? c : 0.f;
@@ -725,7 +764,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_inferS16_kernel(NcwSdfNet 
     s16s_value_chain<0>(net, src, n, tile0, sbuf, gsbuf, lane, wave, sdf, none);
 }
 
-template <bool TRAIN>  // false: forward-only render (no gamma / t_l stash)
+template <bool TRAIN, bool ADJ>  // TRAIN false: forward-only render (no gamma / t_l stash); ADJ: adjoint sweep with hi + lo weights
 __global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwdS16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
                                                                    float* __restrict__ sdf, float* __restrict__ grad, NcwSdfStash st) {
     S16S_LDS_DECL();
@@ -734,7 +773,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwdS16_kernel(NcwSdfNet ne
     S16W r;
     f32x16 acc[2][S16S_T];
     s16_prefetch(r, net.w_feat, 16, wave, lane);
-    s16_fwd_tail<S16S_T, 2, false, TRAIN>(net, src, n, sdf, grad, st, sbuf, gsbuf, r, acc, lane, wave, tile0);
+    s16_fwd_tail<S16S_T, 2, false, TRAIN, ADJ>(net, src, n, sdf, grad, st, sbuf, gsbuf, r, acc, lane, wave, tile0);
 }
 #endif  // NCW_HALF_F16
 
@@ -801,12 +840,17 @@ int ncw_sdf_inferS16_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int6
 int ncw_sdf_fwdS16_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, float* grad,
                               const NcwSdfStash& stash, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
-    if (stash.t[0] == nullptr)  // forward-only render
-        hipLaunchKernelGGL(sdf_fwdS16_kernel<false>, dim3((unsigned)((tiles + S16S_T - 1) / S16S_T)), dim3(64 * S16_WAVES), 0, st, *net,
-                           src, n, sdf, grad, stash);
-    else
-        hipLaunchKernelGGL(sdf_fwdS16_kernel<true>, dim3((unsigned)((tiles + S16S_T - 1) / S16S_T)), dim3(64 * S16_WAVES), 0, st, *net,
-                           src, n, sdf, grad, stash);
+    bool adj = net->n_layers >= 3;  // every transposed residual present: the adjoint sweep takes hi + lo weights
+    for (int l = 0; l < net->n_layers; ++l) adj = adj && net->wt_lo[l] != nullptr;
+    const bool render = stash.t[0] == nullptr;  // forward-only render
+    const dim3 grid((unsigned)((tiles + S16S_T - 1) / S16S_T)), block(64 * S16_WAVES);
+    if (adj) {
+        if (render) hipLaunchKernelGGL((sdf_fwdS16_kernel<false, true>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
+        else hipLaunchKernelGGL((sdf_fwdS16_kernel<true, true>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
+    } else {
+        if (render) hipLaunchKernelGGL((sdf_fwdS16_kernel<false, false>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
+        else hipLaunchKernelGGL((sdf_fwdS16_kernel<true, false>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
+    }
     NCW_CHECK_LAUNCH();
     return 0;
 }

@@ -188,12 +188,12 @@ class SDFNetwork(nn.Module):
         plan = PackPlan(dev, prec)
         net = L.NcwSdfNet()
         slots, lo, lo_t = {}, {}, {}
-        # the adjoint sweep's transposed residuals (NcwSdfNet.wt_lo): W = 256 only (csrc/ncw_split.hip sdf_fwdS); NEUCONW_SDF_ADJ_SPLIT=0
+        # the adjoint sweep's transposed residuals (NcwSdfNet.wt_lo; csrc/ncw_split.hip sdf_fwdSA, ncw_sdf16.hip sdf_fwdS16<., true>); NEUCONW_SDF_ADJ_SPLIT=0
         # / .adj_split = False = single-rounded weights in the adjoint sweep (round 4's kernels)
         adj = self.__dict__.get("adj_split")
         if adj is None:
             adj = os.environ.get("NEUCONW_SDF_ADJ_SPLIT", "1") not in ("0", "")
-        adj = bool(adj) and split and RB == 8
+        adj = bool(adj) and split and RB in (8, 16)
         for l in range(Lm):
             v, g, b = _wvb(getattr(self, "lin%d" % l))
             n_out, n_in = v.shape
