@@ -190,9 +190,15 @@ class SDFNetwork(nn.Module):
         slots, lo, lo_t = {}, {}, {}
         # the adjoint sweep's transposed residuals (NcwSdfNet.wt_lo; csrc/ncw_split.hip sdf_fwdSA, ncw_sdf16.hip sdf_fwdS16<., true>); NEUCONW_SDF_ADJ_SPLIT=0
         # / .adj_split = False = single-rounded weights in the adjoint sweep (round 4's kernels)
+        # Default: ON at W = 256, OFF at W = 512 -- there (shipped 8 + 16 shape: 5x larger sample spacing, K = 512) the weight
+        # operand alone is not enough: with W^T as hi + lo and t_l single the timed batch's worst ray on trained weights goes 3.2e-4
+        # -> 6.2e-4 (GPU; emulated 6.1e-4), only BOTH operands as hi + lo pairs bring it to 1.0e-4 (profiles/r05/
+        # emul_timed_batch_shipped.log), at +0.32 ms for the weight operand alone (sdf_fwd 0.96 -> 1.28 ms).  `.adj_split = True`
+        # / NEUCONW_SDF_ADJ_SPLIT=1 force it on at either width.
         adj = self.__dict__.get("adj_split")
         if adj is None:
-            adj = os.environ.get("NEUCONW_SDF_ADJ_SPLIT", "1") not in ("0", "")
+            env = os.environ.get("NEUCONW_SDF_ADJ_SPLIT")
+            adj = (RB == 8) if env is None else (env not in ("0", ""))
         adj = bool(adj) and split and RB in (8, 16)
         for l in range(Lm):
             v, g, b = _wvb(getattr(self, "lin%d" % l))

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round profile set (run on the GPU box through gpurun): rocprofv3 kernel stats of the bench command, the
-# PMC passes (HBM traffic in separate passes, SQ counters) and the plain bench line.  Outputs: gpurun_out/r04/ (NCW_PROFILE_ROUND)
+# PMC passes (HBM traffic in separate passes, SQ counters) and the plain bench line.  Outputs: gpurun_out/r05/ (NCW_PROFILE_ROUND)
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$REPO/gpurun_out/${NCW_PROFILE_ROUND:-r04}; mkdir -p "$OUT"
+OUT=$REPO/gpurun_out/${NCW_PROFILE_ROUND:-r05}; mkdir -p "$OUT"
 TAG=${1:-v1}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_stats

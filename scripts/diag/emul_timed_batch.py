@@ -29,6 +29,8 @@ sys.argv = [argv_keep[0]]
 import bench  # noqa: E402
 
 torch.set_num_threads(8)
+if "--shipped" in argv_keep:  # bench.py --config shipped: SDF 8 x 512, 8 + 16 samples (config/train_brandenburg_gate.yaml)
+    bench.__dict__.update(W_SDF=512, N_SAMPLES=8, N_IMPORTANCE=16, M_SDF=2097664, M_SDF1=1835520, M_COL=585344)
 sd0, cfg, (rays, ts, label, rgbs) = bench._oracle_setup(n_rays, 1000)
 state = torch.load(state_path, map_location="cpu")
 sd = {k: (v.double() if v.is_floating_point() else v) for k, v in state.items()}
@@ -77,6 +79,9 @@ cases_all = [("the round-4 kernels (colour weights hi+lo, per-ray head columns f
          ("+ kernel-form adjoint + nerf weights + gamma(p) hi+lo", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_s=rnd, nw=split, nin=split)),
          ("+ kernel-form adjoint + nerf all hi+lo", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_s=rnd, nw=split, nin=split, nact=split)),
          ("+ kernel-form adjoint + nerf all + colour inputs hi+lo", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_s=rnd, nw=split, nin=split, nact=split, cin=split)),
+         ("+ adjoint W^T hi+lo, t single, phi' from fp16 h (= round 5's kernels)", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_t=rnd, adj_s=rnd)),
+         ("+ adjoint W^T hi+lo, t single, phi' EXACT", dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_t=rnd)),
+         ("+ adjoint W^T and t hi+lo, phi' EXACT", dict(base, tail=None, tail_feat=rnd, tail_adj=split)),
          ("+ tail + nerf weights hi+lo", dict(base, tail=split, nw=split)),
          ("+ tail + nerf gamma(p) hi+lo", dict(base, tail=split, nin=split)),
          ("+ tail + nerf activations hi+lo", dict(base, tail=split, nact=split)),
@@ -84,7 +89,7 @@ cases_all = [("the round-4 kernels (colour weights hi+lo, per-ray head columns f
          ("+ tail + colour inputs hi+lo", dict(base, tail=split, cin=split)),
          ("+ tail + whole colour net hi+lo", dict(base, tail=split, cin=split, clay=split)),
          ("+ tail + colour net + nerf hi+lo (everything)", dict(base, tail=split, cin=split, clay=split, nw=split, nin=split, nact=split))]
-cases = [c for c in cases_all if ("--only-new" not in argv_keep) or ("kernel" in c[0] or "adjoint:" in c[0] or "round-4" in c[0])]
+cases = [c for c in cases_all if ("--only-new" not in argv_keep) or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
 res = {}
 worst_rays = None
 for name, m in cases:
@@ -124,7 +129,8 @@ if with_ref and os.path.isdir("/root/reference"):
              "weights_sum": rel(o32["weights_sum"], ref["weights_sum"]), "weights": rel(o32["weights"], ref["weights"]),
              "colour_p99": float(torch.quantile(pr, 0.99)), "rays_above_1e-4": int((pr > 1e-4).sum())}
     print("the UNMODIFIED reference in fp32 vs the fp64 oracle on these weights / rays:", {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in ref32.items()})
-out_path = os.path.join(ROOT, "profiles", "r05", "emul_timed_batch%s.json" % ("_kernel_form" if "--only-new" in argv_keep else ""))
+out_path = os.path.join(ROOT, "profiles", "r05", "emul_timed_batch%s%s.json" % ("_shipped" if "--shipped" in argv_keep else "",
+                                                                              "_kernel_form" if "--only-new" in argv_keep else ""))
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 with open(out_path, "w") as fh:
     json.dump({"state": os.path.relpath(os.path.abspath(state_path), ROOT), "rays": n_rays, "emulated_fp16_candidates": res,
