@@ -74,9 +74,14 @@ def _hash_object():
     return obj, False
 
 
+# ncw_rays.hip is compiled a second time for rays of more than 512 samples (-DNCW_RAYS_BIG: 1088 samples per ray in LDS, entry
+# points suffixed _big; the standard object forwards to them) -- the reference's own defaults are 512 + 512 + 32 (config/defaults.py)
+BIG_FILES = ["ncw_rays.hip"]
+
+
 def _sources():
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    return [(f, False) for f in srcs] + [(f, True) for f in F16_FILES]
+    return [(f, False) for f in srcs] + [(f, True) for f in F16_FILES] + [(f, "big") for f in BIG_FILES]
 
 
 def _deps_mtime():
@@ -87,11 +92,11 @@ def _deps_mtime():
 
 def _compile(job):
     src, f16 = job
-    obj = os.path.join(OBJ, src[:-4] + ("_f16.o" if f16 else ".o"))
+    obj = os.path.join(OBJ, src[:-4] + ("_big.o" if f16 == "big" else "_f16.o" if f16 else ".o"))
     srcp = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), _deps_mtime()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + (MLP_FLAGS if src in MLP_FILES else []) + (FLAGS2 if src in FILES2 else []) + (["-DNCW_HALF_F16"] if f16 else [])
+    cmd = [HIPCC] + FLAGS + (MLP_FLAGS if src in MLP_FILES else []) + (FLAGS2 if src in FILES2 else []) + (["-DNCW_RAYS_BIG"] if f16 == "big" else ["-DNCW_HALF_F16"] if f16 else [])
     cmd += ["-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

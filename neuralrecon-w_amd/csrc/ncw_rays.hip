@@ -11,8 +11,23 @@
 #include "../../include/neuconw_hip.h"
 #include "ncw_common.h"
 
-#define RAY_MAXN 512            // max samples per ray handled in LDS
+// A ray's samples live in LDS (one wave per ray).  The file is compiled TWICE (neuralrecon-w_amd/build.py): the standard object
+// handles up to 512 samples per ray (two workgroups per CU in the compositor backward) and forwards larger rays -- up to 1088: the
+// reference's own defaults, config/defaults.py:8-9,32: 512 + 512 samples + 32 outside -- to the `_big` entry points of the second
+// object (-DNCW_RAYS_BIG: the same kernels with 17 elements per lane, 122 KB of LDS in the compositor backward).
+#ifdef NCW_RAYS_BIG
+#define RAY_MAXN 1088
+#define NCW_RAYNS ncw_rays_big
+#define NCW_RAYFN(name) name##_big
+#else
+#define RAY_MAXN 512            // max samples per ray handled in LDS by this object
+#define NCW_RAYNS ncw_rays_std
+#define NCW_RAYFN(name) name
+#endif
+#define RAY_MAXN_BIG 1088
 #define RAY_CH (RAY_MAXN / 64)  // elements per lane in a chunked scan
+
+namespace NCW_RAYNS {
 
 NCW_DEV float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -615,13 +630,30 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs A, CompBwd 
     if (lane == 0) G.d_inv_s[r] = ds_acc;  // per-ray term; the caller sums them (no atomics: reproducible)
 }
 
+}  // namespace NCW_RAYNS
+using namespace NCW_RAYNS;
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-extern "C" int ncw_sample_coarse(const float* near, const float* far, const float* s_near, const float* s_far, int R,
+#ifndef NCW_RAYS_BIG
+extern "C" int ncw_sample_coarse_big(const float*, const float*, const float*, const float*, int, int, int, const float*, const float*,
+                                     float*, float*, float*, void*);
+extern "C" int ncw_upsample_big(const float*, const float*, const float*, const float*, int, int, float, int, float*, void*);
+extern "C" int ncw_sort_merge_big(const float*, int, const float*, int, const float*, const float*, int, float*, float*, void*);
+extern "C" int ncw_composite_fwd_big(const NcwCompositeIn*, const NcwCompositeOut*, void*);
+extern "C" int ncw_composite_bwd_big(const NcwCompositeIn*, const NcwCompositeGrad*, void*);
+#define NCW_RAYS_FORWARD_BIG(cond, call) do { if (cond) return call; } while (0)
+#else
+#define NCW_RAYS_FORWARD_BIG(cond, call) do { } while (0)
+#endif
+
+extern "C" int NCW_RAYFN(ncw_sample_coarse)(const float* near, const float* far, const float* s_near, const float* s_far, int R,
                                  int n_samples, int n_outside, const float* rand_shift, const float* rand_out,
                                  float* z, float* z_out, float* sample_dist, void* stream) {
     if (R <= 0) return 0;
+    NCW_RAYS_FORWARD_BIG(n_samples > RAY_MAXN && n_samples <= RAY_MAXN_BIG,
+                         ncw_sample_coarse_big(near, far, s_near, s_far, R, n_samples, n_outside, rand_shift, rand_out, z, z_out, sample_dist, stream));
     if (n_samples < 1 || n_samples > RAY_MAXN) return NCW_E_BADARG;
     dim3 blk(64, 4);
     hipLaunchKernelGGL(sample_coarse_kernel, dim3((R + 3) / 4), blk, 0, (hipStream_t)stream, near, far, s_near, s_far, R,
@@ -630,9 +662,10 @@ extern "C" int ncw_sample_coarse(const float* near, const float* far, const floa
     return 0;
 }
 
-extern "C" int ncw_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int R, int n,
+extern "C" int NCW_RAYFN(ncw_upsample)(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int R, int n,
                             float inv_s, int n_new, float* z_new, void* stream) {
     if (R <= 0 || n_new <= 0) return 0;
+    NCW_RAYS_FORWARD_BIG(n > RAY_MAXN - 1 && n <= RAY_MAXN_BIG - 1, ncw_upsample_big(rays_o, rays_d, z, sdf, R, n, inv_s, n_new, z_new, stream));
     if (n < 2 || n > RAY_MAXN - 1) return NCW_E_BADARG;
     hipLaunchKernelGGL(upsample_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z, sdf, R,
                        n, inv_s, n_new, z_new);
@@ -640,9 +673,10 @@ extern "C" int ncw_upsample(const float* rays_o, const float* rays_d, const floa
     return 0;
 }
 
-extern "C" int ncw_sort_merge(const float* a, int na, const float* b, int nb, const float* pa, const float* pb, int R,
+extern "C" int NCW_RAYFN(ncw_sort_merge)(const float* a, int na, const float* b, int nb, const float* pa, const float* pb, int R,
                               float* out, float* pout, void* stream) {
     if (R <= 0 || na + nb <= 0) return 0;
+    NCW_RAYS_FORWARD_BIG(na + nb > RAY_MAXN && na + nb <= RAY_MAXN_BIG, ncw_sort_merge_big(a, na, b, nb, pa, pb, R, out, pout, stream));
     if (na + nb > RAY_MAXN) return NCW_E_BADARG;
     hipLaunchKernelGGL(sort_merge_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, pa, pb, R,
                        out, pout);
@@ -650,6 +684,7 @@ extern "C" int ncw_sort_merge(const float* a, int na, const float* b, int nb, co
     return 0;
 }
 
+#ifndef NCW_RAYS_BIG
 extern "C" int ncw_boundary(const float* near, const float* far, const float* z, int n, int R, int nb, float* zb,
                             void* stream) {
     if (R <= 0 || nb <= 0) return 0;
@@ -658,11 +693,13 @@ extern "C" int ncw_boundary(const float* near, const float* far, const float* z,
     NCW_CHECK_LAUNCH();
     return 0;
 }
+#endif
 
-extern "C" int ncw_composite_fwd(const NcwCompositeIn* in, const NcwCompositeOut* out, void* stream) {
+extern "C" int NCW_RAYFN(ncw_composite_fwd)(const NcwCompositeIn* in, const NcwCompositeOut* out, void* stream) {
     if (!in || !out) return NCW_E_BADARG;
     if (in->R <= 0) return 0;
     const int M = in->has_bg ? in->S + in->O : in->S;
+    NCW_RAYS_FORWARD_BIG(M > RAY_MAXN && M <= RAY_MAXN_BIG, ncw_composite_fwd_big(in, out, stream));
     if (in->S < 1 || M > RAY_MAXN) return NCW_E_BADARG;
     CompArgs A;
     A.rays_o = in->rays_o; A.rays_d = in->rays_d; A.z = in->z; A.z_feed = in->z_feed; A.sample_dist = in->sample_dist;
@@ -678,10 +715,11 @@ extern "C" int ncw_composite_fwd(const NcwCompositeIn* in, const NcwCompositeOut
     return 0;
 }
 
-extern "C" int ncw_composite_bwd(const NcwCompositeIn* in, const NcwCompositeGrad* g, void* stream) {
+extern "C" int NCW_RAYFN(ncw_composite_bwd)(const NcwCompositeIn* in, const NcwCompositeGrad* g, void* stream) {
     if (!in || !g) return NCW_E_BADARG;
     if (in->R <= 0) return 0;
     const int M = in->has_bg ? in->S + in->O : in->S;
+    NCW_RAYS_FORWARD_BIG(M > RAY_MAXN && M <= RAY_MAXN_BIG, ncw_composite_bwd_big(in, g, stream));
     if (in->S < 1 || M > RAY_MAXN) return NCW_E_BADARG;
     CompArgs A;
     A.rays_o = in->rays_o; A.rays_d = in->rays_d; A.z = in->z; A.z_feed = in->z_feed; A.sample_dist = in->sample_dist;
@@ -699,6 +737,7 @@ extern "C" int ncw_composite_bwd(const NcwCompositeIn* in, const NcwCompositeGra
     return 0;
 }
 
+#ifndef NCW_RAYS_BIG  // ---- everything below does not keep a ray in LDS: the standard object only --------------------------------------
 // out[r][j] (+)= sum_i rows[r * per_ray + i][j], i ascending: the order-fixed reduction of the per-point appearance-code
 // adjoints (ncw_color_bwd / ncw_nerf_bwd with d_a_rows) to the per-ray gradient of the embedding lookup
 // (models/neuconw.py:131-139, nerf.py:159-160: `a` is repeated over a ray's samples, so autograd sums over them).
@@ -1036,3 +1075,4 @@ extern "C" int ncw_bg_select(const float* rays_o, const float* rays_d, const flo
     }
     return 0;
 }
+#endif  // !NCW_RAYS_BIG

@@ -353,10 +353,10 @@ class NeuconWRenderer:
         # reference unless told otherwise; the training passes and the sampler follow `prec`
         # None = the defaults: fp32 for rgb() / NeuconW.forward, SDFNetwork.value_prec() for sdf() and the sweeps built on it
         self.infer_prec = infer_prec
-        if self.n_samples + self.n_importance + (self.boundary_samples or 0) + self.n_outside > 512:
-            raise ValueError("n_samples + n_importance + boundary_samples + n_outside = %d > 512: the per-ray kernels keep a "
-                             "ray's samples in LDS (RAY_MAXN 512).  Note config/defaults.py's N_SAMPLES = N_IMPORTANCE = "
-                             "512 is overridden by every shipped scene yaml (8 + 16)."
+        if self.n_samples + self.n_importance + (self.boundary_samples or 0) + self.n_outside > 1088:
+            raise ValueError("n_samples + n_importance + boundary_samples + n_outside = %d > 1088: the per-ray kernels keep a "
+                             "ray's samples in LDS (csrc/ncw_rays.hip: 512 in the standard kernels, 1088 in the large-ray ones -- "
+                             "config/defaults.py's own 512 + 512 + 32 fits)."
                              % (self.n_samples + self.n_importance + (self.boundary_samples or 0) + self.n_outside))
         # bg_dense=True: evaluate the background NeRF on every sample like the reference does, instead of only where the
         # compositor can use it (dead-background elimination, _RenderFn.forward: every precision, incl. the reproducible
