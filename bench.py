@@ -137,6 +137,7 @@ def kernel_flops(R):
 
 
 ORACLE_CFG = None
+BATCH_SEED = 1000  # rank r times synth_batch(R, BATCH_SEED + r); the parity / cpu_baseline legs use rank 0's batch (--seed: robustness sweeps)
 
 
 def _oracle_setup(sample_rays, seed, variance=None):
@@ -189,7 +190,8 @@ def recorded_calibration():
         return None, None
 
 
-def cpu_baseline(sample_rays=256, repeats=3, max_threads=32, seed=1000, full_batch=True):
+def cpu_baseline(sample_rays=256, repeats=3, max_threads=32, seed=None, full_batch=True):
+    seed = BATCH_SEED if seed is None else seed
     """The CPU oracle (oracle/neuconw_oracle.py, pinned to the real reference by tests/golden) timed on
     this box's host cores on a bounded sample of the same workload (same nets, same sampler shape).
     Returns (cpu_baseline dict, reference outputs of that sample for the `parity` object)."""
@@ -254,11 +256,12 @@ def _oracle_sdf_at_samples(sd, rays, z):
     return sdf, pts
 
 
-def oracle_outputs(sample_rays=256, seed=1000, variance=None, state=None, voxel=False):
+def oracle_outputs(sample_rays=256, seed=None, variance=None, state=None, voxel=False):
     """Forward-only oracle evaluation of the same sample (fp64), optionally at another variance (inv_s = exp(10 variance))
     or with another state_dict (`state`: the trained-weights point); voxel: configs[2] (coarse + fine level-7 shell octree)."""
     from oracle import neuconw_oracle as O
 
+    seed = BATCH_SEED if seed is None else seed
     sd, cfg, (rays, ts, label, rgbs) = _oracle_setup(sample_rays, seed, variance)
     if state is not None:
         sd = dict(state)
@@ -284,12 +287,13 @@ def _state_dict_of(emb, neuconw, nerf):
     return sd
 
 
-def trained_state(dev, steps=40, sample_rays=256, seed=1000, lr=1e-3, variance=0.6):
+def trained_state(dev, steps=40, sample_rays=256, seed=None, lr=1e-3, variance=0.6):
     """A NON-initial operating point for `parity`: `steps` TrainSteps in the fp32 mode (bitwise reproducible) from the bench's
     initial weights on the parity sample, then SingleVarianceNetwork.variance set to `variance` (inv_s 403, where NeuS
     trains) -- the recipe of tests/test_gpu_fullsize.py::test_train_step_vs_oracle_after_training.  -> CPU state_dict."""
     import neuralrecon_w_amd as nw
 
+    seed = BATCH_SEED if seed is None else seed
     emb, neuconw, nerf, rdr = build_models(dev, nw.PREC_F32)
     train = nw.TrainStep(rdr, [emb, neuconw, nerf], loss_fn, lr=lr, eps=1e-7, clip=0.99)
     rays, ts, label, rgbs = [t[:sample_rays] for t in synth_batch(R_PER_GPU, seed, dev)]
@@ -317,10 +321,11 @@ def voxel_setup(rdr, dev):
     return oct_, oct_, dict(boundary_samples=10, sample_range=16, radius=1.0, voxel_size=vs)
 
 
-def gpu_outputs(dev, prec, sample_rays=256, seed=1000, variance=None, pts=None, state=None, z_override=None, voxel=False):
+def gpu_outputs(dev, prec, sample_rays=256, seed=None, variance=None, pts=None, state=None, z_override=None, voxel=False):
     """The product's render + loss of the same sample, same (initial, or `state`) weights, in the TIMED precision,
     deterministic sampling (perturb 0) like the oracle leg; `pts`: where to evaluate the SDF network (the oracle's samples);
     `z_override`: the oracle's own primary sample depths (the MLPs + compositor at FIXED positions); `voxel`: configs[2]."""
+    seed = BATCH_SEED if seed is None else seed
     emb, neuconw, nerf, rdr = build_models(dev, prec)
     if voxel:
         voxel_setup(rdr, dev)
@@ -587,7 +592,7 @@ def bench_render(args, nw, L, dev, world, rank):
     emb, neuconw, nerf, rdr = build_models(dev, prec)
     rdr.bg_dense = not args.bg_eliminate
     R = args.rays
-    rays, ts, label, rgbs = synth_batch(R, 1000 + rank, dev)
+    rays, ts, label, rgbs = synth_batch(R, BATCH_SEED + rank, dev)
     bg = torch.zeros(1, 3, device=dev)
     S = N_SAMPLES + N_IMPORTANCE
 
@@ -703,6 +708,7 @@ def main():
                     help="secondary: time the MAIN leg with dead-background elimination (the product default) instead of "
                          "evaluating the background NeRF on every sample like the reference; marked in the metric name")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 parity-mode timing (`parity_mode`)")
+    ap.add_argument("--seed", type=int, default=1000, help="seed of the synthetic ray batch (default 1000: the reported line); the parity legs follow it")
     ap.add_argument("--save-trained-state", default=None, help="write the trained-weights parity point's state_dict here (.pt)")
     ap.add_argument("--inner", action="store_true", help="(internal) the short run the PMC passes profile: timing loop only")
     ap.add_argument("--grid-width", type=int, default=None, choices=[256, 512], help="--config grid512: SDF width (default 512)")
@@ -732,6 +738,7 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.stdout.flush()
         os.execvp(sys.executable, cmd)
+    globals().update(BATCH_SEED=int(args.seed))
     if args.config == "shipped":  # config/train_brandenburg_gate.yaml: SDF 8x512, N_SAMPLES 8, N_IMPORTANCE 16
         globals().update(W_SDF=512, N_SAMPLES=8, N_IMPORTANCE=16, M_SDF=2097664, M_SDF1=1835520, M_COL=585344)
     if args.rays is None:  # the reference's recipe trains 2048 rays per GPU (scripts/train.sh:16-19)
@@ -792,7 +799,7 @@ def main():
     prec = {"bf16": nw.PREC_BF16, "f16": nw.PREC_F16, "f32": nw.PREC_F32}[args.prec]
     R = args.rays
     bg = torch.zeros(1, 3, device=dev)
-    rays, ts, label, rgbs = synth_batch(R, 1000 + rank, dev)
+    rays, ts, label, rgbs = synth_batch(R, BATCH_SEED + rank, dev)
     n_boundary = 0
 
     def make_step(prec_, bg_dense=True, sdf_split=None):
