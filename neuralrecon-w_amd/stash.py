@@ -70,7 +70,7 @@ class WgradBatch:
         """n_dev: device int32[1] -- the products cover only the first min(n_points, n_dev[0]) points of their stashes (a
         selection made on the device, NcwPoints mode 4; 16-bit tiled launch only).  sel_fraction: the fraction of n_points the
         selection is EXPECTED to hold (the split-K plan balances the launch with it; the kernel clamps to the real count):
-        the renderer passes what it last observed (renderer.SelectionProbe), SEL_FRACTION otherwise."""
+        the renderer passes what it last observed (stash.SelectionProbe), SEL_FRACTION otherwise."""
         self.device = torch.device(device)
         self.prec = prec
         self.n = int(n_points)
@@ -251,7 +251,7 @@ class SelectionProbe:
             self.i ^= 1
 
     def bucket(self, default):
-        """(fraction to plan with, its bucket): re-planning happens when the observed share leaves a +-12 % bucket."""
+        """(fraction to plan with, its bucket): re-planning happens when the observed share leaves its 1.25x bucket (with hysteresis)."""
         import math
 
         f = default if self.fraction is None else min(1.0, max(self.fraction, 1e-3))
@@ -260,5 +260,8 @@ class SelectionProbe:
         # planned at 7.5 % the launch takes 0.80 ms, at 12.5 % 0.69 ms; under-planning -- 12.5 % for the 18 % of the shipped
         # shape -- costs 1.09 against 0.87 ms).  NCW_SEL_OVERPLAN: tuning hook of scripts/r05.
         f = min(1.0, f * self.OVERPLAN)
-        b = round(math.log(f) / math.log(1.25))
+        bf = math.log(f) / math.log(1.25)
+        b = self.__dict__.get("_b")
+        if b is None or abs(bf - b) > 0.75:  # hysteresis: a share that hovers around a bucket edge must not re-plan every step
+            b = self._b = round(bf)
         return 1.25 ** b, b

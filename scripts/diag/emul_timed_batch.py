@@ -31,7 +31,8 @@ import bench  # noqa: E402
 torch.set_num_threads(8)
 if "--shipped" in argv_keep:  # bench.py --config shipped: SDF 8 x 512, 8 + 16 samples (config/train_brandenburg_gate.yaml)
     bench.__dict__.update(W_SDF=512, N_SAMPLES=8, N_IMPORTANCE=16, M_SDF=2097664, M_SDF1=1835520, M_COL=585344)
-sd0, cfg, (rays, ts, label, rgbs) = bench._oracle_setup(n_rays, 1000)
+batch_seed = int(argv_keep[argv_keep.index("--seed") + 1]) if "--seed" in argv_keep else 1000
+sd0, cfg, (rays, ts, label, rgbs) = bench._oracle_setup(n_rays, batch_seed)
 state = torch.load(state_path, map_location="cpu")
 sd = {k: (v.double() if v.is_floating_point() else v) for k, v in state.items()}
 print("variance in the saved state: %.3f (inv_s %.0f)" % (float(sd["neuconw.deviation_network.variance"]),
@@ -89,7 +90,19 @@ cases_all = [("the round-4 kernels (colour weights hi+lo, per-ray head columns f
          ("+ tail + colour inputs hi+lo", dict(base, tail=split, cin=split)),
          ("+ tail + whole colour net hi+lo", dict(base, tail=split, cin=split, clay=split)),
          ("+ tail + colour net + nerf hi+lo (everything)", dict(base, tail=split, cin=split, clay=split, nw=split, nin=split, nact=split))]
-cases = [c for c in cases_all if ("--only-new" not in argv_keep) or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
+r5 = dict(base, tail=None, tail_feat=rnd, tail_adj=split, adj_t=rnd, adj_s=rnd)  # round 5's kernels
+if "--candidates" in argv_keep:
+    cases_all = [("round-5 kernels (adjoint W^T hi+lo)", r5),
+                 ("+ nerf weights hi+lo", dict(r5, nw=split)),
+                 ("+ nerf weights + gamma(p) + activations hi+lo", dict(r5, nw=split, nin=split, nact=split)),
+                 ("+ colour inputs (feat, points, normals) hi+lo", dict(r5, cin=split)),
+                 ("+ colour activations hi+lo", dict(r5, clay=split)),
+                 ("+ colour inputs + activations hi+lo", dict(r5, cin=split, clay=split)),
+                 ("+ feature rows hi+lo", dict(r5, tail_feat=split)),
+                 ("+ adjoint t hi+lo too", dict(r5, adj_t=None)),
+                 ("+ nerf weights + colour inputs hi+lo", dict(r5, nw=split, cin=split)),
+                 ("+ nerf weights + colour inputs + activations hi+lo", dict(r5, nw=split, cin=split, clay=split))]
+cases = [c for c in cases_all if ("--only-new" not in argv_keep) or "--candidates" in argv_keep or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
 res = {}
 worst_rays = None
 for name, m in cases:
@@ -129,8 +142,9 @@ if with_ref and os.path.isdir("/root/reference"):
              "weights_sum": rel(o32["weights_sum"], ref["weights_sum"]), "weights": rel(o32["weights"], ref["weights"]),
              "colour_p99": float(torch.quantile(pr, 0.99)), "rays_above_1e-4": int((pr > 1e-4).sum())}
     print("the UNMODIFIED reference in fp32 vs the fp64 oracle on these weights / rays:", {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in ref32.items()})
-out_path = os.path.join(ROOT, "profiles", "r05", "emul_timed_batch%s%s.json" % ("_shipped" if "--shipped" in argv_keep else "",
-                                                                              "_kernel_form" if "--only-new" in argv_keep else ""))
+out_path = os.path.join(ROOT, "profiles", "r05", "emul_timed_batch%s%s%s.json" % ("_shipped" if "--shipped" in argv_keep else "",
+                                                                                "_kernel_form" if "--only-new" in argv_keep else "",
+                                                                                "" if batch_seed == 1000 else "_seed%d" % batch_seed))
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 with open(out_path, "w") as fh:
     json.dump({"state": os.path.relpath(os.path.abspath(state_path), ROOT), "rays": n_rays, "emulated_fp16_candidates": res,
