@@ -275,6 +275,9 @@ typedef struct NcwNerfNet {
     int32_t D;       /* trunk depth (8)                                         */
     int32_t skip;    /* layer index after whose ReLU gamma(p) is concatenated    */
     int32_t rbn, rbh, n_head, n_a;
+    /* fp16 mode: the rounding residuals h16(W - h16(W)) of the FORWARD matrices above (NcwPackDesc.residual), or all NULL: the
+     * operands of ncw_nerf_refine. */
+    const void* w_p_lo[8]; const void* w_alpha_lo; const void* w_feat_lo; const void* w_a_lo[4]; const void* w_rgb_lo;
 } NcwNerfNet;
 
 typedef struct NcwNerfStash {
@@ -300,6 +303,15 @@ int ncw_nerf_fwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, const fl
                  float* density, float* rgb, const NcwNerfStash* stash, void* stream);
 int ncw_nerf_bwd(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_density,
                  const float* d_rgb, float* d_a, float* d_a_rows, const NcwNerfStash* stash, void* stream);
+/* FORWARD REFINEMENT of the background NeRF in split precision (fp16 mode, W = 256; models/nerf.py:156-182 on the points of
+ * rendering/renderer.py:176-186): density / raw rgb of the SELECTED samples (pts: NcwPoints mode 4, the list of ncw_bg_select --
+ * the samples whose background the compositor can use) are re-evaluated with gamma_10(p4), weights (net->w_*_lo) and hidden
+ * activations as fp16 hi + lo pairs (three MFMAs per product, f32 accumulate: fp32-level outputs) and written over the
+ * plain-fp16 results of ncw_nerf_fwd at those samples.  aux_bias: the per-ray fp32 rows of ncw_aux_ray_bias ([R, 128]) -- the
+ * view-direction / appearance-code columns of the head.  Forward only (the stash and the backward are the plain launch's).
+ * Rays whose colour is all background carry the plain NeRF's error undiluted: 1.1e-4 .. 1.6e-4 on trained weights without this. */
+int ncw_nerf_refine(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* aux_bias, float* density,
+                    float* rgb, void* stream);
 /* Batch assembly from the HBM-resident ray cache.  Replaces, per batch, PhototourismDataset.__getitem__
  * for split "train" (datasets/phototourism.py:709-726: rays = row[0:8] ++ row[10:13] (with semantics) / row[9:12],
  * ts = long(row[8]), semantics = row[9]), the DataLoader's collate + pinned H2D copy, and the black-list test of

@@ -296,6 +296,32 @@ extern "C" int NCW_FN(ncw_nerf_fwd)(const NcwNerfNet* net, int prec, const NcwPo
     return 0;
 }
 
+// fp16 build: the split-precision refinement of ncw_split.hip (W = 256 networks that carry residual matrices)
+#ifdef NCW_HALF_F16
+int ncw_nerf_refineS_launch_f16(const NcwNerfNet* net, const NcwPoints& src, int64_t n, const float* aux_bias, float* density,
+                                float* rgb, hipStream_t st);
+#else
+extern "C" int ncw_nerf_refine_f16(const NcwNerfNet*, int, const NcwPoints*, int64_t, const float*, float*, float*, void*);
+#endif
+
+extern "C" int NCW_FN(ncw_nerf_refine)(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* aux_bias,
+                                       float* density, float* rgb, void* stream) {
+    NCW_FORWARD_F16(prec, ncw_nerf_refine_f16(net, NCW_PREC_BF16, pts, n, aux_bias, density, rgb, stream));
+#ifdef NCW_HALF_F16
+    if (!nerf_ok(net) || !pts || !aux_bias || !density || !rgb || n < 0 || prec != NCW_PREC_BF16) return NCW_E_BADARG;
+    if (pts->mode != 4 || !pts->idx || !pts->count) return NCW_E_BADARG;   // a device-made selection (ncw_bg_select)
+    if (net->rbn != 8 || net->rbh != 4) return NCW_E_UNSUPPORTED;
+    bool lo = net->w_alpha_lo != nullptr && net->w_feat_lo != nullptr && net->w_rgb_lo != nullptr;
+    for (int i = 0; i < net->D; ++i) lo = lo && net->w_p_lo[i] != nullptr;
+    for (int i = 0; i < net->n_head; ++i) lo = lo && net->w_a_lo[i] != nullptr;
+    if (!lo) return NCW_E_BADARG;
+    if (n == 0) return 0;
+    return ncw_nerf_refineS_launch_f16(net, *pts, n, aux_bias, density, rgb, (hipStream_t)stream);
+#else
+    return NCW_E_UNSUPPORTED;  // fp16 mode only (prec 2)
+#endif
+}
+
 extern "C" int NCW_FN(ncw_nerf_bwd)(const NcwNerfNet* net, int prec, const NcwPoints* pts, int64_t n, const float* d_density,
                                     const float* d_rgb, float* d_a, float* d_a_rows, const NcwNerfStash* stash, void* stream) {
     NCW_FORWARD_F16(prec, ncw_nerf_bwd_f16(net, NCW_PREC_BF16, pts, n, d_density, d_rgb, d_a, d_a_rows, stash, stream));

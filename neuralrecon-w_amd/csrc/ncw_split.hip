@@ -763,6 +763,220 @@ __global__ __launch_bounds__(64 * SS_WAVES) void sdf_fwdSA_kernel(NcwSdfNet net,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Background NeRF, FORWARD REFINEMENT in split precision (round 5): density / raw rgb of a SELECTION of points (NcwPoints
+// mode 4: the samples the compositor can use, ncw_bg_select) re-evaluated with every operand of every product as an fp16 hi + lo
+// pair -- gamma_10(p4), weights and hidden activations: W x ~= W_hi x_hi + W_lo x_hi + W_hi x_lo, f32 accumulate -- and
+// written over the plain-fp16 outputs of ncw_nerf_fwd at those samples.  Why: on TRAINED weights the rays whose colour is all
+// background (weights_sum ~ 0: sky) carry the plain-fp16 NeRF's error undiluted -- the worst rays of the timed batch, 1.1e-4 to
+// 1.6e-4 on two of four seeds, and only ALL three operand groups as hi + lo pairs remove it (scripts/diag/emul_timed_batch.py
+// --candidates: 1.6e-4 -> 4e-8; weights alone: no change).  The selection is ~7 % of the background samples (the rest is
+// multiplied by 1 - inside_sphere = 0 in the compositor, rendering/renderer.py:693-708), so three MFMAs per product cost less here
+// than hi + lo weights would on every sample.  Forward only: stash, ncw_nerf_bwd and the weight gradients are those of the plain
+// launch.  The appearance head's view-direction / appearance-code columns come from the per-ray fp32 rows of ncw_aux_ray_bias.
+// Structure: 8 waves, 2 tiles (64 points) per workgroup; wave w owns output block w of a 256-wide layer (both tiles), block w & 3
+// of tile w >> 2 in the 128-wide head; activations [tile][k-unit][hi | lo] in LDS, rewritten in place; weight slices hi + lo in two
+// K-halves of 8 units.
+// ------------------------------------------------------------------------------------------------
+constexpr int NS_WAVES = 8, NS_TILES = 2;
+constexpr int NS_ACT = NS_TILES * 16 * 2 * 1024;  // [tile][16 units][hi | lo][64 lanes x 16 B]
+constexpr int NS_X = NS_TILES * 6 * 2 * 1024;     // gamma_10(p4): 84 features = 6 units, hi | lo
+
+NCW_DEV void ns_inverted_sphere(const float (&x)[3], float (&p4)[4]) {  // renderer.py:181-186
+    float r = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    r = fminf(fmaxf(r, 1.0f), 1e10f);
+    p4[0] = x[0] / r; p4[1] = x[1] / r; p4[2] = x[2] / r; p4[3] = 1.0f / r;
+}
+
+// acc[t] += W[ob, units u0 .. u0 + NU) . in[t, units iu0 .. iu0 + NU)] (upt units per tile in `in`), three MFMAs per unit
+template <int NU>
+NCW_DEV void ns_mma(f32x16 (&acc)[NS_TILES], const bf16x8 (&wh)[NU], const bf16x8 (&wl)[NU], const ss_lfrag* in, int upt, int iu0) {
+#pragma unroll
+    for (int q = 0; q < NU; ++q) {
+        const ss_lfrag* p0 = in + ((0 * upt + iu0 + q) * 2) * 64;
+        const ss_lfrag* p1 = in + ((1 * upt + iu0 + q) * 2) * 64;
+        const bf16x8 bh0 = p0[0], bl0 = p0[64], bh1 = p1[0], bl1 = p1[64];
+        acc[0] = NCW_MFMA_H(wh[q], bh0, acc[0], 0, 0, 0);
+        acc[1] = NCW_MFMA_H(wh[q], bh1, acc[1], 0, 0, 0);
+        acc[0] = NCW_MFMA_H(wl[q], bh0, acc[0], 0, 0, 0);
+        acc[1] = NCW_MFMA_H(wl[q], bh1, acc[1], 0, 0, 0);
+        acc[0] = NCW_MFMA_H(wh[q], bl0, acc[0], 0, 0, 0);
+        acc[1] = NCW_MFMA_H(wh[q], bl1, acc[1], 0, 0, 0);
+    }
+}
+// one tile only
+template <int NU>
+NCW_DEV void ns_mma1(f32x16& acc, const bf16x8 (&wh)[NU], const bf16x8 (&wl)[NU], const ss_lfrag* in, int t, int upt, int iu0) {
+#pragma unroll
+    for (int q = 0; q < NU; ++q) {
+        const ss_lfrag* p0 = in + ((t * upt + iu0 + q) * 2) * 64;
+        const bf16x8 bh = p0[0], bl = p0[64];
+        acc = NCW_MFMA_H(wh[q], bh, acc, 0, 0, 0);
+        acc = NCW_MFMA_H(wl[q], bh, acc, 0, 0, 0);
+        acc = NCW_MFMA_H(wh[q], bl, acc, 0, 0, 0);
+    }
+}
+
+// v (one output block of tile t, f32) -> hi / lo fragments of k-units 2 ob, 2 ob + 1 of the activation buffer
+NCW_DEV void ns_store(ss_lfrag* abuf, int t, int ob, const f32x16& v, int lane) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        bf16x8 hi, lo;
+        ss_split8(v, tt, hi, lo);
+        abuf[((t * 16 + 2 * ob + tt) * 2 + 0) * 64 + lane] = hi;
+        abuf[((t * 16 + 2 * ob + tt) * 2 + 1) * 64 + lane] = lo;
+    }
+}
+
+__global__ __launch_bounds__(64 * NS_WAVES) void nerf_refineS_kernel(NcwNerfNet net, NcwPoints src, int64_t n, const float* __restrict__ aux_bias,
+                                                                    float* __restrict__ density, float* __restrict__ rgb) {
+    __shared__ __attribute__((aligned(16))) char lds[NS_ACT + NS_X + NS_TILES * 32 * 4];
+    ss_lfrag* const abuf = (ss_lfrag*)(ncw_lchar*)lds;
+    ss_lfrag* const xbuf = abuf + NS_ACT / 16;
+    typedef __attribute__((address_space(3))) int ns_lint;
+    ns_lint* const rbuf = (ns_lint*)(xbuf + NS_X / 16);
+    const int lane = ncw_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile0 = (int64_t)blockIdx.x * NS_TILES;
+    const int D = net.D;
+    n = points_count(src, n);            // the selection's size, read on the device
+    if (tile0 * 32 >= n) return;         // (uniform: before any barrier)
+    int64_t pp = 0;
+    bool pvalid = false;
+    if (wave < NS_TILES) {
+        int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
+        pvalid = p < n;
+        if (!pvalid) p = n - 1;
+        pp = point_slot(src, p);         // density / rgb are addressed by the ray sample
+        float xs[3], p4[4];
+        load_point(src, p, xs, ray);
+        ns_inverted_sphere(xs, p4);
+        if (lane < 32) rbuf[wave * 32 + lane] = (int)ray;
+        CVec<3> gp;
+        freq_encode<3, 4, 10, false>(gp, p4, lane);  // sinf / cosf: frequencies up to 2^9
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            bf16x8 hi, lo;
+            ss_split8(gp.v[q >> 1], q & 1, hi, lo);
+            xbuf[((wave * 6 + q) * 2 + 0) * 64 + lane] = hi;
+            xbuf[((wave * 6 + q) * 2 + 1) * 64 + lane] = lo;
+        }
+    }
+    bf16x8 Ah[8], Al[8], Bh[8], Bl[8];
+    f32x16 acc[NS_TILES];
+    const ss_lfrag* const ain = abuf + lane;
+    const ss_lfrag* const xin = xbuf + lane;
+    auto relu_store = [&](int ob) {  // ReLU, hi / lo fragments of this wave's block into abuf (in place)
+        ncw_lds_barrier();  // every wave has finished reading the layer input
+#pragma unroll
+        for (int t = 0; t < NS_TILES; ++t) {
+            f32x16 y;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = ncw_relu(acc[t][r]);
+            ns_store(abuf, t, ob, y, lane);
+        }
+        ncw_lds_barrier();  // the layer output is complete
+    };
+    // ---- trunk layer 0 (K = 84: the 6 units of gamma(p)) ---------------------------------------------------------
+    {
+        bf16x8 w0h[6], w0l[6];
+        ss_load_half<6>(w0h, w0l, net.w_p[0], net.w_p_lo[0], 8, wave, 0, lane);
+        if (D > 1) ss_load_half<8>(Ah, Al, net.w_p[1], net.w_p_lo[1], 8, wave, 0, lane);
+        const f32x16 bias = ss_bias(net.b_p[0], wave, lane);
+        acc[0] = bias; acc[1] = bias;
+        ncw_lds_barrier();  // gamma(p) visible
+        ns_mma<6>(acc, w0h, w0l, xin, 6, 0);
+        relu_store(wave);
+    }
+    // ---- trunk layers 1 .. D-1 -----------------------------------------------------------------------------------------
+    for (int i = 1; i < D; ++i) {
+        const f32x16 bias = ss_bias(net.b_p[i], wave, lane);
+        acc[0] = bias; acc[1] = bias;
+        ss_load_half<8>(Bh, Bl, net.w_p[i], net.w_p_lo[i], 8, wave, 8, lane);  // second half: lands during the first
+        ns_mma<8>(acc, Ah, Al, ain, 16, 0);
+        {   // first half of the NEXT matrix (trunk layer i + 1, or the feature layer)
+            const void* nh = i + 1 < D ? net.w_p[i + 1] : net.w_feat;
+            const void* nl = i + 1 < D ? net.w_p_lo[i + 1] : net.w_feat_lo;
+            ss_load_half<8>(Ah, Al, nh, nl, 8, wave, 0, lane);
+        }
+        ns_mma<8>(acc, Bh, Bl, ain, 16, 8);
+        if (i == net.skip + 1) {  // the gamma(p) columns: units 16..21 (once per launch)
+            bf16x8 wgh[6], wgl[6];
+            ss_load_half<6>(wgh, wgl, net.w_p[i], net.w_p_lo[i], 8, wave, 16, lane);
+            ns_mma<6>(acc, wgh, wgl, xin, 6, 0);
+        }
+        relu_store(wave);
+    }
+    // ---- density (1 output block; tile t by wave t) and the feature layer (Ah / Al = first half of w_feat) ----------------
+    if (wave < NS_TILES) {
+        CVec<1> o;
+        load_bias(o, net.b_alpha, lane);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bf16x8 wh[8], wl[8];
+            ss_load_half<8>(wh, wl, net.w_alpha, net.w_alpha_lo, 1, 0, 8 * half, lane);
+            ns_mma1<8>(o.v[0], wh, wl, ain, wave, 16, 8 * half);
+        }
+        if (pvalid && lane < 32) density[pp] = o.v[0][0];
+    }
+    {
+        const f32x16 bias = ss_bias(net.b_feat, wave, lane);
+        acc[0] = bias; acc[1] = bias;
+        ss_load_half<8>(Bh, Bl, net.w_feat, net.w_feat_lo, 8, wave, 8, lane);
+        ns_mma<8>(acc, Ah, Al, ain, 16, 0);
+        ns_mma<8>(acc, Bh, Bl, ain, 16, 8);
+        ncw_lds_barrier();  // every wave (and the density row) has read h_D
+#pragma unroll
+        for (int t = 0; t < NS_TILES; ++t) ns_store(abuf, t, wave, acc[t], lane);  // no activation (nerf.py:171)
+        ncw_lds_barrier();
+    }
+    // ---- appearance head (nerf.py:131-139,173-174): 128 wide = 4 output blocks; wave w: block w & 3 of tile w >> 2 -----
+    const int hb = wave & 3, ht = wave >> 2;
+    f32x16 hacc;
+    {
+        hacc = ss_bias(net.b_a[0], hb, lane);
+        // the view-direction / appearance-code columns of static_linear_0: per-ray fp32 rows of ncw_aux_ray_bias
+        ncw_add_ray_bias_block(hacc, aux_bias + (size_t)rbuf[ht * 32 + (lane & 31)] * 128, hb, lane);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bf16x8 wh[8], wl[8];
+            ss_load_half<8>(wh, wl, net.w_a[0], net.w_a_lo[0], 4, hb, 8 * half, lane);
+            ns_mma1<8>(hacc, wh, wl, ain, ht, 16, 8 * half);
+        }
+        ncw_lds_barrier();
+        f32x16 y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = ncw_relu(hacc[r]);
+        ns_store(abuf, ht, hb, y, lane);  // units 0..7 of tile ht
+        ncw_lds_barrier();
+    }
+    for (int i = 1; i < net.n_head; ++i) {
+        hacc = ss_bias(net.b_a[i], hb, lane);
+        bf16x8 wh[8], wl[8];
+        ss_load_half<8>(wh, wl, net.w_a[i], net.w_a_lo[i], 4, hb, 0, lane);
+        ns_mma1<8>(hacc, wh, wl, ain, ht, 16, 0);
+        ncw_lds_barrier();
+        f32x16 y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = ncw_relu(hacc[r]);
+        ns_store(abuf, ht, hb, y, lane);
+        ncw_lds_barrier();
+    }
+    // ---- raw rgb (nerf.py:181): tile t by wave t -----------------------------------------------------------------------
+    if (wave < NS_TILES) {
+        CVec<1> o;
+        load_bias(o, net.b_rgb, lane);
+        bf16x8 wh[8], wl[8];
+        ss_load_half<8>(wh, wl, net.w_rgb, net.w_rgb_lo, 1, 0, 0, lane);
+        ns_mma1<8>(o.v[0], wh, wl, ain, wave, 16, 0);
+        if (pvalid && lane < 32) {
+            rgb[pp * 3 + 0] = o.v[0][0];
+            rgb[pp * 3 + 1] = o.v[0][1];
+            rgb[pp * 3 + 2] = o.v[0][2];
+        }
+    }
+}
+
 }  // namespace
 
 // Measured per 131,072 points on MI355X (scripts/diag/split_check.py; plain fp16 kernels: 0.160 / 0.558 ms):
@@ -794,6 +1008,15 @@ int ncw_sdf_fwdS_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_t 
         if (render) hipLaunchKernelGGL(sdf_fwdS_kernel<false>, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
         else hipLaunchKernelGGL(sdf_fwdS_kernel<true>, grid, dim3(64 * SS_WAVES), 0, st, *net, src, n, sdf, grad, stash);
     }
+    NCW_CHECK_LAUNCH();
+    return 0;
+}
+
+int ncw_nerf_refineS_launch_f16(const NcwNerfNet* net, const NcwPoints& src, int64_t n, const float* aux_bias, float* density,
+                                float* rgb, hipStream_t st) {
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(nerf_refineS_kernel, dim3((unsigned)((tiles + NS_TILES - 1) / NS_TILES)), dim3(64 * NS_WAVES), 0, st, *net, src,
+                       n, aux_bias, density, rgb);
     NCW_CHECK_LAUNCH();
     return 0;
 }

@@ -99,7 +99,9 @@ class NcwNerfNet(C.Structure):
                 ("w_a", C.c_void_p * 4), ("wt_a", C.c_void_p * 4), ("b_a", C.c_void_p * 4),
                 ("w_rgb", C.c_void_p), ("wt_rgb", C.c_void_p), ("b_rgb", C.c_void_p),
                 ("D", C.c_int32), ("skip", C.c_int32), ("rbn", C.c_int32), ("rbh", C.c_int32),
-                ("n_head", C.c_int32), ("n_a", C.c_int32)]
+                ("n_head", C.c_int32), ("n_a", C.c_int32),
+                ("w_p_lo", C.c_void_p * 8), ("w_alpha_lo", C.c_void_p), ("w_feat_lo", C.c_void_p), ("w_a_lo", C.c_void_p * 4),
+                ("w_rgb_lo", C.c_void_p)]
 
 
 class NcwNerfStash(C.Structure):
@@ -174,6 +176,8 @@ _PROTOS = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NcwNerfStash), C.c_void_p]),
     "ncw_nerf_bwd": (C.c_int, [C.POINTER(NcwNerfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NcwNerfStash), C.c_void_p]),
+    "ncw_nerf_refine": (C.c_int, [C.POINTER(NcwNerfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
     "ncw_sdf_fwd": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p, C.c_void_p,
                               C.POINTER(NcwSdfStash), C.c_void_p]),
     "ncw_sdf_bwd": (C.c_int, [C.POINTER(NcwSdfNet), C.c_int, C.POINTER(NcwPoints), C.c_int64, C.c_void_p, C.c_void_p,

@@ -44,6 +44,9 @@ class NeRF(_PackedNet):
         self.rgb_linear = nn.Linear(W // 2, 3)
         # fwd_stash: per-ray fp32 head columns (16-bit modes); NEUCONW_NERF_RAY_BIAS overrides NEUCONW_COLOR_RAY_BIAS for this net
         self.ray_bias = os.environ.get("NEUCONW_NERF_RAY_BIAS", os.environ.get("NEUCONW_COLOR_RAY_BIAS", "1")) != "0"
+        # fp16 mode, W = 256: the forward re-evaluates the samples the compositor can use in split precision (ncw_nerf_refine: every
+        # operand as an fp16 hi + lo pair) over the plain-fp16 outputs; NEUCONW_NERF_REFINE=0 / .refine = False = plain fp16 only
+        self.refine = os.environ.get("NEUCONW_NERF_REFINE", "1") != "0"
         self._init_plans()
 
     @property
@@ -56,6 +59,8 @@ class NeRF(_PackedNet):
         net = L.NcwNerfNet()
         sl = {}
 
+        split = prec == L.PREC_F16 and self.refine and RBN == 8  # residual matrices of the forward (ncw_nerf_refine)
+
         def full(name, mod, rb_out, rb_in, segs):
             v, g, b = _wvb(mod)
             m, bs, mt = plan.new_matrix(rb_out, rb_in), plan.new_bias(rb_out), plan.new_matrix(rb_in, rb_out)
@@ -63,7 +68,11 @@ class NeRF(_PackedNet):
             plan.add_pack(v, g, b, m, bs, segs)
             plan.add_pack(v, g, None, mt, None, segs, transpose=True)
             plan.add_unpack(v, g, b, dn, segs)
-            sl[name] = (m, bs, mt, dn)
+            lo = None
+            if split:
+                lo = plan.new_matrix(rb_out, rb_in)
+                plan.add_pack(v, g, None, lo, None, segs, residual=True)
+            sl[name] = (m, bs, mt, dn, lo)
 
         full("p0", self.pts_linears[0], RBN, 3, [(0, E, 0)])
         for i in range(1, self.D):
@@ -90,6 +99,13 @@ class NeRF(_PackedNet):
         for i in range(self.n_head):
             net.w_a[i], net.b_a[i], net.wt_a[i] = trip("a%d" % i)
         net.w_rgb, net.b_rgb, net.wt_rgb = trip("rgb")
+        if split:
+            for i in range(self.D):
+                net.w_p_lo[i] = plan.mat_ptr(sl["p%d" % i][4])
+            for i in range(self.n_head):
+                net.w_a_lo[i] = plan.mat_ptr(sl["a%d" % i][4])
+            net.w_alpha_lo, net.w_feat_lo, net.w_rgb_lo = (plan.mat_ptr(sl[k][4]) for k in ("alpha", "feat", "rgb"))
+        plan.has_lo = split
         net.D, net.skip, net.rbn, net.rbh, net.n_head, net.n_a = self.D, self.skips[0], RBN, RBH, self.n_head, A
         plan.net, plan.slots = net, sl
         return plan
@@ -100,8 +116,11 @@ class NeRF(_PackedNet):
         other widths / the reproducible d_a_rows path)."""
         return True
 
-    def fwd_stash(self, pts, n, prec, a, x4=None, select=None, train=True):
-        """train=False: the forward-only render -- nothing is stashed (NcwNerfStash.gp == NULL selects the render kernels); the same
+    def fwd_stash(self, pts, n, prec, a, x4=None, select=None, train=True, refine=None):
+        """refine = (z, O) (like `select`; fp16 mode at W = 256 with .refine on): after the plain forward the samples the compositor
+        can use are re-evaluated in split precision over its outputs (ncw_nerf_refine) -- also when `select` is None (the dense
+        evaluation of every sample like the reference; the list is then made for the refinement alone).
+        train=False: the forward-only render -- nothing is stashed (NcwNerfStash.gp == NULL selects the render kernels); the same
         density / rgb bit for bit.
         select = (z, O): pts are the R x (S + O) mode-2 samples of z_feed, z [R, S] the primary samples; evaluate only the
         columns the compositor can use -- i < S where primary sample i is outside the unit sphere, and the O outside
@@ -138,8 +157,10 @@ class NeRF(_PackedNet):
                                                                              build if train else build_render)
         ar, ids, st = ent["arena"], ent["ids"], ent["stash"]
         sel_count = None
-        if select is not None:
-            z_prim, O_ = select
+        do_refine = (refine is not None and prec == L.PREC_F16 and self.refine and getattr(plan, "has_lo", False) and x4 is None)
+        pts_sel = None
+        if select is not None or do_refine:
+            z_prim, O_ = select if select is not None else refine
             z_prim = z_prim.contiguous().float()
             S_ = int(z_prim.shape[1])
             assert x4 is None and pts.mode == 2 and pts.per_ray == S_ + O_ and self.supports_selection(prec)
@@ -151,7 +172,7 @@ class NeRF(_PackedNet):
             L.check(L.get_lib().ncw_bg_select(pts.rays_o, pts.rays_d, L.ptr(z_prim), pts.sample_dist, n // (S_ + O_), S_, O_,
                                               L.ptr(ent["sel_idx"]), L.ptr(ent["sel_offs"]), L.ptr(sel_count),
                                               L.stream_ptr(dev)), "ncw_bg_select")
-            if train:  # the weight-gradient launch plans its split-K with the observed share (no synchronisation: stash.SelectionProbe)
+            if train and select is not None:  # the weight-gradient launch plans its split-K with the observed share (stash.SelectionProbe)
                 from .stash import SelectionProbe
 
                 probe = self.__dict__.get("_sel_probe")
@@ -163,13 +184,16 @@ class NeRF(_PackedNet):
                 default = (O_ + 0.05 * S_) / float(S_ + O_)
                 ent["sel_plan"] = probe.bucket(default) if probe is not None else ent.get("sel_plan", (default, None))
             keep_src = pts
-            pts = points_struct(mode=4, idx=ent["sel_idx"], count=sel_count)
-            pts.rays_o, pts.rays_d, pts.z, pts.sample_dist = keep_src.rays_o, keep_src.rays_d, keep_src.z, keep_src.sample_dist
-            pts.per_ray = keep_src.per_ray
-            pts._keep = pts._keep + [keep_src, z_prim]
+            pts_sel = points_struct(mode=4, idx=ent["sel_idx"], count=sel_count)
+            pts_sel.rays_o, pts_sel.rays_d, pts_sel.z, pts_sel.sample_dist = keep_src.rays_o, keep_src.rays_d, keep_src.z, keep_src.sample_dist
+            pts_sel.per_ray = keep_src.per_ray
+            pts_sel._keep = pts_sel._keep + [keep_src, z_prim]
+        if select is not None:
+            pts = pts_sel
             density = torch.zeros(n, device=dev, dtype=torch.float32)
             rgb = torch.zeros(n, 3, device=dev, dtype=torch.float32)
         else:
+            sel_count = None  # (a list made for the refinement alone does not size the weight-gradient products)
             density = torch.empty(n, device=dev, dtype=torch.float32)
             rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
         a = a.contiguous().float()
@@ -190,6 +214,9 @@ class NeRF(_PackedNet):
             st.aux_bias = ab.data_ptr()
         L.check(L.get_lib().ncw_nerf_fwd(plan.net, prec, pts, L.ptr(x4c), n, L.ptr(a), L.ptr(density), L.ptr(rgb), st,
                                          L.stream_ptr(dev)), "ncw_nerf_fwd")
+        if do_refine and st.aux_bias:  # (the head's per-ray fp32 columns are its input: .ray_bias on)
+            L.check(L.get_lib().ncw_nerf_refine(plan.net, prec, pts_sel, n, ctypes.c_void_p(st.aux_bias), L.ptr(density), L.ptr(rgb),
+                                                L.stream_ptr(dev)), "ncw_nerf_refine")
         return density, rgb, dict(arena=ar, ids=ids, stash=st, pts=pts, n=n, prec=prec, plan=plan, keep=(a, x4c),
                                   lease=ent, sel_count=sel_count)
 

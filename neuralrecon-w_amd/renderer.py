@@ -55,9 +55,11 @@ class _RenderFn(torch.autograd.Function):
             # multiplied by 1 - inside_sphere = 0, forward and backward) and at the n_outside samples; the reference
             # evaluates the NeRF on all S + O samples all the same.  Identical outputs and gradients; bg_dense=True
             # evaluates everything like the reference.  (Columns are paired with primary samples by index, as there.)
-            select = None
-            if rdr.trim_sphere and not rdr.bg_dense and nerf.supports_selection(prec):
-                select = (z, M - S)
+            select = refine = None
+            if rdr.trim_sphere and nerf.supports_selection(prec):
+                refine = (z, M - S)  # fp16 mode: the samples the compositor can use are re-evaluated in split precision (ncw_nerf_refine)
+                if not rdr.bg_dense:
+                    select = refine
             # The background NeRF is independent of the SDF / colour chain until the compositor: with `bg_stream` (a
             # second HIP stream, renderer.use_bg_stream) its launches overlap the ramps, tails and partial last rounds of the
             # SDF / colour launches (1056 workgroups of 128 background points = 4.125 rounds of 256 CUs: the fifth round
@@ -67,13 +69,13 @@ class _RenderFn(torch.autograd.Function):
                 main = torch.cuda.current_stream(dev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select, train=train)
+                    density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select, train=train, refine=refine)
                 # allocated under the side stream, consumed by the compositor on the main stream after the join below: tell
                 # the caching allocator, so that freeing them can never hand the memory out while the main stream still reads it
                 density.record_stream(main)
                 bg_rgb.record_stream(main)
             else:
-                density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select, train=train)
+                density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select, train=train, refine=refine)
             density, bg_rgb = density.view(R, M), bg_rgb.view(R, M, 3)
         try:
             pts_in = points_struct(rays_o=rays_o, rays_d=rays_d, z=z, sample_dist=sample_dist, mode=2)

@@ -151,3 +151,64 @@ def test_elimination_under_graph_capture():
     for a, b in zip(*curves):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), curves  # 16-bit runs separate through Adam's sign steps
     assert curves[0][-1] < curves[0][0]
+
+
+@pytest.mark.parametrize("dense", [True, False])
+def test_background_refinement_in_split_precision(dense):
+    """fp16 mode, W = 256: ncw_nerf_refine re-evaluates the samples the compositor can use (ncw_bg_select's list) with gamma_10(p4),
+    weights and activations as fp16 hi + lo pairs over the plain-fp16 outputs of ncw_nerf_fwd (models/nerf.py:156-182 on the points of
+    rendering/renderer.py:176-186).  At the selected samples density / raw rgb must be at the fp32 level of the fp64 oracle (the plain
+    kernel: 3-9e-4); the other samples keep the plain values (dense) or zeros (elimination); `.refine = False` gives the plain outputs."""
+    import neuralrecon_w_amd as nw
+    from neuralrecon_w_amd.neuconw import points_struct
+    from neuralrecon_w_amd.stash import StashCache
+    from neuralrecon_w_amd import rayops
+    from oracle import neuconw_oracle as O
+    from tests._build import build_system, state_dict_cpu
+    from tests._util import rel_err, synth_rays
+
+    emb, neuconw, nerf, rdr = build_system(W=256, n_a=48, n_vocab=100, nerf_w=256, color_hidden=256, head=128, seed=7, prec=nw.PREC_F16,
+                                           n_samples=16, n_importance=16)
+    with torch.no_grad():
+        for p_ in nerf.parameters():
+            p_.add_(0.02 * torch.randn_like(p_))
+    R, S, O_ = 50, 32, 4
+    rays, ts, label, _ = synth_rays(R, 31, 100)
+    rays_o, rays_d = rays[:, 0:3].cuda().contiguous(), rays[:, 3:6].cuda().contiguous()
+    g = torch.Generator().manual_seed(3)
+    z = torch.sort(1.0 + 2.5 * torch.rand(R, S, generator=g), -1)[0].cuda()      # primary samples: some leave the unit sphere
+    z_out = torch.sort(3.6 + 3.0 * torch.rand(R, O_, generator=g), -1)[0].cuda()
+    sample_dist = torch.full((R, 1), 0.05).cuda()
+    z_feed, _ = rayops.sort_merge(z, z_out)
+    M = S + O_
+    a = emb.weight.detach()[ts.cuda()].contiguous()
+    pts = points_struct(rays_o=rays_o, rays_d=rays_d, z=z_feed, sample_dist=sample_dist, mode=2)
+    sel = (z, O_)
+    outs = {}
+    for refine in (True, False):
+        nerf.refine = refine
+        nerf._plans.clear()  # (the residual matrices belong to the pack plan: built once per precision)
+        den, rgb, c = nerf.fwd_stash(pts, R * M, nw.PREC_F16, a, select=None if dense else sel, train=False, refine=sel)
+        StashCache.release(c["lease"])
+        outs[refine] = (den.view(R, M).cpu(), rgb.view(R, M, 3).cpu())
+        if refine:
+            idx = c["lease"]["sel_idx"][: int(c["lease"]["sel_count"])].cpu().long()
+    sd = {k[len("nerf."):]: v for k, v in state_dict_cpu(emb, neuconw, nerf, torch.float64).items() if k.startswith("nerf.")}
+    rgb_r, _, den_r = O.render_core_outside({"nerf." + k: v for k, v in sd.items()}, rays_o.cpu().double(), rays_d.cpu().double(),
+                                            z_feed.cpu().double(), sample_dist.cpu().double(), a.cpu().double(), "nerf.")
+    keep = torch.zeros(R * M, dtype=torch.bool)
+    keep[idx] = True
+    keep = keep.view(R, M)
+    assert 0.08 < float(keep.float().mean()) < 0.9 and bool(keep[:, S:].all())
+    e = {}
+    for refine in (True, False):
+        den, rgb = outs[refine]
+        e[refine] = (rel_err(den[keep], den_r[keep]), rel_err(rgb[keep], rgb_r[keep]))
+    print("background NeRF at the %d selected samples (dense=%s): split-precision refinement density %.2e rgb %.2e; plain fp16 %.2e / %.2e"
+          % (int(keep.sum()), dense, e[True][0], e[True][1], e[False][0], e[False][1]))
+    assert max(e[True]) < 5e-6 and min(e[False]) > 20 * max(e[True]), e
+    # what the refinement does NOT touch
+    if dense:
+        assert torch.equal(outs[True][0][~keep], outs[False][0][~keep]) and torch.equal(outs[True][1][~keep], outs[False][1][~keep])
+    else:
+        assert float(outs[True][0][~keep].abs().max()) == 0.0 and float(outs[True][1][~keep].abs().max()) == 0.0
