@@ -139,8 +139,34 @@ NCW_DEV void color_fwd_body(const NcwColorNet& net, const NcwPoints& src, int64_
         Act<P, RBH + 1> cat2;
         act_concat<RBH, 1>(cat2, ea, aux2a);
         load_bias(x, net.b_l[0], lane);
-        mma_stream_split<SPLIT, RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l_lo[0], SH::FCB_L0,
-                                                                net.w_l[1], 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
+        if constexpr (SPLIT) {
+            // lin0 takes [points | normals | e] (models/neuconw.py:147-148,158): with the weights as hi + lo pairs the remaining coherent
+            // term on trained weights was the fp16 rounding of POINTS and NORMALS themselves (scripts/diag/emul_timed_batch.py
+            // --candidates: a surface ray at 8.8e-5 -> 1.3e-5).  Third pass of the ring: W_hi . lo([p | n]) -- the e blocks of the
+            // operand are zero, the AUX2 block holds h16(v - h16(v)).  Forward only (the stash keeps the single-rounded AUX2).
+            const int nxt = 1 == last ? SH::FCB_LAST : SH::FCB_L;
+            mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l_lo[0], SH::FCB_L0, lane);
+            mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l_lo[0], net.w_l[0], SH::FCB_L0, lane);
+            {
+                CVec<1> aux2;
+                build_aux2(aux2, xs, nrm, lane);
+#pragma unroll
+                for (int i = 0; i < 2 * RBH; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cat2.f[i][e] = (ncw_h16)0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = aux2.v[0][8 * t + e];
+                        cat2.f[2 * RBH + t][e] = (ncw_h16)(v - (float)(ncw_h16)v);
+                    }
+            }
+            mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l[1], nxt, lane);
+        } else {
+            mma_stream_split<false, RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l_lo[0], SH::FCB_L0,
+                                                                          net.w_l[1], 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
+        }
         relu_epilogue<P, RBC>(xa, x, stp(st.x[0]), tile, lane);
     }
     for (int l = 1; l < last; ++l) {

@@ -96,6 +96,12 @@ if "--candidates" in argv_keep:
                  ("+ nerf weights hi+lo", dict(r5, nw=split)),
                  ("+ nerf weights + gamma(p) + activations hi+lo", dict(r5, nw=split, nin=split, nact=split)),
                  ("+ colour inputs (feat, points, normals) hi+lo", dict(r5, cin=split)),
+                 ("+ colour input feat hi+lo only", dict(r5, cin_f=split)),
+                 ("+ colour input points + normals hi+lo only", dict(r5, cin_p=split)),
+                 ("+ nerf all + colour feat hi+lo", dict(r5, nw=split, nin=split, nact=split, cin_f=split)),
+                 ("+ nerf all + colour points + normals hi+lo", dict(r5, nw=split, nin=split, nact=split, cin_p=split)),
+                 ("+ nerf all + colour inputs hi+lo", dict(r5, nw=split, nin=split, nact=split, cin=split)),
+                 ("+ nerf all + colour inputs + activations hi+lo", dict(r5, nw=split, nin=split, nact=split, cin=split, clay=split)),
                  ("+ colour activations hi+lo", dict(r5, clay=split)),
                  ("+ colour inputs + activations hi+lo", dict(r5, cin=split, clay=split)),
                  ("+ feature rows hi+lo", dict(r5, tail_feat=split)),
