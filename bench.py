@@ -8,7 +8,9 @@ A "step" = NeuconWRenderer.render (sampler + background NeRF + SDF/colour nets +
 gradient all-reduce + grad-norm clip + Adam step, on a synthetic batch of BASELINE.json's
 configs[1]: 1024 rays/GPU x (64 coarse + 64 fine) samples, SDF 8x256, colour 4x256, background
 NeRF 8x256, 4 outside samples, fp16 MFMA operands with f32 accumulation, a dynamic loss scale, and the SDF VALUE chain in
-split precision (fp16 hi + lo pairs, three MFMAs per product: fp32-like SDF values -- csrc/ncw_split.hip) (--prec f16, the
+split precision (fp16 hi + lo pairs, three MFMAs per product: fp32-like SDF values -- csrc/ncw_split.hip), as are the adjoint
+sweep's weights, the colour network's weights and point / normal inputs and -- at the samples the compositor can use -- the whole
+background NeRF (ncw_nerf_refine) (--prec f16, the
 default: rendered outputs within 1e-4 of the oracle at initialisation AND at trained sharpness, `parity`; --prec bf16 | f32
 select the others, `plain_f16_mode` times the step without the split).  Rays
 shard across ranks (weak scaling); value = total ray-samples of all ranks / max-over-ranks time.
@@ -812,6 +814,8 @@ def main():
         rdr_.bg_dense = bg_dense
         if sdf_split is not None:  # None = the product default (fp16: split-precision SDF value path, csrc/ncw_split.hip)
             neuconw_.sdf_net.sdf_split = sdf_split
+            if not sdf_split:  # `plain_f16_mode`: no split-precision work anywhere a switch exists (also the background refinement)
+                nerf_.refine = False
         if args.config == "voxel":  # configs[2]: coarse octree -> ray near/far; fine octree -> +-SAMPLE_RANGE window + boundary samples
             voxel_setup(rdr_, dev)
         train_ = nw.TrainStep(rdr_, [emb_, neuconw_, nerf_], loss_fn, lr=1e-4 * world * R / 4096.0, eps=1e-7, clip=0.99,
@@ -1007,9 +1011,9 @@ def main():
             torch.cuda.synchronize()
             d_p = (time.perf_counter() - t1) / args.steps
             plain = {"dtype": "f16", "value": R * S / d_p, "unit": "ray-samples/s", "ms_per_step": d_p * 1e3, "steps": args.steps,
-                     "note": "NEUCONW_SDF_SPLIT=0: one fp16 rounding per operand in the SDF value chain too (round 2's "
-                             "kernels); rendered outputs 5e-4 of the oracle at inv_s 20 and 2e-2 at inv_s 403 on these rays, "
-                             "against 4e-5 / 9e-5 for the timed split path"}
+                     "note": "NEUCONW_SDF_SPLIT=0 NEUCONW_NERF_REFINE=0: one fp16 rounding per operand in the SDF value chain and "
+                             "in the background NeRF (round 2's kernels); rendered outputs 5e-4 of the oracle at inv_s 20 and 2e-2 at inv_s 403 on these rays, "
+                             "against 1e-5 / 5e-5 for the timed path"}
             del train_p, step_p
             torch.cuda.empty_cache()
         # the product default: dead-background elimination (renderer.py _RenderFn.forward) -- identical outputs and

@@ -114,6 +114,7 @@ def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=Tru
         neuconw.color_net.ray_bias = False
         neuconw.color_net.weight_split = False
         nerf.ray_bias = False
+        nerf.refine = False  # (round 5: the split-precision re-evaluation of the usable background samples, forward only)
         neuconw.sdf_net.adj_split = False  # (round 5: the adjoint sweep's hi + lo weights are a forward-only refinement too)
     if sdf_split is not None:  # None = the product default (split-precision SDF value path in the fp16 mode at W = 256)
         neuconw.sdf_net.sdf_split = bool(sdf_split)
