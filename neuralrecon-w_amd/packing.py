@@ -154,8 +154,9 @@ class PackPlan:
         L.check(lib.ncw_pack_weights(L.ptr(self._pack_tab), L.ptr(self._pack_prefix), self._pack_n,
                                      self._pack_rows, L.stream_ptr(self.device)), "ncw_pack_weights")
 
-    def unpack_grads(self, accumulate_into, accumulate=False, grad_mul=1.0, grad_mul_dev=None):
-        """accumulate_into: dict id(param) -> grad tensor (same shape, fp32, contiguous).  Writes (or,
+    def unpack_grads(self, accumulate_into, accumulate=False, grad_mul=1.0, grad_mul_dev=None, launch=True):
+        """launch=False: only build / look up the device table -> (tab, prefix, n, rows) (unpack_many launches several plans' tables at once).
+        accumulate_into: dict id(param) -> grad tensor (same shape, fp32, contiguous).  Writes (or,
         with accumulate=True, adds) the parameter gradients from the dense gradient arena.  The device
         descriptor table is cached by content, so the steady state does no host->device copy.
         grad_mul (host float) and grad_mul_dev (1-element device tensor, read at run time) multiply everything written
@@ -167,6 +168,8 @@ class PackPlan:
         hit = cache.get(key)
         if hit is not None:
             tab, pre, n, rows = hit
+            if not launch:
+                return hit
             L.check(L.get_lib().ncw_unpack_grads(L.ptr(tab), L.ptr(pre), n, rows, L.stream_ptr(self.device)),
                     "ncw_unpack_grads")
             return tab, pre
@@ -194,10 +197,66 @@ class PackPlan:
             prefix.append(prefix[-1] + u["nrows"])
         tab = self._table(descs)
         pre = torch.tensor(prefix, dtype=torch.int32, device=self.device)
-        lib = L.get_lib()
-        L.check(lib.ncw_unpack_grads(L.ptr(tab), L.ptr(pre), len(descs), prefix[-1], L.stream_ptr(self.device)),
-                "ncw_unpack_grads")
         if len(cache) > 8:
             cache.clear()
         cache[key] = (tab, pre, len(descs), prefix[-1])
+        if not launch:
+            return cache[key]
+        lib = L.get_lib()
+        L.check(lib.ncw_unpack_grads(L.ptr(tab), L.ptr(pre), len(descs), prefix[-1], L.stream_ptr(self.device)),
+                "ncw_unpack_grads")
         return tab, pre  # keep alive until the stream has consumed them
+
+
+# ---- several plans in ONE launch ------------------------------------------------------------------------------------
+# The descriptor tables hold absolute device pointers, so the tables of several plans concatenate into one launch: the three
+# networks of a train step (SDF, colour, background NeRF) re-pack in one ncw_pack_weights and run their weight-norm backward in
+# one ncw_unpack_grads instead of three each (launch-latency-sized kernels, back to back on one stream).
+_MERGED = {}
+
+
+def _merge_tables(parts):
+    """parts: [(tab uint8, prefix int32 [n + 1], n, rows)] -> one (tab, prefix, n, rows); cached by the parts' storage."""
+    key = tuple((t.data_ptr(), pre.data_ptr(), n, rows) for t, pre, n, rows in parts)
+    hit = _MERGED.get(key)
+    if hit is None:
+        tab = torch.cat([t for t, _, _, _ in parts])
+        pres, off = [], 0
+        for i, (_, pre, n, rows) in enumerate(parts):
+            pres.append((pre if i == 0 else pre[1:]) + off)
+            off += rows
+        prefix = torch.cat(pres).to(torch.int32).contiguous()
+        if len(_MERGED) > 16:
+            _MERGED.clear()
+        hit = _MERGED[key] = (tab, prefix, sum(p[2] for p in parts), off, parts)  # (parts kept: their addresses are the key)
+    return hit[:4]
+
+
+def pack_many(owners):
+    """owners: [(module with _param_version(), its PackPlan)].  Re-packs every STALE plan in one launch on the current stream and
+    marks it fresh (what module.packed(prec) does one plan at a time).  Fewer than two stale plans: nothing (packed() does it)."""
+    stale = [(m, p) for m, p in owners if p.packed_version != (m._param_version(), p.param_key())]
+    if len(stale) < 2:
+        return
+    dev = stale[0][1].device
+    if any(p.device != dev for _, p in stale):
+        return
+    for _, p in stale:
+        if p.param_key() != p._key:
+            p._build_pack_table()
+    tab, prefix, n, rows = _merge_tables([(p._pack_tab, p._pack_prefix, p._pack_n, p._pack_rows) for _, p in stale])
+    L.check(L.get_lib().ncw_pack_weights(L.ptr(tab), L.ptr(prefix), n, rows, L.stream_ptr(dev)), "ncw_pack_weights")
+    for m, p in stale:
+        p.packed_version = (m._param_version(), p.param_key())
+
+
+def unpack_many(plans, accumulate_into, accumulate=False, grad_mul=1.0, grad_mul_dev=None):
+    """PackPlan.unpack_grads of several plans in one launch -> objects to keep alive until the stream has consumed them."""
+    parts = [pl.unpack_grads(accumulate_into, accumulate=accumulate, grad_mul=grad_mul, grad_mul_dev=grad_mul_dev, launch=False)
+             for pl in plans]
+    if len(parts) == 1:
+        tab, prefix, n, rows = parts[0]
+    else:
+        tab, prefix, n, rows = _merge_tables(parts)
+    L.check(L.get_lib().ncw_unpack_grads(L.ptr(tab), L.ptr(prefix), n, rows, L.stream_ptr(plans[0].device)), "ncw_unpack_grads")
+    return tab, prefix, parts

@@ -17,6 +17,7 @@ import yaml
 from . import lib as L
 from . import rayops
 from .neuconw import default_infer_prec, default_prec, points_struct
+from .packing import pack_many, unpack_many
 from .stash import LeaseGuard, WgradBatch
 
 from .labels import LABEL_IDS, label_id as _label_id  # noqa: E402  (ADE20K ids: datasets/mask_utils.py)
@@ -206,7 +207,7 @@ class _RenderFn(torch.autograd.Function):
             flat, views = rdr._grad_views(ctx.params)
             direct = all(p.grad is not None and p.grad.data_ptr() == views[id(p)].data_ptr() for p in ctx.params)
         if direct:
-            keep = [pl.unpack_grads(views, accumulate=True, grad_mul_dev=sc_inv) for pl in plans]
+            keep = unpack_many(plans, views, accumulate=True, grad_mul_dev=sc_inv)  # one launch for the three networks
         else:
             tmp = torch.zeros(sum(p.numel() for p in ctx.params), device=dev, dtype=torch.float32)
             tviews, off = {}, 0
@@ -216,7 +217,7 @@ class _RenderFn(torch.autograd.Function):
                 tviews[id(p)] = v
                 out.append(v)
                 off += p.numel()
-            keep = [pl.unpack_grads(tviews, grad_mul_dev=sc_inv) for pl in plans]
+            keep = unpack_many(plans, tviews, grad_mul_dev=sc_inv)
         ctx._keep = (keep, batch)
         d_var = torch.empty(1, device=dev, dtype=torch.float32)  # 10 inv_s [clamp inactive] sum_r d_inv_s[r], fixed order
         L.check(lib.ncw_inv_s_bwd(L.ptr(g["d_inv_s"]), R, L.ptr(ctx.inv_s), L.ptr(d_var), L.stream_ptr(dev)), "ncw_inv_s_bwd")
@@ -514,6 +515,11 @@ class NeuconWRenderer:
         if self.origin.device != device:
             self.origin = self.origin.to(device).float()
             self.sfm_to_gt = self.sfm_to_gt.to(device).float()
+        # the three networks' weight-norm forward + MFMA-order packing in ONE launch when more than one of them is stale (after an
+        # optimiser step: all three); each module's packed() then finds its plan fresh
+        if self.__dict__.get("sampler_prec") is None:
+            nets = [self.neuconw.sdf_net, self.neuconw.color_net] + ([self.nerf] if (self.render_bg and self.n_outside > 0) else [])
+            pack_many([(m, m.plan(self.prec)) for m in nets])
         # renderer.py:793-806 (ray normalisation into unit-sphere units) as one launch
         R = rays.shape[0]
         rays_c = rays.contiguous().float()

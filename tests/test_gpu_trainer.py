@@ -184,3 +184,39 @@ def test_grad_norm_launch_matches_torch_and_rearms(n):
     x[n // 2] = float("nan")
     L.check(lib.ncw_grad_norm(L.ptr(x), n, L.ptr(scratch), L.ptr(out), L.stream_ptr(x.device)), "ncw_grad_norm")
     assert float(out) != float(out)
+
+
+def test_merged_pack_and_unpack_equal_per_plan_launches():
+    """packing.pack_many / unpack_many (the three networks' tables concatenated: ONE ncw_pack_weights, ONE ncw_unpack_grads per step)
+    against one launch per plan: bitwise the same arenas / parameter gradients."""
+    import neuralrecon_w_amd as nw
+    from neuralrecon_w_amd import packing
+
+    emb, neuconw, nerf, rdr = build_system(seed=3, prec=nw.PREC_F16)
+    mods = [neuconw.sdf_net, neuconw.color_net, nerf]
+    plans = [m.plan(rdr.prec) for m in mods]
+    for p in plans:
+        p.pack()
+    ref = [(p.w_arena.clone(), p.b_arena.clone()) for p in plans]
+    for p in plans:
+        p.w_arena.zero_()
+        p.b_arena.zero_()
+        p.packed_version = None
+    packing.pack_many(list(zip(mods, plans)))
+    for p, (w, b), m in zip(plans, ref, mods):
+        assert torch.equal(p.w_arena, w) and torch.equal(p.b_arena, b)
+        assert p.packed_version == (m._param_version(), p.param_key())  # module.packed() will not launch again
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for p in plans:
+        p.g_arena.copy_(torch.randn(p.g_arena.shape, device="cuda", generator=g))
+    params = [q for m in mods for q in m.parameters()]
+    one = {id(q): torch.zeros_like(q) for q in params}
+    many = {id(q): torch.zeros_like(q) for q in params}
+    scale = torch.full((1,), 0.5, device="cuda")
+    keep = [p.unpack_grads(one, accumulate=True, grad_mul_dev=scale) for p in plans]
+    keep2 = packing.unpack_many(plans, many, accumulate=True, grad_mul_dev=scale)
+    torch.cuda.synchronize()
+    assert any(float(one[id(q)].abs().max()) > 0 for q in params)
+    for q in params:
+        assert torch.equal(one[id(q)], many[id(q)])
+    del keep, keep2
