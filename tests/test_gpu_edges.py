@@ -36,8 +36,9 @@ def test_single_ray_matches_oracle():
     sd = state_dict_cpu(emb, neuconw, nerf, torch.float64)
     ref = O.render(sd, dict(CFG, n_samples=16, n_importance=16), rays.double(), ts, label, 1.0,
                    torch.zeros(1, 3, dtype=torch.float64))
-    for k in ("color", "depth", "weights_sum"):
-        assert rel_err(out[k].detach().cpu(), ref[k]) < 2e-4, k
+    errs = {k: rel_err(out[k].detach().cpu(), ref[k]) for k in ("color", "depth", "weights_sum")}
+    print("single ray, f32:", {k: "%.2e" % v for k, v in errs.items()})
+    assert max(errs.values()) < 1e-4, errs
     assert all(torch.isfinite(p.grad).all() for p in neuconw.sdf_net.parameters())
 
 
@@ -57,8 +58,9 @@ def test_max_samples_per_ray_and_one_past():
     sd = state_dict_cpu(emb, neuconw, nerf, torch.float64)
     ref = O.render(sd, dict(CFG, n_samples=ns, n_importance=ni), rays.double(), ts, label, 0.5,
                    torch.zeros(1, 3, dtype=torch.float64))
-    for k in ("color", "depth", "weights_sum"):
-        assert rel_err(out[k].detach().cpu(), ref[k]) < 5e-4, (k, rel_err(out[k].detach().cpu(), ref[k]))
+    errs = {k: rel_err(out[k].detach().cpu(), ref[k]) for k in ("color", "depth", "weights_sum")}
+    print("508 + 4 samples per ray, f32:", {k: "%.2e" % v for k, v in errs.items()})
+    assert max(errs.values()) < 1e-4, errs
     with pytest.raises(ValueError, match="1088"):  # beyond the large-ray kernels' capacity: refused at construction, with the reason
         build_system(seed=3, prec=nw.PREC_F32, n_samples=544, n_importance=544)
     # ... and the C ABI itself refuses an over-long ray instead of truncating it (600 samples: the large-ray object takes it)
@@ -109,6 +111,6 @@ def test_more_than_512_samples_per_ray(ns, ni, n_out, steps):
     errs = {k: rel_err(out[k].detach().cpu(), ref[k]) for k in ("color", "depth", "weights_sum", "gradient_error")}
     e_g = rel_err(named_params(emb, neuconw, nerf)["neuconw.sdf_net.lin4.weight_v"].grad.cpu(), g)
     print("%d + %d + %d samples per ray:" % (ns, ni, n_out), {k: "%.2e" % v for k, v in errs.items()}, "d(lin4.weight_v) %.2e" % e_g)
-    assert max(errs.values()) < 2e-4 and e_g < 2e-3, (errs, e_g)
+    assert max(errs.values()) < 1e-4 and e_g < 2e-3, (errs, e_g)
     z = out["weights"]
     assert bool(torch.isfinite(z).all()) and bool((z >= 0).all())

@@ -33,7 +33,9 @@ def _jitter(neuconw):
 #   (eikonal 9e-6) / 1.3e-2, loss 1.1e-5 (plain fp16 value path: 3.4e-3, eikonal 7.6e-3).
 # (tol colour/depth/weights_sum, tol parameter gradients, tol eikonal term)
 BF16_TOL = {(16, 16): (1e-2, 0.175, 1e-2), (64, 64): (1.4e-2, 0.09, 1.4e-2), (8, 16): (3e-2, 0.1, 3e-2)}
-F16_TOL = {(16, 16): (1.2e-4, 8e-3, 5e-4), (64, 64): (1.2e-4, 3e-3, 6e-4), (8, 16): (1.5e-4, 0.03, 1e-4)}
+# round 5 (adjoint sweep, background refinement, colour lin0 inputs as hi + lo pairs): measured outputs 3.2e-5 / 7.6e-6 / 3.4e-5, eikonal term
+# 5.8e-7 / 2.3e-5 / 8.2e-6 at 16+16 / 64+64 / W = 512 8+16 -- every output bound is now at or under the north-star bar
+F16_TOL = {(16, 16): (8e-5, 8e-3, 1e-4), (64, 64): (5e-5, 3e-3, 1e-4), (8, 16): (1e-4, 0.03, 1e-4)}
 LOSS_TOL = {"f32": 1e-4, "bf16": 1.4e-3, "f16": 5e-5}
 
 
@@ -67,7 +69,8 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
     names = list(sd)
     gref = dict(zip(names, torch.autograd.grad(lref, [sd[k] for k in names], allow_unused=True)))
     if prec_name == "f32":
-        tol_out, tol_grad, tol_eik = 2e-4, 2e-3, 2e-4
+        # W = 256: the bar itself (measured 1.3e-6); W = 512 at 24 samples per ray: fp32's own conditioning (1.5e-4, note above)
+        tol_out, tol_grad, tol_eik = (1e-4, 2e-3, 1e-4) if W == 256 else (2e-4, 2e-3, 2e-4)
     elif prec_name == "f16":  # fp16 operands (split-precision SDF value path at W = 256) + dynamic loss scale
         tol_out, tol_grad, tol_eik = F16_TOL[(ns, ni)]
     else:  # bf16 throughput mode
@@ -128,10 +131,12 @@ def test_train_step_vs_oracle_real_widths(W, ns, ni, prec_name, R):
 # is 10x and bf16 100x above it.  DESIGN.md 4 has the full table.
 # (tol colour/depth/weights_sum, tol parameter gradients, tol eikonal term)
 TRAINED_TOL = {
-    (0.5, 0.0): {"f32": (1e-4, 2e-3, 1e-4), "f16": (1.2e-4, 2.6e-3, 3e-4), "bf16": (3e-2, 0.75, 4e-3)},
-    (0.6, 0.0): {"f32": (1.3e-3, 3.5e-3, 1e-4), "f16": (1.3e-3, 4e-3, 3e-4), "bf16": (0.12, 0.1, 4e-3)},
-    (0.7, 0.0): {"f32": (4.5e-4, 4e-2, 1e-4), "f16": (4.5e-4, 4e-2, 3e-4), "bf16": (4e-3, 0.32, 4e-3)},
-    (0.6, 0.05): {"f32": (1e-4, 2e-3, 1e-4), "f16": (1.2e-4, 2.1e-3, 2e-4), "bf16": (3e-3, 0.5, 2.2e-2)},
+    # (fp16, round 5: measured 1.6e-5 [7.5e-7] at (0.5, 0), 1.4e-6 [3.4e-5] at (0.6, 0.05); the sphere-SDF rows (0.6, 0) / (0.7, 0) are the
+    # sampler-conditioned ones where the reference's own fp32 sits at 7.8e-4 / 1.9e-4)
+    (0.5, 0.0): {"f32": (1e-4, 2e-3, 1e-4), "f16": (5e-5, 2.6e-3, 1e-4), "bf16": (3e-2, 0.75, 4e-3)},
+    (0.6, 0.0): {"f32": (1.3e-3, 3.5e-3, 1e-4), "f16": (1.3e-3, 4e-3, 1e-4), "bf16": (0.12, 0.1, 4e-3)},
+    (0.7, 0.0): {"f32": (4.5e-4, 4e-2, 1e-4), "f16": (4.5e-4, 4e-2, 1e-4), "bf16": (4e-3, 0.32, 4e-3)},
+    (0.6, 0.05): {"f32": (1e-4, 2e-3, 1e-4), "f16": (5e-5, 2.1e-3, 1e-4), "bf16": (3e-3, 0.5, 2.2e-2)},
 }
 
 
@@ -174,12 +179,13 @@ def test_train_step_vs_oracle_after_training(prec_name):
           "grads %.2e (d variance %.2e)" % (g_rest, g_var))
     # Round 4: the head's view-direction / appearance-code columns per ray in fp32 (ncw_aux_ray_bias) for the colour network
     # AND the background NeRF: fp16 colour 1.88e-4 -> 1.02e-4 (colour net only) -> 8.7e-5 (both); the colour network's forward
-    # with its weights as fp16 hi + lo pairs (NcwColorNet.w_*_lo): 6.1e-5.  The bound is the north-star bar itself, 1e-4.
+    # with its weights as fp16 hi + lo pairs (NcwColorNet.w_*_lo): 6.1e-5.  Round 5 (adjoint sweep with hi + lo weights, background refinement,
+    # lin0's point / normal inputs as hi + lo pairs): colour 3.1e-5, eikonal term 1.4e-5 -- bounds 7.5e-5 / 1e-4, under the north-star bar.
     # d(loss)/d(variance) is ONE scalar formed by a cancelling sum over all samples: on these inputs the REFERENCE's own fp32
     # arithmetic gets it to 3.7e-4 with colours at 3.2e-6 (profiles/r04/port_over_reference.json `d_variance_trained`), i.e. it
     # amplifies colour errors ~115x; with fp16 colours at 1e-4 it sits at 1e-2 .. 6e-2 (measured 1.0e-2 / 5.8e-2 with two
     # equally accurate forwards) and gets its own bound; every weight TENSOR stays under the old bound.
-    tol_out, tol_grad, tol_eik, tol_var = {"f32": (1e-4, 2e-3, 1e-4, 2e-3), "f16": (1e-4, 2e-2, 4e-4, 0.12),
+    tol_out, tol_grad, tol_eik, tol_var = {"f32": (1e-4, 2e-3, 1e-4, 2e-3), "f16": (7.5e-5, 2e-2, 1e-4, 0.12),
                                            "bf16": (2.5e-3, 0.18, 1e-2, 0.5)}[prec_name]
     for k, e in r["errs"].items():
         assert e < (tol_eik if k == "gradient_error" else tol_out), (k, e)

@@ -47,9 +47,10 @@ def test_ray_voxel_near_far_vs_bruteforce(level):
 
 # (W, precision, rays, tol per-ray outputs, tol per-sample tensors).  f32: the W = 64 networks of round 1; f16: the HEADLINE
 # networks (W = 256: the split-precision SDF value path exists there) in the timed dtype, at the fp16 output tolerance of
-# tests/test_gpu_fullsize.py (F16_TOL[(16, 16)][0] = 1.2e-4) -- config 3 in the precision `bench.py --config voxel` times.
-@pytest.mark.parametrize("W,prec_name,R,tol_out,tol_sample", [(64, "f32", 96, 2e-4, 2e-3), (256, "f32", 48, 2e-4, 2e-3),
-                                                              (256, "f16", 48, 1.2e-4, 2e-3)])
+# networks (W = 256: the split-precision SDF value path exists there) in the timed dtype -- config 3 in the precision `bench.py --config
+# voxel` times.  Every per-ray output bound is the north-star bar, 1e-4 (measured: fp32 2.3e-6 / 1.0e-5, fp16 4.3e-5, mask_error 6.7e-5).
+@pytest.mark.parametrize("W,prec_name,R,tol_out,tol_sample", [(64, "f32", 96, 1e-4, 2e-3), (256, "f32", 48, 1e-4, 2e-3),
+                                                              (256, "f16", 48, 1e-4, 2e-3)])
 def test_render_with_fine_octree_window_and_boundary_samples(W, prec_name, R, tol_out, tol_sample):
     """sampler narrowed to surface +- SAMPLE_RANGE voxels, 10 boundary samples (renderer.py:415-456, 549-566)."""
     import neuralrecon_w_amd as nw
@@ -84,12 +85,12 @@ def test_render_with_fine_octree_window_and_boundary_samples(W, prec_name, R, to
     print("voxel-guided render W=%d %s:" % (W, prec_name), {k: "%.2e" % v for k, v in errs.items()})
     for k in ("color", "depth", "weights_sum", "mask_error"):
         assert errs[k] < tol_out, (k, errs[k])
-    # two derived quantities have their own fp16 bounds (measured on MI355X: 1.8e-4 and 2.8e-4 with colour / depth / weights_sum at
-    # 5e-5): sfm_depth_loss = w (depth - depth_gt)^2 amplifies the depth error by 2 depth / |depth - depth_gt|; color_bg is the
-    # background NeRF's share alone (plain fp16 operands, relative to ITS small maximum: the colour it feeds is within tol_out)
-    assert errs["sfm_depth_loss"] < (4e-4 if prec_name == "f16" else tol_out), errs["sfm_depth_loss"]
-    assert errs["color_bg"] < (6e-4 if prec_name == "f16" else tol_out), errs["color_bg"]
-    # the eikonal term comes from the plain-fp16 adjoint sweep (normals 4e-4): F16_TOL[(16, 16)][2]
-    assert errs["gradient_error"] < (5e-4 if prec_name == "f16" else tol_out), errs["gradient_error"]
+    # fp16: sfm_depth_loss = w (depth - depth_gt)^2 amplifies the depth error by 2 depth / |depth - depth_gt| (measured 1.0e-4); color_bg is the
+    # background NeRF's share alone, relative to ITS small maximum -- 2.8e-4 with plain fp16 operands, 1.0e-6 since the split-precision
+    # refinement of the usable samples (ncw_nerf_refine): the common bound
+    assert errs["sfm_depth_loss"] < (2.5e-4 if prec_name == "f16" else tol_out), errs["sfm_depth_loss"]
+    assert errs["color_bg"] < tol_out, errs["color_bg"]
+    # the eikonal term: the adjoint sweep's t_l stays single-rounded fp16 (per-sample normals 2.8e-4; measured 1.2e-4)
+    assert errs["gradient_error"] < (3e-4 if prec_name == "f16" else tol_out), errs["gradient_error"]
     for k in ("weights", "cdf_fine", "gradients"):
         assert errs[k] < tol_sample, (k, errs[k])
