@@ -48,9 +48,7 @@ class _RenderFn(torch.autograd.Function):
         use_bg = rdr.render_bg and rdr.n_outside > 0 and z_out is not None
         z_feed = density = bg_rgb = nctx = None
         if use_bg:
-            z_feed, _ = rayops.sort_merge(z, z_out)
-            pts_bg = points_struct(rays_o=rays_o, rays_d=rays_d, z=z_feed, sample_dist=sample_dist, mode=2)
-            M = z_feed.shape[1]
+            M = S + z_out.shape[1]
             # Dead-background elimination: with trim_sphere the compositor takes the background NeRF only where a primary
             # sample's section mid-point is OUTSIDE the unit sphere (renderer.py:637,693-708: everything else is
             # multiplied by 1 - inside_sphere = 0, forward and backward) and at the n_outside samples; the reference
@@ -70,13 +68,21 @@ class _RenderFn(torch.autograd.Function):
                 main = torch.cuda.current_stream(dev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
+                    # (the merge of the primary and outside depths is only read by the NeRF and, after the join, by the compositor: a
+                    # launch-latency-sized kernel off the SDF / colour chain)
+                    z_feed, _ = rayops.sort_merge(z, z_out)
+                    pts_bg = points_struct(rays_o=rays_o, rays_d=rays_d, z=z_feed, sample_dist=sample_dist, mode=2)
                     density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select, train=train, refine=refine)
                 # allocated under the side stream, consumed by the compositor on the main stream after the join below: tell
                 # the caching allocator, so that freeing them can never hand the memory out while the main stream still reads it
                 density.record_stream(main)
                 bg_rgb.record_stream(main)
+                z_feed.record_stream(main)
             else:
+                z_feed, _ = rayops.sort_merge(z, z_out)
+                pts_bg = points_struct(rays_o=rays_o, rays_d=rays_d, z=z_feed, sample_dist=sample_dist, mode=2)
                 density, bg_rgb, nctx = nerf.fwd_stash(pts_bg, R * M, prec, a_det, select=select, train=train, refine=refine)
+            assert z_feed.shape[1] == M
             density, bg_rgb = density.view(R, M), bg_rgb.view(R, M, 3)
         try:
             pts_in = points_struct(rays_o=rays_o, rays_d=rays_d, z=z, sample_dist=sample_dist, mode=2)
