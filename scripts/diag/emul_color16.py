@@ -42,7 +42,7 @@ def split(x, dt=H):
     return hi + rnd(x - hi, dt)
 
 
-MODE = {"tail_feat": None, "tail_adj": None, "adj_t": None, "adj_w": None, "adj_s": None, "nin": None, "nda": None, "nw": None, "nact": None, "tail": None, "cin": None, "clay": None, "cw": None, "cin_f": None, "cin_da": None, "cin_p": None}   # None = exact; rnd / split
+MODE = {"samp_w": None, "samp_h": None, "tail_feat": None, "tail_adj": None, "adj_t": None, "adj_w": None, "adj_s": None, "nin": None, "nda": None, "nw": None, "nact": None, "tail": None, "cin": None, "clay": None, "cw": None, "cin_f": None, "cin_da": None, "cin_p": None}   # None = exact; rnd / split
 
 
 def q(x, key):
@@ -68,6 +68,9 @@ def sdf_net_e(sd, x, prefix="sdf_net.", skip_in=(4,), multires=6, scale=1.0, wit
             h = torch.cat([h, gamma], 1) / math.sqrt(2.0)
         if l == L - 1:  # sdf row exact (split path), feature rows in the tail precision
             z = torch.cat([F.linear(h, W[:1], b[:1]), F.linear(q(h, "tail_feat"), q(W[1:], "tail_feat"), b[1:])], 1)
+        elif not with_grad and (MODE["samp_w"] is not None or MODE["samp_h"] is not None):
+            # the SAMPLER's queries (no gradient asked) with their own operand roundings: samp_w on the weights, samp_h on the layer input
+            z = F.linear(q(h, "samp_h"), q(W, "samp_w"), b)
         else:
             z = F.linear(h, W, b)
         zs.append(z)

@@ -108,7 +108,13 @@ if "--candidates" in argv_keep:
                  ("+ adjoint t hi+lo too", dict(r5, adj_t=None)),
                  ("+ nerf weights + colour inputs hi+lo", dict(r5, nw=split, cin=split)),
                  ("+ nerf weights + colour inputs + activations hi+lo", dict(r5, nw=split, cin=split, clay=split))]
-cases = [c for c in cases_all if ("--only-new" not in argv_keep) or "--candidates" in argv_keep or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
+now = dict(r5, nw=split, nin=split, nact=split, cin_p=split)  # the round's final kernels (R5.8)
+if "--sampler" in argv_keep:  # the sampler's SDF queries (split precision, 3 MFMAs per product, as timed) with cheaper operand forms
+    cases_all = [("final round-5 kernels, sampler in split precision (as shipped)", now),
+                 ("sampler: weights hi+lo, layer inputs single fp16 (2 MFMAs)", dict(now, samp_h=rnd)),
+                 ("sampler: layer inputs hi+lo, weights single fp16 (2 MFMAs)", dict(now, samp_w=rnd)),
+                 ("sampler: plain fp16 (1 MFMA)", dict(now, samp_h=rnd, samp_w=rnd))]
+cases = [c for c in cases_all if "--sampler" in argv_keep or ("--only-new" not in argv_keep) or "--candidates" in argv_keep or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
 res = {}
 worst_rays = None
 for name, m in cases:
