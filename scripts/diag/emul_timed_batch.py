@@ -114,7 +114,19 @@ if "--sampler" in argv_keep:  # the sampler's SDF queries (split precision, 3 MF
                  ("sampler: weights hi+lo, layer inputs single fp16 (2 MFMAs)", dict(now, samp_h=rnd)),
                  ("sampler: layer inputs hi+lo, weights single fp16 (2 MFMAs)", dict(now, samp_w=rnd)),
                  ("sampler: plain fp16 (1 MFMA)", dict(now, samp_h=rnd, samp_w=rnd))]
-cases = [c for c in cases_all if "--sampler" in argv_keep or ("--only-new" not in argv_keep) or "--candidates" in argv_keep or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
+if "--next" in argv_keep:  # what is left after R5.8, one candidate at a time
+    cases_all = [("final round-5 kernels", now),
+                 ("+ colour feat input hi+lo", dict(now, cin_f=split)),
+                 ("+ colour activations hi+lo", dict(now, clay=split)),
+                 ("+ colour feat + activations hi+lo (whole colour net split)", dict(now, cin_f=split, clay=split)),
+                 ("+ feature rows hi+lo", dict(now, tail_feat=split)),
+                 ("+ feature rows + colour feat input hi+lo", dict(now, tail_feat=split, cin_f=split)),
+                 ("+ adjoint t hi+lo too", dict(now, adj_t=None)),
+                 ("+ adjoint exact (t, W^T, phi')", dict(now, adj_t=None, adj_s=None)),
+                 ("+ per-ray head columns exact instead of fp32 (cin_da)", dict(now)),
+                 ("+ feature rows + colour feat + activations hi+lo", dict(now, tail_feat=split, cin_f=split, clay=split)),
+                 ("+ everything hi+lo", dict(now, tail_feat=split, cin_f=split, clay=split, adj_t=None, adj_s=None))]
+cases = [c for c in cases_all if "--sampler" in argv_keep or "--next" in argv_keep or ("--only-new" not in argv_keep) or "--candidates" in argv_keep or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
 res = {}
 worst_rays = None
 for name, m in cases:
