@@ -425,7 +425,8 @@ int ncw_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  * The reference's recipe has no counterpart for the scale (fp32 training, train.py:48-62). */
 /* total_norm of torch.nn.utils.clip_grad_norm_ (train.py:61) over ONE flat fp32 buffer (16-byte aligned): norm[0] = ||grad||_2.
  * One launch, fixed summation order (run-to-run reproducible), non-finite entries propagate.  scratch: device floats,
- * ncw_grad_norm_scratch_floats() of them, ZERO-FILLED ONCE by the caller (it holds the kernel's re-arming ticket). */
+ * ncw_grad_norm_scratch_floats() of them; it holds the partial sums and the blocks' arrival ticket, which a stream-ordered memset
+ * arms in front of every launch (capture-safe).  One scratch buffer serves ONE stream at a time. */
 int64_t ncw_grad_norm_scratch_floats(void);
 int ncw_grad_norm(const float* grad, int64_t n, float* scratch, float* norm, void* stream);
 

@@ -173,7 +173,6 @@ __global__ __launch_bounds__(256) void grad_norm_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         norm[0] = sqrtf((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
-        *reinterpret_cast<unsigned*>(scratch + NORM_BLOCKS) = 0u;  // re-armed for the next launch (stream order)
     }
 }
 
@@ -181,6 +180,10 @@ extern "C" int64_t ncw_grad_norm_scratch_floats(void) { return NORM_BLOCKS + 4; 
 
 extern "C" int ncw_grad_norm(const float* grad, int64_t n, float* scratch, float* norm, void* stream) {
     if (!grad || !scratch || !norm || n < 0 || ((uintptr_t)grad & 15) != 0) return NCW_E_BADARG;
+    // The arrival ticket is armed by a stream-ordered memset in front of EVERY launch (capture-safe: a memset node): a launch that
+    // was aborted before its last block arrived (device fault, killed graph replay) cannot leave a stale count behind.  One
+    // scratch buffer belongs to one stream at a time.
+    if (hipMemsetAsync(scratch + NORM_BLOCKS, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return NCW_E_BADARG;
     hipLaunchKernelGGL(grad_norm_kernel, dim3(NORM_BLOCKS), dim3(256), 0, (hipStream_t)stream, grad, n, scratch, norm);
     NCW_CHECK_LAUNCH();
     return 0;

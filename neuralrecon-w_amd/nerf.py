@@ -53,6 +53,9 @@ class NeRF(_PackedNet):
     def n_head(self):
         return len(self.apperence_encoding)
 
+    def _plan_switches(self):
+        return (bool(self.refine),)
+
     def _build_plan(self, prec, dev):
         RBN, RBH, W, A, E = self.W // 32, self.W // 64, self.W, self.in_channels_a, self.input_ch
         plan = PackPlan(dev, prec)

@@ -379,6 +379,10 @@ class _PackedNet(nn.Module):
     def _init_plans(self):
         self._plans = {}
 
+    def _plan_switches(self):
+        """Mutable attributes `_build_plan` reads (part of the plan cache key)."""
+        return ()
+
     def _param_version(self):
         # _ncw_version_srcs: base tensors whose in-place updates change these parameters without touching their
         # own version counters (trainer.FlatParams re-seats p.data into one flat buffer)
@@ -390,7 +394,9 @@ class _PackedNet(nn.Module):
 
     def plan(self, prec):
         dev = self._first_param().device
-        key = (prec, str(dev))
+        # switches read when the plan is BUILT (residual matrices present or not) belong to the key: flipping `.refine` /
+        # `.weight_split` after the first forward selects (or builds) the matching plan instead of being a silent no-op
+        key = (prec, str(dev)) + tuple(self._plan_switches())
         p = self._plans.get(key)
         if p is None:
             p = self._build_plan(prec, dev)
@@ -443,6 +449,9 @@ class RenderingNetwork(_PackedNet):
         # first forward: the packed-weight plan is built once per precision)
         self.weight_split = os.environ.get("NEUCONW_COLOR_WSPLIT", "1") != "0"
         self._init_plans()
+
+    def _plan_switches(self):
+        return (bool(self.weight_split),)
 
     @property
     def n_lin(self):

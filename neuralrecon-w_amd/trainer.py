@@ -175,7 +175,7 @@ class FlatAdam:
         norm = None
         if need_norm:  # ||flat_grad||_2 as one fixed-order launch (ncw_grad_norm) instead of ATen's reduction kernels
             lib = L.get_lib()
-            if self.__dict__.get("_norm_scratch") is None:
+            if self.__dict__.get("_norm_scratch") is None or self._norm_scratch.device != fp.flat_grad.device:
                 self._norm_scratch = torch.zeros(int(lib.ncw_grad_norm_scratch_floats()), device=fp.flat_grad.device, dtype=torch.float32)
                 self._norm = torch.empty(1, device=fp.flat_grad.device, dtype=torch.float32)
             norm = self._norm
@@ -188,7 +188,9 @@ class FlatAdam:
             float(self.clip) if self.clip is not None else 0.0, L.ptr(self.loss_scale), self.growth_interval,
             self.scale_min, self.scale_max, L.stream_ptr(fp.flat_grad.device)), "ncw_adam_step_dev")
         fp.mark_updated()
-        return norm
+        # a fresh 4-byte tensor (device copy, no sync): `_norm` is overwritten by the next step, a caller keeping norms across
+        # steps must not alias it
+        return norm.clone() if norm is not None else None
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,

@@ -70,11 +70,22 @@ def main():
     del rdr_t, emb_t, neuconw_t, nerf_t
     result = {"steps": args.steps, "rays": args.rays, "pool": args.pool, "lr": args.lr, "runs": {}}
     for name in args.precs.split(","):
-        prec = {"f32": nw.PREC_F32, "f16": nw.PREC_F16, "bf16": nw.PREC_BF16}[name]
+        prec = {"f32": nw.PREC_F32, "f16": nw.PREC_F16, "bf16": nw.PREC_BF16, "f16_noextras": nw.PREC_F16,
+                "f32b": nw.PREC_F32}[name]  # f32b: fp32 again with ANOTHER batch order -- the run-to-run spread the others are read against
         emb, neuconw, nerf, rdr = bench.build_models(dev, prec, seed=7)
+        if name == "f16_noextras":
+            # the forward-only refinements of the fp16 mode OFF (tests/_parity.py run_case(forward_extras=False)): the forward
+            # then computes exactly the function the single-rounded fp16 backward differentiates.  Set before the first forward.
+            neuconw.color_net.ray_bias = False
+            neuconw.color_net.weight_split = False
+            nerf.ray_bias = False
+            nerf.refine = False
+            neuconw.sdf_net.adj_split = False
+            if hasattr(neuconw.sdf_net, "tangent"):
+                neuconw.sdf_net.tangent = False
         step_fn = nw.TrainStep(rdr, [emb, neuconw, nerf], bench.loss_fn, lr=args.lr, eps=1e-7, clip=0.99)
         g = torch.Generator(device=dev)
-        g.manual_seed(99)
+        g.manual_seed(100 if name == "f32b" else 99)
         bg = torch.zeros(1, 3, device=dev)
         log = []
         t0 = time.perf_counter()
@@ -82,10 +93,11 @@ def main():
             if it % args.log_every == 0 or it == args.steps:
                 pv = psnr(render_colors(rdr, rays_v, ts_v, label_v), target_v)
                 inv_s = float(torch.exp(neuconw.deviation_network.variance.detach() * 10.0))
-                log.append({"step": it, "psnr_heldout": round(pv, 3), "inv_s": round(inv_s, 2),
+                log.append({"step": it, "psnr_heldout": round(pv, 3), "inv_s": round(inv_s, 4),
+                            "variance": float(neuconw.deviation_network.variance.detach()),
                             "loss": None if it == 0 else round(float(loss.detach()), 5),
                             "skipped": int(getattr(step_fn.opt, "skipped_steps", 0)),
-                            "loss_scale": float(rdr.grad_scale) if name == "f16" else None})
+                            "loss_scale": float(rdr.grad_scale) if name.startswith("f16") else None})
                 print("%s step %5d  held-out PSNR %.3f dB  inv_s %.1f  loss %s  skipped %d" %
                       (name, it, pv, inv_s, log[-1]["loss"], log[-1]["skipped"]), flush=True)
             if it == args.steps:

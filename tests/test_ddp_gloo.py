@@ -1,5 +1,5 @@
-"""Multi-process (world_size 2, gloo, CPU) check of the gradient exchange used by bench.py --gpus N:
-one flat all-reduce, mean over ranks, parameters without gradients skipped consistently."""
+"""Multi-process (world_size 2, gloo, CPU) check of the gradient exchange used by bench.py --gpus N and scripts/train.py
+(trainer.FlatParams): one broadcast, one flat all-reduce per step, mean over ranks, replicas bit-identical."""
 import os
 import socket
 
@@ -14,62 +14,6 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
-
-
-def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from neuralrecon_w_amd import ddp
-
-    torch.manual_seed(rank)  # different initial params per rank -> broadcast must fix it
-    lin = torch.nn.Linear(5, 3)
-    dead = torch.nn.Linear(2, 2)  # never gets a gradient (reference's dead layers)
-    ddp.broadcast_params([lin, dead])
-    g = torch.Generator().manual_seed(100 + rank)
-    x = torch.randn(4, 5, generator=g)
-    lin(x).sum().backward()
-    local = [p.grad.clone() for p in lin.parameters()]
-    params = list(lin.parameters()) + list(dead.parameters())
-    # second module whose .grad tensors are views of ONE persistent flat buffer (the renderer's layout)
-    lin2 = torch.nn.Linear(3, 2)
-    ddp.broadcast_params([lin2])
-    flat = torch.zeros(sum(p.numel() for p in lin2.parameters()))
-    off = 0
-    for p in lin2.parameters():
-        p.grad = flat[off:off + p.numel()].view(p.shape)
-        p.grad.fill_(float(rank + 1))
-        off += p.numel()
-    ddp.allreduce_grads(params + list(lin2.parameters()), world, flat_buffers=[flat])
-    assert torch.allclose(flat, torch.full_like(flat, 1.5)), flat  # mean of 1 and 2, reduced in place
-    assert all(p.grad.data_ptr() >= flat.data_ptr() for p in lin2.parameters())
-    tl = lambda ts: [t.detach().reshape(-1).tolist() for t in ts]  # noqa: E731  (plain lists cross the queue)
-    q.put((rank, tl(lin.parameters()), tl(local), tl([p.grad for p in lin.parameters()]),
-           [p.grad is None for p in dead.parameters()]))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_allreduce_grads_world2():
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    (_, p0, l0, g0, d0), (_, p1, l1, g1, d1) = res
-    T = torch.tensor
-    for a, b in zip(p0, p1):
-        assert torch.equal(T(a), T(b))  # broadcast made the replicas identical
-    for a, b, m0, m1 in zip(l0, l1, g0, g1):
-        assert torch.allclose(T(m0), (T(a) + T(b)) / 2) and torch.equal(T(m0), T(m1))
-    assert all(d0) and all(d1)
 
 
 def _worker_flat(rank, world, port, q):
