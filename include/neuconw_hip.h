@@ -480,6 +480,16 @@ int ncw_voxel_build(const float* pts_normalised, int64_t n, int level, uint32_t*
 int ncw_ray_voxel_near_far(const float* rays_o_sfm, const float* rays_d, int R, const float* scene_origin_host,
                            float scale, int level, const uint32_t* occ, const uint32_t* brick, float* near_sfm,
                            float* far_sfm, void* stream);
+/* kaolin.render.spc.unbatched_raytrace(octree, points, pyramid, prefix, origin, direction, level, return_depth=True,
+ * with_exit=...) as tools/prepare_data/generate_voxel.py:358-368 calls it: EVERY intersection of a ray with an occupied
+ * level-`level` voxel (a "nugget"), ordered by ray, then by depth.  Origins are already normalised to the cube [-1,1]^3
+ * (generate_voxel.py:345) and nothing is added to them.  Two calls: offsets == NULL writes counts[R] (nuggets per ray); with
+ * offsets[R] (their exclusive prefix sum) ray r writes nug_ray / nug_voxel (linear index (x 2^level + y) 2^level + z) /
+ * nug_depth [N,2] = (entry, exit) depth along the direction as given, from offsets[r] on.  (compat/kaolin maps the voxel
+ * index to kaolin's point-hierarchy index.) */
+int ncw_ray_voxel_trace(const float* rays_o_norm, const float* rays_d, int R, int level, const uint32_t* occ,
+                        const uint32_t* brick, const int32_t* offsets, int32_t* counts, int32_t* nug_ray,
+                        int32_t* nug_voxel, float* nug_depth, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Compositor: renderer.py:205-216 (background alpha) + :586-783 (render_core after the networks).

@@ -11,6 +11,56 @@ import math
 import torch
 
 from . import lib as L
+from . import spc
+
+
+class OctreeData(dict):
+    """`renderer.octree_data` / `renderer.fine_octree_data`.  Holds what the HIP kernels read (`occ` / `brick` bit masks) beside
+    the reference's keys (`scene_origin`, `scale`, `level`, `voxel_size`).  The reference's kaolin-format members -- `octree`
+    (generate_voxel.py:150) and `spc_data` = {points, pyramid, prefix} (neuconw_system.py:300-305) -- are derived on first
+    access, so code written against the reference's dictionaries (its `surface_selection`, `convert_to_dense`, checkpointing of
+    the octree) finds them, and a training step never pays for them."""
+
+    def __missing__(self, key):
+        if key in ("octree", "spc_data") and "occ" in self:
+            q = voxels_from_occupancy(self)
+            octree = spc.unbatched_points_to_octree(q, int(self["level"]))
+            _, pyramid, prefix = spc.scan_octrees(octree, torch.tensor([octree.shape[0]], dtype=torch.int32))
+            self["octree"] = octree
+            self["spc_data"] = {"points": spc.generate_points(octree, pyramid, prefix), "pyramid": pyramid[0], "prefix": prefix}
+            return self[key]
+        if key in ("occ", "brick") and "octree" in self:
+            ensure_occupancy(self)
+            return self[key]
+        raise KeyError(key)
+
+
+def ensure_occupancy(octree_data):
+    """A dictionary in the REFERENCE's format (built by its own `gen_octree` / `octree_update` over compat/kaolin: `octree`
+    + optionally `spc_data`, no bit masks) gets the `occ` / `brick` masks the kernels read, once."""
+    if dict.__contains__(octree_data, "occ"):
+        return octree_data
+    octree, level = octree_data["octree"], int(octree_data["level"])
+    sd = octree_data.get("spc_data") if dict.__contains__(octree_data, "spc_data") else None
+    if sd is None:
+        _, pyramid, prefix = spc.scan_octrees(octree, torch.tensor([octree.shape[0]], dtype=torch.int32))
+        points, pyramid = spc.generate_points(octree, pyramid, prefix), pyramid[0]
+    else:
+        points, pyramid = sd["points"], sd["pyramid"]
+    q, _, _ = spc.level_points(points, pyramid, level)
+    octree_data["occ"], octree_data["brick"] = spc.occupancy_bits(q, level)
+    return octree_data
+
+
+def voxels_from_occupancy(octree_data):
+    """Integer coordinates [K, 3] (x, y, z; lexicographic) of the occupied voxels, decoded from the non-zero words only."""
+    occ = ensure_occupancy(octree_data)["occ"]
+    G = 1 << int(octree_data["level"])
+    w = occ.nonzero().reshape(-1)
+    bits = (occ[w].view(-1, 1) >> torch.arange(32, device=occ.device, dtype=torch.int32).view(1, 32)) & 1
+    hit = bits.nonzero()
+    lin = w[hit[:, 0]] * 32 + hit[:, 1]
+    return torch.stack([lin // (G * G), (lin // G) % G, lin % G], -1)
 
 
 def occupancy_from_points(points_sfm, scene_origin, scale, level, voxel_size=None):
@@ -27,8 +77,8 @@ def occupancy_from_points(points_sfm, scene_origin, scale, level, voxel_size=Non
     brick = torch.zeros((gb ** 3 + 31) // 32, dtype=torch.int32, device=dev)
     L.check(L.get_lib().ncw_voxel_build(L.ptr(pn), pn.shape[0], level, L.ptr(occ), L.ptr(brick), L.stream_ptr(dev)),
             "ncw_voxel_build")
-    return {"occ": occ, "brick": brick, "scene_origin": origin, "scale": float(scale), "level": int(level),
-            "voxel_size": float(voxel_size) if voxel_size is not None else 2.0 * float(scale) / G}
+    return OctreeData({"occ": occ, "brick": brick, "scene_origin": origin, "scale": float(scale), "level": int(level),
+                       "voxel_size": float(voxel_size) if voxel_size is not None else 2.0 * float(scale) / G})
 
 
 def occupancy_from_dense(dense_bool, scene_origin, scale, voxel_size=None):
@@ -120,6 +170,7 @@ def get_near_far(rays_o_sfm, rays_d, octree_data):
     d = rays_d.contiguous().float()
     near = torch.empty(R, device=dev, dtype=torch.float32)
     far = torch.empty(R, device=dev, dtype=torch.float32)
+    ensure_occupancy(octree_data)
     so_host = octree_data.get("_scene_origin_host")
     if so_host is None:  # one device->host read per octree, not per step
         so = octree_data["scene_origin"]
@@ -141,7 +192,7 @@ def get_near_far(rays_o_sfm, rays_d, octree_data):
 def dense_from_occupancy(octree_data):
     """[G,G,G] bool (x slowest) from the bit mask: generate_voxel.py:181-186 `convert_to_dense`."""
     G = 1 << int(octree_data["level"])
-    occ = octree_data["occ"]
+    occ = ensure_occupancy(octree_data)["occ"]
     bits = (occ.view(-1, 1) >> torch.arange(32, device=occ.device, dtype=torch.int32).view(1, 32)) & 1
     return bits.reshape(-1)[: G * G * G].bool().view(G, G, G)
 
@@ -184,7 +235,7 @@ def surface_selection(renderer, train_level, threshold, chunk=1 << 22, group=Non
     od = renderer.octree_data
     if od is None:
         od = renderer.octree_data = renderer.get_octree(renderer.origin.device)
-    dev = od["occ"].device
+    dev = ensure_occupancy(od)["occ"].device
     level = int(od["level"])
     octree_origin = od["scene_origin"].float().to(dev).reshape(3)
     octree_scale = float(od["scale"])

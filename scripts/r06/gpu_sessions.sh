@@ -18,5 +18,17 @@ s1() {  # trained-weights parity point of the SHIPPED shape for the CPU emulatio
   done
 }
 
+s2() {  # (s1 skipped the parity legs with --no-cpu-baseline: the trained state is written by the parity leg)
+  for S in 1000 2000 3000; do
+    timeout -k 10 400 python bench.py --no-pmc --no-parity-mode --config shipped --seed $S --save-trained-state $OUT/trained_shipped_seed$S.pt > $OUT/bench_shipped_seed$S.json 2>$OUT/bench_shipped_seed$S.err; echo "shipped seed $S rc $?"
+  done
+}
+
+s3() {  # s2 again on a consistent build + the new voxel / kaolin-boundary tests
+  s2
+  timeout -k 10 900 python -m pytest tests/test_gpu_voxel.py tests/test_gpu_octree_refresh.py tests/test_gpu_mesh.py tests/test_gpu_trainer.py tests/test_compat_kaolin.py tests/test_octree_from_sfm.py -x -q -s -m "gpu or not gpu" > $OUT/voxel_tests.log 2>&1; echo "voxel tests rc $?"
+  tail -5 $OUT/voxel_tests.log
+}
+
 "$NAME"
 ls -la $OUT

@@ -53,3 +53,23 @@ def synth_rays(R, seed, n_vocab, dtype=torch.float32):
     label = torch.where(torch.rand(R, generator=g) < 0.1, torch.tensor(2), torch.tensor(0))
     rgbs = torch.rand(R, 3, generator=g).to(dtype)
     return rays, ts, label, rgbs
+
+
+def compat_kaolin():
+    """(kaolin.ops.spc, kaolin.render.spc) of compat/kaolin, whatever `kaolin` currently is in sys.modules (oracle/ref_import.py
+    parks MagicMock stubs there for the reference imports of other tests): imported under a clean slate, previous entries restored."""
+    import importlib
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "kaolin" or k.startswith("kaolin.")}
+    sys.path.insert(0, os.path.join(root, "compat"))
+    try:
+        ops_spc = importlib.import_module("kaolin.ops.spc")
+        render_spc = importlib.import_module("kaolin.render.spc")
+    finally:
+        sys.path.remove(os.path.join(root, "compat"))
+        for k in [k for k in sys.modules if k == "kaolin" or k.startswith("kaolin.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    return ops_spc, render_spc
