@@ -123,7 +123,7 @@ typedef struct NcwSdfNet {
     int32_t rb;           /* hidden width / 32 (2, 8 or 16)                 */
     int32_t multires;     /* 6                                              */
     float scale;          /* SDFNetwork.scale                               */
-    int32_t _pad;
+    int32_t adj_mode;     /* with wt_lo present: 2 = the adjoint sweep's t_l as a hi + lo pair too (rb = 16: see wt_lo below); 0 / 1 = weights only */
     /* Split-precision VALUE path (fp16 mode, W = 256): w_lo[l] = the rounding residuals of w[l] in the same packed layout
      * (NcwPackDesc.residual), or all NULL.  When present, ncw_sdf_infer* and the forward sweep of ncw_sdf_fwd evaluate
      * sdf with activations AND weights as fp16 hi + lo pairs, three MFMAs per product (hi.hi + lo.hi + hi.lo, f32
@@ -137,7 +137,9 @@ typedef struct NcwSdfNet {
      * two MFMAs per product; t stays single fp16): the compositor multiplies the normal's component along the ray by
      * dist * inv_s inside the sigmoid (rendering/renderer.py:600-632), and on trained weights the plain-fp16 adjoint sweep was
      * what put single rays above 1e-4 (scripts/diag/emul_timed_batch.py: worst rays 1.5e-4 -> 3.7e-5).  Forward only: the stash
-     * t_l, ncw_sdf_bwd and the weight gradients are unchanged. */
+     * t_l, ncw_sdf_bwd and the weight gradients are unchanged.  adj_mode = 2 (rb = 16, the shipped W = 512): t_l is a hi + lo pair
+     * as well (three MFMAs per product, the value chain's accuracy): with 8 + 16 samples per ray one sample carries a ray and
+     * the colour network reads ITS normal -- the weights alone as pairs were not enough there (profiles/r06/emul_timed_batch_shipped_tangent*.log). */
     const void* wt_lo[NCW_MAX_LAYERS];
 } NcwSdfNet;
 
@@ -231,6 +233,11 @@ typedef struct NcwColorNet {
      * weights the colour network's weight rounding was the largest remaining term of the fp16 mode's colour error
      * (scripts/diag/emul_color16.py: 5 % of the rays above 1e-4 -> none). */
     const void* w_f_lo; const void* w_e_lo[4]; const void* w_l_lo[8];
+    /* with the residual matrices present: 1 = the ACTIVATIONS of every layer as fp16 hi + lo pairs too (a third pass W_hi x_lo; rbf
+     * 8 / 16 only).  Default at d_feature = 512, the shipped width: with 8 + 16 samples one sample carries a ray and the
+     * activations' rounding was, with the normals', what kept rays above 1e-4 on trained weights (ncw_color.hip).  Forward only. */
+    int32_t act_split;
+    int32_t _pad;
 } NcwColorNet;
 
 typedef struct NcwColorStash {

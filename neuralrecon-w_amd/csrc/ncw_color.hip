@@ -36,11 +36,45 @@ NCW_DEV void mma_stream_split(CVec<RB_OUT>& acc, const Act<P, RB_IN>& in, WRing&
     }
 }
 
-template <class P, int RBF, int RBH, int RBC>
+// hi = h16(x) and lo = h16(x - h16(x)) of one block of a C-layout vector as B fragments: an fp16 hi + lo ACTIVATION pair.  Block by
+// block, so that the f32 block dies as soon as its two fragments exist (RBF = 16: 256 accumulators next to 2 x 128 fragment registers)
+template <class P, int RB>
+NCW_DEV void to_act_block_hl(Act<P, RB>& hi, Act<P, RB>& lo, int rb, const f32x16& v) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) ncw_split8(v, t, hi.f[2 * rb + t], lo.f[2 * rb + t]);  // (ONE conversion per element: ncw_common.h)
+}
+
+// relu_epilogue that also leaves the lo halves of the post-activations (ASPLIT; the stash keeps the single-rounded values)
+template <class P, int RB>
+NCW_DEV void relu_epilogue_hl(Act<P, RB>& act, Act<P, RB>& act_lo, CVec<RB>& acc, typename P::selem* st, size_t tile, int lane) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        f32x16 yv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[r] = ncw_relu(acc.v[rb][r]);
+        if (st) stash_store_block(st, tile, RB, rb, yv, lane);
+        to_act_block_hl<P, RB>(act, act_lo, rb, yv);
+    }
+}
+
+// acc += W_hi in + W_lo in + W_hi in_lo: weights AND activations as fp16 hi + lo pairs, three passes of the weight ring
+// (round 6, ASPLIT).  Chaining like mma_stream_split: self_bytes = first-chunk bytes of this matrix shape.
+template <int RB_IN, int RB_OUT, int K_REAL, int SLOT, class P>
+NCW_DEV void mma_stream_split3(CVec<RB_OUT>& acc, const Act<P, RB_IN>& in, const Act<P, RB_IN>& in_lo, WRing& ring,
+                               const typename P::welem* __restrict__ w_hi, const void* w_lo, int self_bytes, const void* w_next,
+                               int next_bytes, int lane) {
+    typedef typename P::welem WE;
+    mma_stream<RB_IN, RB_OUT, K_REAL, SLOT>(acc, in, ring, w_hi, w_lo, self_bytes, lane);
+    mma_stream<RB_IN, RB_OUT, K_REAL, SLOT>(acc, in, ring, (const WE*)w_lo, w_hi, self_bytes, lane);
+    mma_stream<RB_IN, RB_OUT, K_REAL, SLOT>(acc, in_lo, ring, w_hi, w_next, next_bytes, lane);
+}
+
+template <class P, int RBF, int RBH, int RBC, bool WIDE = false>
 struct ColShapes {
     // both colour kernels fit 256 registers at d_feature = 256: 2 workgroups / CU; with a 512-wide feature
-    // vector (RBF = 16: 256 accumulators for xyz_encoding_final alone) they own the CU like the SDF forward
-    static constexpr int OCC = RBF >= 16 ? 1 : 2;
+    // vector (RBF = 16: 256 accumulators for xyz_encoding_final alone) they own the CU like the SDF forward -- and so does the
+    // forward with hi + lo ACTIVATIONS at any width (WIDE: 64 more live registers per trunk layer)
+    static constexpr int OCC = (RBF >= 16 || WIDE) ? 1 : 2;
     static constexpr int SLOT = RingSlot<RBC, OCC>::bytes;
     static constexpr int FCB_F = ncw_first_chunk_bytes<P, RBF, 32 * RBF, RBF, SLOT>();
     static constexpr int FCB_E0 = ncw_first_chunk_bytes<P, RBF + 3, 32 * RBF + 96, RBH, SLOT>();
@@ -55,14 +89,19 @@ struct ColShapes {
 
 // TRAIN = false (color_render_kernel): the forward-only render -- the same arithmetic bit for bit, NOTHING is stashed
 // (validation / novel views / vertex colours: rendering/renderer.py:785-916 under no_grad, :951-961 `rgb`).
-template <class P, int RBF, int RBH, int RBC, bool SPLIT, bool TRAIN>
+// SPLIT 1: weights as fp16 hi + lo pairs (+ lin0's [points | normals] inputs); 2 (round 6): the ACTIVATIONS of every layer as pairs
+// too (f, the head's and the trunk's post-activations: a third pass W_hi x_lo per layer) -- at the shipped shape (W = 512, 8 + 16
+// samples: one sample carries a ray) their rounding was, with the normals, what kept 2 % of the rays above 1e-4 on trained weights
+// (profiles/r06/emul_timed_batch_shipped_tangent*.log: 1.2e-4 -> 2e-5 once both are pairs).  Forward only, like SPLIT 1.
+template <class P, int RBF, int RBH, int RBC, int SPLIT, bool TRAIN>
 NCW_DEV void color_fwd_body(const NcwColorNet& net, const NcwPoints& src, int64_t n, const float* __restrict__ normals,
                             const float* __restrict__ a, const void* __restrict__ feat_stash, float* __restrict__ rgb,
                             const NcwColorStash& st) {
     typedef typename P::welem WE;
     typedef typename P::selem SE;
     auto stp = [](void* p) -> SE* { return TRAIN ? (SE*)p : nullptr; };  // compile-time null: the helpers' `if (st)` folds away
-    typedef ColShapes<P, RBF, RBH, RBC> SH;
+    typedef ColShapes<P, RBF, RBH, RBC, SPLIT == 2> SH;
+    constexpr bool AS = SPLIT == 2;
     NCW_RING_DECL(SH::SLOT);
     const int lane = ncw_lane();
     ring_prologue(ring, net.w_f, SH::FCB_F);
@@ -84,15 +123,21 @@ NCW_DEV void color_fwd_body(const NcwColorNet& net, const NcwPoints& src, int64_
         // zero (the stash above keeps the real one for the backward and the weight gradients)
         if (st.aux_bias != nullptr) ncw_act_zero3(aux1a);
     }
-    Act<P, 1> aux2a;
+    Act<P, 1> aux2a, aux2lo;  // (SPLIT: [points | normals] as an fp16 hi + lo pair, ONE conversion per element: ncw_common.h ncw_split8)
     {
         CVec<1> aux2;
         build_aux2(aux2, xs, nrm, lane);
         if (TRAIN) stash_store<1>((SE*)st.aux2, tile, aux2, lane);
-        to_act(aux2a, aux2);
+        if constexpr (SPLIT != 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) ncw_split8(aux2.v[0], t, aux2a.f[t], aux2lo.f[t]);
+        } else {
+            to_act(aux2a, aux2);
+        }
     }
     // f = xyz_encoding_final(feat)   (no activation, neuconw.py:128,136)
     Act<P, RBF + 3> cat1;
+    Act<P, (AS ? RBF + 3 : 1)> cat1_lo;  // (AS) [lo(f) | 0]
     {
         Act<P, RBF> fin;
 #pragma unroll
@@ -103,15 +148,26 @@ NCW_DEV void color_fwd_body(const NcwColorNet& net, const NcwPoints& src, int64_
         }
         CVec<RBF> f;
         load_bias(f, net.b_f, lane);
-        mma_stream_split<SPLIT, RBF, RBF, 32 * RBF, SH::SLOT>(f, fin, ring, (const WE*)net.w_f, net.w_f_lo, SH::FCB_F, net.w_e[0],
-                                                         SH::FCB_E0, lane);
+        mma_stream_split<(SPLIT != 0), RBF, RBF, 32 * RBF, SH::SLOT>(f, fin, ring, (const WE*)net.w_f, net.w_f_lo, SH::FCB_F, net.w_e[0],
+                                                                SH::FCB_E0, lane);
         if (TRAIN) stash_store<RBF>((SE*)st.f, tile, f, lane);
-        Act<P, RBF> fa;
-        to_act(fa, f);
-        act_concat<RBF, 3>(cat1, fa, aux1a);
+        if constexpr (AS) {
+            Act<P, RBF> fa, fl;
+#pragma unroll
+            for (int rb = 0; rb < RBF; ++rb) to_act_block_hl<P, RBF>(fa, fl, rb, f.v[rb]);
+            act_concat<RBF, 3>(cat1, fa, aux1a);
+            Act<P, 3> z3;
+            ncw_act_zero3(z3);
+            act_concat<RBF, 3>(cat1_lo, fl, z3);
+        } else {
+            Act<P, RBF> fa;
+            to_act(fa, f);
+            act_concat<RBF, 3>(cat1, fa, aux1a);
+        }
     }
     // appearance head (neuconw.py:111-127,137-140)
     Act<P, RBH> ea;
+    Act<P, (AS ? RBH : 1)> ea_lo;
     {
         CVec<RBH> e;
         load_bias(e, net.b_e[0], lane);
@@ -119,27 +175,43 @@ NCW_DEV void color_fwd_body(const NcwColorNet& net, const NcwPoints& src, int64_
         if (st.aux_bias != nullptr) ncw_add_ray_bias<RBH>(e, st.aux_bias + ray * (32 * RBH), lane);
         const void* wn = net.n_head > 1 ? net.w_e[1] : net.w_l[0];
         const int nb = net.n_head > 1 ? SH::FCB_E : SH::FCB_L0;
-        mma_stream_split<SPLIT, RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e[0], net.w_e_lo[0], SH::FCB_E0, wn,
-                                                                  nb, lane);
-        relu_epilogue<P, RBH>(ea, e, stp(st.e[0]), tile, lane);
+        if constexpr (AS) {
+            // (the lo operand's AUX1 blocks are zero: its pass stops after the f columns -- same first chunk, fewer units)
+            static_assert(ncw_first_chunk_bytes<P, RBF + 3, 32 * RBF, RBH, SH::SLOT>() == SH::FCB_E0, "lo pass: same first chunk");
+            mma_stream<RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e[0], net.w_e_lo[0], SH::FCB_E0, lane);
+            mma_stream<RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e_lo[0], net.w_e[0], SH::FCB_E0, lane);
+            mma_stream<RBF + 3, RBH, 32 * RBF, SH::SLOT>(e, cat1_lo, ring, (const WE*)net.w_e[0], wn, nb, lane);
+            relu_epilogue_hl<P, RBH>(ea, ea_lo, e, stp(st.e[0]), tile, lane);
+        } else {
+            mma_stream_split<(SPLIT != 0), RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e[0], net.w_e_lo[0],
+                                                                             SH::FCB_E0, wn, nb, lane);
+            relu_epilogue<P, RBH>(ea, e, stp(st.e[0]), tile, lane);
+        }
         for (int i = 1; i < net.n_head; ++i) {
             load_bias(e, net.b_e[i], lane);
             const void* wn2 = i + 1 < net.n_head ? net.w_e[i + 1] : net.w_l[0];
             const int nb2 = i + 1 < net.n_head ? SH::FCB_E : SH::FCB_L0;
-            mma_stream_split<SPLIT, RBH, RBH, 32 * RBH, SH::SLOT>(e, ea, ring, (const WE*)net.w_e[i], net.w_e_lo[i], SH::FCB_E, wn2, nb2,
-                                                             lane);
-            relu_epilogue<P, RBH>(ea, e, stp(st.e[i]), tile, lane);
+            if constexpr (AS) {
+                mma_stream_split3<RBH, RBH, 32 * RBH, SH::SLOT>(e, ea, ea_lo, ring, (const WE*)net.w_e[i], net.w_e_lo[i], SH::FCB_E, wn2,
+                                                                nb2, lane);
+                relu_epilogue_hl<P, RBH>(ea, ea_lo, e, stp(st.e[i]), tile, lane);
+            } else {
+                mma_stream_split<(SPLIT != 0), RBH, RBH, 32 * RBH, SH::SLOT>(e, ea, ring, (const WE*)net.w_e[i], net.w_e_lo[i], SH::FCB_E,
+                                                                        wn2, nb2, lane);
+                relu_epilogue<P, RBH>(ea, e, stp(st.e[i]), tile, lane);
+            }
         }
     }
     // trunk (neuconw.py:158-166)
     Act<P, RBC> xa;
+    Act<P, (AS ? RBC : 1)> xa_lo;
     CVec<RBC> x;
     const int last = net.n_lin - 1;
     {
         Act<P, RBH + 1> cat2;
         act_concat<RBH, 1>(cat2, ea, aux2a);
         load_bias(x, net.b_l[0], lane);
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT != 0) {
             // lin0 takes [points | normals | e] (models/neuconw.py:147-148,158): with the weights as hi + lo pairs the remaining coherent
             // term on trained weights was the fp16 rounding of POINTS and NORMALS themselves (scripts/diag/emul_timed_batch.py
             // --candidates: a surface ray at 8.8e-5 -> 1.3e-5).  Third pass of the ring: W_hi . lo([p | n]) -- the e blocks of the
@@ -147,38 +219,43 @@ NCW_DEV void color_fwd_body(const NcwColorNet& net, const NcwPoints& src, int64_
             const int nxt = 1 == last ? SH::FCB_LAST : SH::FCB_L;
             mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l_lo[0], SH::FCB_L0, lane);
             mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l_lo[0], net.w_l[0], SH::FCB_L0, lane);
-            {
-                CVec<1> aux2;
-                build_aux2(aux2, xs, nrm, lane);
 #pragma unroll
-                for (int i = 0; i < 2 * RBH; ++i)
+            for (int i = 0; i < 2 * RBH; ++i)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) cat2.f[i][e] = (ncw_h16)0.f;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = aux2.v[0][8 * t + e];
-                        cat2.f[2 * RBH + t][e] = (ncw_h16)(v - (float)(ncw_h16)v);
-                    }
-            }
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (AS) cat2.f[i][e] = ea_lo.f[i][e];  // (AS: the head's output as a pair too)
+                    else cat2.f[i][e] = (ncw_h16)0.f;
+                }
+            cat2.f[2 * RBH] = aux2lo.f[0];
+            cat2.f[2 * RBH + 1] = aux2lo.f[1];
             mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l[1], nxt, lane);
         } else {
             mma_stream_split<false, RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l_lo[0], SH::FCB_L0,
                                                                           net.w_l[1], 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
         }
-        relu_epilogue<P, RBC>(xa, x, stp(st.x[0]), tile, lane);
+        if constexpr (AS) relu_epilogue_hl<P, RBC>(xa, xa_lo, x, stp(st.x[0]), tile, lane);
+        else relu_epilogue<P, RBC>(xa, x, stp(st.x[0]), tile, lane);
     }
     for (int l = 1; l < last; ++l) {
         load_bias(x, net.b_l[l], lane);
-        mma_stream_split<SPLIT, RBC, RBC, 32 * RBC, SH::SLOT>(x, xa, ring, (const WE*)net.w_l[l], net.w_l_lo[l], SH::FCB_L, net.w_l[l + 1],
-                                                        l + 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
-        relu_epilogue<P, RBC>(xa, x, stp(st.x[l]), tile, lane);
+        if constexpr (AS) {
+            mma_stream_split3<RBC, RBC, 32 * RBC, SH::SLOT>(x, xa, xa_lo, ring, (const WE*)net.w_l[l], net.w_l_lo[l], SH::FCB_L,
+                                                            net.w_l[l + 1], l + 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
+            relu_epilogue_hl<P, RBC>(xa, xa_lo, x, stp(st.x[l]), tile, lane);
+        } else {
+            mma_stream_split<(SPLIT != 0), RBC, RBC, 32 * RBC, SH::SLOT>(x, xa, ring, (const WE*)net.w_l[l], net.w_l_lo[l], SH::FCB_L,
+                                                                    net.w_l[l + 1], l + 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);
+            relu_epilogue<P, RBC>(xa, x, stp(st.x[l]), tile, lane);
+        }
     }
     CVec<1> o;
     load_bias(o, net.b_l[last], lane);
-    mma_stream_split<SPLIT, RBC, 1, 32 * RBC, SH::SLOT>(o, xa, ring, (const WE*)net.w_l[last], net.w_l_lo[last], SH::FCB_LAST, nullptr, 0,
-                                                  lane);
+    if constexpr (AS)
+        mma_stream_split3<RBC, 1, 32 * RBC, SH::SLOT>(o, xa, xa_lo, ring, (const WE*)net.w_l[last], net.w_l_lo[last], SH::FCB_LAST,
+                                                      nullptr, 0, lane);
+    else
+        mma_stream_split<(SPLIT != 0), RBC, 1, 32 * RBC, SH::SLOT>(o, xa, ring, (const WE*)net.w_l[last], net.w_l_lo[last], SH::FCB_LAST,
+                                                              nullptr, 0, lane);
     if (valid && lane < 32) {  // features 0,1,2 <-> registers 0,1,2 of half 0; sigmoid (neuconw.py:168-169)
         rgb[p * 3 + 0] = sigmoidf_<Fast<P>::v>(o.v[0][0]);
         rgb[p * 3 + 1] = sigmoidf_<Fast<P>::v>(o.v[0][1]);
@@ -186,16 +263,16 @@ NCW_DEV void color_fwd_body(const NcwColorNet& net, const NcwPoints& src, int64_
     }
 }
 
-template <class P, int RBF, int RBH, int RBC, bool SPLIT = false>
-__global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_fwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
+template <class P, int RBF, int RBH, int RBC, int SPLIT = 0>
+__global__ __launch_bounds__(64 * NCW_WG_WAVES, ((RBF >= 16 || SPLIT == 2) ? 1 : 2)) void color_fwd_kernel(NcwColorNet net, NcwPoints src, int64_t n,
                                                                       const float* __restrict__ normals,
                                                                       const float* __restrict__ a,
                                                                       const void* __restrict__ feat_stash,
                                                                       float* __restrict__ rgb, NcwColorStash st) {
     color_fwd_body<P, RBF, RBH, RBC, SPLIT, true>(net, src, n, normals, a, feat_stash, rgb, st);
 }
-template <class P, int RBF, int RBH, int RBC, bool SPLIT = false>
-__global__ __launch_bounds__(64 * NCW_WG_WAVES, (RBF >= 16 ? 1 : 2)) void color_render_kernel(NcwColorNet net, NcwPoints src, int64_t n,
+template <class P, int RBF, int RBH, int RBC, int SPLIT = 0>
+__global__ __launch_bounds__(64 * NCW_WG_WAVES, ((RBF >= 16 || SPLIT == 2) ? 1 : 2)) void color_render_kernel(NcwColorNet net, NcwPoints src, int64_t n,
                                                                          const float* __restrict__ normals,
                                                                          const float* __restrict__ a,
                                                                          const void* __restrict__ feat_stash,
@@ -340,16 +417,27 @@ extern "C" int NCW_FN(ncw_color_fwd)(const NcwColorNet* net, int prec, const Ncw
         const int key = net->rbf * 10000 + net->rbh * 100 + net->rbc;
         for (int i = 0; i < net->n_head; ++i) if (net->w_e_lo[i] == nullptr) return NCW_E_BADARG;
         for (int l = 0; l < net->n_lin; ++l) if (net->w_l_lo[l] == nullptr) return NCW_E_BADARG;
-#define NCW_COLOR_SPLIT_DISPATCH(KERNEL)                                                                                                     \
+#define NCW_COLOR_SPLIT_DISPATCH(KERNEL, S)                                                                                               \
         do {                                                                                                                                    \
-            if (key == 20102) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 2, 1, 2, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);        \
-            else if (key == 20408) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 2, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);   \
-            else if (key == 80408) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 8, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);   \
-            else if (key == 160408) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 16, 4, 8, true>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash); \
+            if (key == 20102) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 2, 1, 2, S>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);        \
+            else if (key == 20408) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 2, 4, 8, S>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);   \
+            else if (key == 80408) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 8, 4, 8, S>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);   \
+            else if (key == 160408) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 16, 4, 8, S>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash); \
             else return NCW_E_UNSUPPORTED;                                                                                                      \
         } while (0)
-        if (render) NCW_COLOR_SPLIT_DISPATCH(color_render_kernel);
-        else NCW_COLOR_SPLIT_DISPATCH(color_fwd_kernel);
+        if (net->act_split) {  // the activations as hi + lo pairs too (the two widths that ship: d_feature 256 / 512)
+#define NCW_COLOR_ASPLIT_DISPATCH(KERNEL)                                                                                                  \
+        do {                                                                                                                                    \
+            if (key == 80408) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 8, 4, 8, 2>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash);        \
+            else if (key == 160408) NCW_LAUNCH_TILES((KERNEL<PrecBF16, 16, 4, 8, 2>), n, st, *net, *pts, n, normals, a, feat_stash, rgb, *stash); \
+            else return NCW_E_UNSUPPORTED;                                                                                                      \
+        } while (0)
+            if (render) NCW_COLOR_ASPLIT_DISPATCH(color_render_kernel);
+            else NCW_COLOR_ASPLIT_DISPATCH(color_fwd_kernel);
+            return 0;
+        }
+        if (render) NCW_COLOR_SPLIT_DISPATCH(color_render_kernel, 1);
+        else NCW_COLOR_SPLIT_DISPATCH(color_fwd_kernel, 1);
         return 0;
     }
     if (render) NCW_COLOR_DISPATCH(color_render_kernel, *net, *pts, n, normals, a, feat_stash, rgb, *stash);

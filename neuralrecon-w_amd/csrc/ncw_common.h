@@ -439,6 +439,57 @@ NCW_DEV void softplus100(float z, float& y, float& s) {
     }
 }
 
+// fp16 hi + lo images of accumulator registers 8 t .. 8 t + 7 (one k-unit of a B operand): x ~= hi + lo to 2^-22.
+// lo MUST be the residual of the hi bits that are stored.  Written naively -- h = (half)x; hi = h; lo = (half)(x - (float)h) -- hipcc
+// converts twice, v_cvt_pk_f16_f32 for the stored fragment and v_cvt_f16_f32 for the residual, and on gfx950 the two do not round an
+// EXACT TIE the same way: the pair is then one whole fp16 ulp off (measured, round 6: one point in ~16 k with 5.5e-5 on the SDF where
+// every other point is at 8e-7; profiles/r06/tunits_bisect.log).  The empty asm pins the PACKED pair (one v_cvt_pk_f16_f32 per two
+// elements, as hipcc emits for the fragment anyway): one conversion, the residuals read its halves back (v_cvt_f32_f16 / _sdwa).
+typedef ncw_h16 ncw_h16x2 __attribute__((ext_vector_type(2)));
+// one PAIR: (x0, x1) -> packed hi (ONE v_cvt_pk_f16_f32, pinned) and the two residuals read back from it
+NCW_DEV void ncw_split2(float x0, float x1, ncw_h16& h0, ncw_h16& h1, ncw_h16& l0, ncw_h16& l1) {
+    ncw_h16x2 p = {(ncw_h16)x0, (ncw_h16)x1};
+    asm volatile("" : "+v"(p));
+    h0 = p[0];
+    h1 = p[1];
+    l0 = (ncw_h16)(x0 - (float)p[0]);
+    l1 = (ncw_h16)(x1 - (float)p[1]);
+}
+NCW_DEV void ncw_split8(const f32x16& v, int t, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        ncw_h16 h0, h1, l0, l1;
+        ncw_split2(v[8 * t + e], v[8 * t + e + 1], h0, h1, l0, l1);
+        hi[e] = h0; hi[e + 1] = h1;
+        lo[e] = l0; lo[e + 1] = l1;
+    }
+}
+
+// Softplus(beta = 100) in "t-units" (round 6; the value-only SDF kernels: sampler queries, sdf(), grid sweep): with
+// t = 100 log2(e) z and h' = 100 log2(e) h the activation is h' = log2(1 + 2^t) = max(t, 0) + log2(1 + 2^-|t|) -- no scale in front of
+// the exp2, none behind the log2: 3 plain VALU + 2 transcendentals instead of 4 + 2 (`-|t|` is a source modifier of v_exp_f32).
+// Because (ln 2 / 100) (100 log2 e) = 1 every hidden matrix is UNCHANGED: t_{l+1} = W h'_l + 144.27 b.  The kernels scale what enters
+// the chain -- gamma(x) and the biases, once per point / per launch -- and divide the sdf row's result (models/neuconw.py:261-279).
+constexpr float NCW_TU = 144.26950408889634f;  // 100 log2(e)
+NCW_DEV float softplus_tu(float t) {
+    const float w = __builtin_amdgcn_exp2f(-__builtin_fabsf(t));
+    return ncw_relu(t) + __builtin_amdgcn_logf(1.f + w);
+}
+template <bool TU>
+NCW_DEV float softplus_sel(float z) {
+    if (TU) return softplus_tu(z);
+    float y, s;
+    softplus100<true>(z, y, s);
+    return y;
+}
+template <int RB>
+NCW_DEV void cvec_scale(CVec<RB>& v, float c) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v.v[rb][r] *= c;
+}
+
 template <bool FAST>
 NCW_DEV float sigmoidf_(float x) {
     if (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-x * 1.4426950408889634f));

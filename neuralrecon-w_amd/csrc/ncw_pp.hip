@@ -86,11 +86,9 @@ NCW_DEV void pp_prio(int p) {
 #endif
 }
 
-NCW_DEV float pp_softplus(float z) {
-    float y, s;
-    softplus100<true>(z, y, s);  // hardware exp2 / log2 form of ncw_common.h
-    return y;
-}
+// Softplus in t-units (ncw_common.h softplus_tu: this kernel is value-only -- gamma and the biases enter scaled by 100 log2 e,
+// the sdf row's result is divided by it; the hidden matrices are unchanged)
+NCW_DEV float pp_softplus(float t) { return softplus_tu(t); }
 
 // ------------------------------------------------------------------------------------------------
 // NB = output blocks per wave: 1 -> 8 waves per workgroup (two per SIMD, <= 256 registers each): the shipped form.  (NB = 2 --
@@ -237,7 +235,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
     // ---- biases of the Softplus layers -> LDS (256 f32 per layer) ---------------------------------------------------
     for (int i = threadIdx.x; i < NL * 64; i += 64 * NW) {
         const int l = i >> 6;
-        bbuf[i] = reinterpret_cast<const f32x4*>(net.b[l])[i & 63];
+        bbuf[i] = reinterpret_cast<const f32x4*>(net.b[l])[i & 63] * NCW_TU;  // t-units
     }
     // ---- gamma of the 4 tiles: tile t by wave t % NW ---------------------------------------------------------------------
     for (int t = wave; t < PP_TILES; t += NW) {
@@ -248,6 +246,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
         xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
         CVec<2> gam;
         freq_encode<2, 3, 6, true>(gam, xs, lane);
+        cvec_scale<2>(gam, NCW_TU);  // t-units: layer 0 and the skip layer's gamma columns see 100 log2(e) gamma
         Act<PrecBF16, 2> ga;
         to_act(ga, gam);
 #pragma unroll
@@ -340,11 +339,12 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
         pp_load_slice<16>(w1, net.w[L - 1], 1, 0, 0, lane);
         CVec<1> o;
         load_bias(o, net.b[L - 1], lane);
+        cvec_scale<1>(o, NCW_TU);  // 100 log2(e) (b + W h) = 100 log2(e) b + W h'
         const pp_lfrag* in = abuf + ((t >> 1) * 2 + ((NL - 1) & 1)) * (PP_GRP / 16) + (t & 1) * 16 * 64 + lane;
 #pragma unroll
         for (int u = 0; u < 16; ++u) o.v[0] = NCW_MFMA_H(w1[u], in[u * 64], o.v[0], 0, 0, 0);
         const int64_t p = (tile0 + t) * 32 + (lane & 31);
-        if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+        if (p < n && lane < 32) sdf[p] = o.v[0][0] / (net.scale * NCW_TU);
     }
 }
 

@@ -96,6 +96,35 @@ NCW_DEV void s16_mma_hl(f32x16 (&acc)[2][T], S16W& r, S16W& rl, const void* w, c
     }
 }
 
+// ... and with BOTH operands as hi + lo pairs (round 6): `in` is a split buffer [tile][unit][hi | lo]; W_hi b_hi + W_lo b_hi + W_hi b_lo,
+// six MFMAs per (unit, tile), consecutive MFMAs on different accumulators
+template <int T, int NU>
+NCW_DEV void s16_mma_hl2(f32x16 (&acc)[2][T], S16W& r, S16W& rl, const void* w, const void* wlo, int rb_stride, int wave,
+                         const s16_lfrag* in, int lane) {
+#pragma unroll
+    for (int q = 0; q < NU; ++q) {
+        const bf16x8 a0 = r.f[q % S16_D][0], a1 = r.f[q % S16_D][1], l0 = rl.f[q % S16_D][0], l1 = rl.f[q % S16_D][1];
+        if (q + S16_D < NU) {
+            r.f[q % S16_D][0] = s16_ld(w, rb_stride, wave, q + S16_D, lane);
+            r.f[q % S16_D][1] = s16_ld(w, rb_stride, wave + 8, q + S16_D, lane);
+            rl.f[q % S16_D][0] = s16_ld(wlo, rb_stride, wave, q + S16_D, lane);
+            rl.f[q % S16_D][1] = s16_ld(wlo, rb_stride, wave + 8, q + S16_D, lane);
+        }
+        bf16x8 bh[T], bl[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            bh[t] = in[((t * S16_KU + q) * 2) * 64 + lane];
+            bl[t] = in[((t * S16_KU + q) * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) { acc[0][t] = NCW_MFMA_H(a0, bh[t], acc[0][t], 0, 0, 0); acc[1][t] = NCW_MFMA_H(a1, bh[t], acc[1][t], 0, 0, 0); }
+#pragma unroll
+        for (int t = 0; t < T; ++t) { acc[0][t] = NCW_MFMA_H(l0, bh[t], acc[0][t], 0, 0, 0); acc[1][t] = NCW_MFMA_H(l1, bh[t], acc[1][t], 0, 0, 0); }
+#pragma unroll
+        for (int t = 0; t < T; ++t) { acc[0][t] = NCW_MFMA_H(a0, bl[t], acc[0][t], 0, 0, 0); acc[1][t] = NCW_MFMA_H(a1, bl[t], acc[1][t], 0, 0, 0); }
+    }
+}
+
 // the 3 gamma k-units (32..34) of the forward-orientation skip layer against gbuf (units 0..2 of a tile)
 template <int T>
 NCW_DEV void s16_mma_gamma(f32x16 (&acc)[2][T], const void* w, int wave, const s16_lfrag* gbuf, int lane) {
@@ -111,11 +140,23 @@ NCW_DEV void s16_mma_gamma(f32x16 (&acc)[2][T], const void* w, int wave, const s
 }
 
 // one output block of one tile (gamma columns of a transposed matrix, the sdf row): acc += W[block ob][.] . in[tile t][.]
-template <int NU, int BS = 1>
+// (BS = 2: a split buffer; PLANE 0 = its hi fragments, 1 = its lo fragments)
+template <int NU, int BS = 1, int PLANE = 0>
 NCW_DEV void s16_mma1(f32x16& acc, const void* w, int rb_stride, int ob, const s16_lfrag* in, int t, int lane) {
 #pragma unroll
     for (int q = 0; q < NU; ++q)
-        acc = NCW_MFMA_H(s16_ld(w, rb_stride, ob, q, lane), in[((t * S16_KU + q) * BS) * 64 + lane], acc, 0, 0, 0);
+        acc = NCW_MFMA_H(s16_ld(w, rb_stride, ob, q, lane), in[((t * S16_KU + q) * BS + PLANE) * 64 + lane], acc, 0, 0, 0);
+}
+
+// hi and lo fragments of the two k-units of one output block into a split buffer [tile][unit][hi | lo]
+NCW_DEV void s16_store_units_hl(s16_lfrag* buf, int t, int ob, const f32x16& v, int lane) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        bf16x8 hi, lo;
+        ncw_split8(v, tt, hi, lo);
+        buf[((t * S16_KU + 2 * ob + tt) * 2 + 0) * 64 + lane] = hi;
+        buf[((t * S16_KU + 2 * ob + tt) * 2 + 1) * 64 + lane] = lo;
+    }
 }
 
 NCW_DEV void s16_store_units(s16_lfrag* buf, int t, int ob, const f32x16& v, int lane) {
@@ -144,10 +185,13 @@ NCW_DEV void s16_fill(f32x16 (&acc)[2][T], const f32x16& b0, const f32x16& b1) {
     for (int t = 0; t < T; ++t) { acc[0][t] = b0; acc[1][t] = b1; }
 }
 
+// TU: the value-only launches run the hidden layers in t-units (ncw_common.h softplus_tu: gamma and the biases enter x 100 log2 e,
+// the sdf row's result is divided by it, the hidden matrices are unchanged)
+template <bool TU = false>
 NCW_DEV f32x16 s16_softplus(const f32x16& z) {
     f32x16 y;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { float yy, s; softplus100<true>(z[r], yy, s); y[r] = yy; }
+    for (int r = 0; r < 16; ++r) y[r] = softplus_sel<TU>(z[r]);
     return y;
 }
 
@@ -185,6 +229,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_infer16_kernel(NcwSdfNet n
         xs[0] *= net.scale; xs[1] *= net.scale; xs[2] *= net.scale;
         CVec<2> gam;
         freq_encode<2, 3, 6, true>(gam, xs, lane);
+        cvec_scale<2>(gam, NCW_TU);  // t-units
         Act<PrecBF16, 2> ga;
         to_act(ga, gam);
 #pragma unroll
@@ -199,7 +244,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_infer16_kernel(NcwSdfNet n
 #pragma unroll
             for (int q = 0; q < 3; ++q) w0[j][q] = s16_ld(net.w[0], 16, wave + 8 * j, q, lane);
         if (L - 1 > 1) s16_prefetch(r, net.w[1], 16, wave, lane);
-        const f32x16 b0 = s16_bias(net.b[0], wave, lane), b1 = s16_bias(net.b[0], wave + 8, lane);
+        const f32x16 b0 = s16_bias(net.b[0], wave, lane) * NCW_TU, b1 = s16_bias(net.b[0], wave + 8, lane) * NCW_TU;
         ncw_lds_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -208,11 +253,11 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_infer16_kernel(NcwSdfNet n
                 f32x16 a = j ? b1 : b0;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a = NCW_MFMA_H(w0[j][q], gbuf[(t * 4 + q) * 64 + lane], a, 0, 0, 0);
-                s16_store_units(abuf, t, wave + 8 * j, s16_softplus(a), lane);
+                s16_store_units(abuf, t, wave + 8 * j, s16_softplus<true>(a), lane);
             }
     }
     for (int l = 1; l < L - 1; ++l) {
-        const f32x16 b0 = s16_bias(net.b[l], wave, lane), b1 = s16_bias(net.b[l], wave + 8, lane);
+        const f32x16 b0 = s16_bias(net.b[l], wave, lane) * NCW_TU, b1 = s16_bias(net.b[l], wave + 8, lane) * NCW_TU;
         ncw_lds_barrier();  // layer l-1 outputs of all waves are in abuf
         s16_fill<T>(acc, b0, b1);
         s16_mma<T, S16_KU>(acc, r, net.w[l], 16, wave, abuf, lane);
@@ -222,15 +267,16 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_infer16_kernel(NcwSdfNet n
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) s16_store_units(abuf, t, wave + 8 * j, s16_softplus(acc[j][t]), lane);
+            for (int j = 0; j < 2; ++j) s16_store_units(abuf, t, wave + 8 * j, s16_softplus<true>(acc[j][t]), lane);
     }
     ncw_lds_barrier();
     for (int tw = wave; tw < T; tw += S16_WAVES) {  // sdf row
         CVec<1> o;
         load_bias(o, net.b[L - 1], lane);
+        cvec_scale<1>(o, NCW_TU);
         s16_mma1<S16_KU>(o.v[0], net.w[L - 1], 1, 0, abuf, tw, lane);
         const int64_t p = (tile0 + tw) * 32 + (lane & 31);
-        if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+        if (p < n && lane < 32) sdf[p] = o.v[0][0] / (net.scale * NCW_TU);
     }
 }
 
@@ -239,9 +285,15 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_infer16_kernel(NcwSdfNet n
 // [tile][unit][hi | lo] buffer, whose hi fragments are read) and r holds the first units of w_feat; abuf is then reused in the
 // plain layout.  SDF_ROW = false: the caller's (split-precision) chain has written sdf already.
 // TRAIN = false: forward-only render -- t_l is not stashed (feat is: the colour network reads it).
-// ADJ: the sweep's transposed weights as hi + lo pairs (net.wt_lo; round 5 -- the normals are multiplied by dist * inv_s inside the
+// ADJ 1: the sweep's transposed weights as hi + lo pairs (net.wt_lo; round 5 -- the normals are multiplied by dist * inv_s inside the
 // compositor's sigmoid: ncw_split.hip sdf_fwdSA_kernel has the measurements).
-template <int T, int BS, bool SDF_ROW, bool TRAIN, bool ADJ = false>
+// ADJ 2 (round 6, BS = 2 only: the split kernel's 128 KiB buffer): t_l as a hi + lo pair too -- W_hi^T t_hi + W_lo^T t_hi + W_hi^T t_lo,
+// i.e. the normals at the accuracy of the value chain.  At W = 512 with the shipped 8 + 16 samples ONE sample carries most of a
+// ray's weight and the colour network reads the normal of that sample: on trained weights the plain sweep's 4e-4 put 2 % of the
+// rays above 1e-4, W^T alone as a pair made the worst ray worse (profiles/r05/emul_timed_batch_shipped.log), both operands --
+// together with the colour network's activations as pairs -- bring the worst of 256 rays to 2e-5 (profiles/r06/
+// emul_timed_batch_shipped_tangent*.log).  The stash t_l stays the single-rounded hi part: the backward is unchanged.
+template <int T, int BS, bool SDF_ROW, bool TRAIN, int ADJ = 0>
 NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n, float* __restrict__ sdf, float* __restrict__ grad,
                           const NcwSdfStash& st, s16_lfrag* abuf, s16_lfrag* gbuf, S16W& r, f32x16 (&acc)[2][T], int lane, int wave,
                           int64_t tile0) {
@@ -290,7 +342,8 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
 #pragma unroll
                 for (int q = 0; q < 16; ++q) sv[q] *= aa[q];
                 if (TRAIN) stash_store_block((SE*)st.t[L - 2], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
-                s16_store_units(abuf, t, wave + 8 * j, sv, lane);
+                if (ADJ == 2) s16_store_units_hl(abuf, t, wave + 8 * j, sv, lane);
+                else s16_store_units(abuf, t, wave + 8 * j, sv, lane);
             }
     }
     // ---- adjoint layers l = L-2 .. 1: t_{l-1} = (W_l^T t_l) * phi'(z_{l-1});  r = first units of wt[l] -------------
@@ -299,13 +352,15 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
         const bool skip = (l == net.skip_layer);
         ncw_lds_barrier();  // t_l complete in abuf
         s16_fill<T>(acc, s16_zero(), s16_zero());
-        if (ADJ) s16_mma_hl<T, S16_KU>(acc, r, rl, net.wt[l], net.wt_lo[l], skip ? 18 : 16, wave, abuf, lane);
+        if (ADJ == 2) s16_mma_hl2<T, S16_KU>(acc, r, rl, net.wt[l], net.wt_lo[l], skip ? 18 : 16, wave, abuf, lane);
+        else if (ADJ) s16_mma_hl<T, S16_KU>(acc, r, rl, net.wt[l], net.wt_lo[l], skip ? 18 : 16, wave, abuf, lane);
         else s16_mma<T, S16_KU>(acc, r, net.wt[l], skip ? 18 : 16, wave, abuf, lane);
         if (l - 1 >= 1) s16_prefetch(r, net.wt[l - 1], (l - 1 == net.skip_layer) ? 18 : 16, wave, lane);
         if (ADJ && l - 1 >= 1) s16_prefetch(rl, net.wt_lo[l - 1], (l - 1 == net.skip_layer) ? 18 : 16, wave, lane);
         if (skip && gjob) {  // gamma columns of the skip layer
-            s16_mma1<S16_KU>(gg, net.wt[l], 18, 16 + jb, abuf, jt, lane);
-            if (ADJ) s16_mma1<S16_KU>(gg, net.wt_lo[l], 18, 16 + jb, abuf, jt, lane);
+            s16_mma1<S16_KU, (ADJ == 2 ? 2 : 1)>(gg, net.wt[l], 18, 16 + jb, abuf, jt, lane);
+            if (ADJ) s16_mma1<S16_KU, (ADJ == 2 ? 2 : 1)>(gg, net.wt_lo[l], 18, 16 + jb, abuf, jt, lane);
+            if (ADJ == 2) s16_mma1<S16_KU, 2, 1>(gg, net.wt[l], 18, 16 + jb, abuf, jt, lane);
         }
         ncw_lds_barrier();
 #pragma unroll
@@ -316,7 +371,8 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
 #pragma unroll
                 for (int q = 0; q < 16; ++q) sv[q] *= acc[j][t][q];
                 if (TRAIN) stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
-                s16_store_units(abuf, t, wave + 8 * j, sv, lane);
+                if (ADJ == 2) s16_store_units_hl(abuf, t, wave + 8 * j, sv, lane);
+                else s16_store_units(abuf, t, wave + 8 * j, sv, lane);
             }
     }
     // ---- adjoint layer 0: g_gamma += W_0^T t_0 (2 out-blocks), then grad = J_gamma^T g_gamma ------------------------
@@ -325,8 +381,9 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
     int64_t p = (tile0 + jt) * 32 + (lane & 31), ray;
     const bool valid = gjob && p < n;
     if (gjob) {
-        s16_mma1<S16_KU>(gg, net.wt[0], 2, jb, abuf, jt, lane);
-        if (ADJ) s16_mma1<S16_KU>(gg, net.wt_lo[0], 2, jb, abuf, jt, lane);
+        s16_mma1<S16_KU, (ADJ == 2 ? 2 : 1)>(gg, net.wt[0], 2, jb, abuf, jt, lane);
+        if (ADJ) s16_mma1<S16_KU, (ADJ == 2 ? 2 : 1)>(gg, net.wt_lo[0], 2, jb, abuf, jt, lane);
+        if (ADJ == 2) s16_mma1<S16_KU, 2, 1>(gg, net.wt[0], 2, jb, abuf, jt, lane);
         if (p >= n) p = n - 1;
         float xs[3];
         load_point(src, p, xs, ray);
@@ -337,7 +394,7 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
             const int f0 = 32 * jb + ncw_feat_of(q, 0);
             if (f0 >= 39) continue;  // (block 1 holds features 32..38 only)
             int comp;
-            const float dv = freq_feature_deriv<3, 6, !ADJ>(xs, f0 + 4 * h, comp);  // (ADJ: sinf / cosf like the split value chain's gamma)
+            const float dv = freq_feature_deriv<3, 6, ADJ == 0>(xs, f0 + 4 * h, comp);  // (ADJ: sinf / cosf like the split value chain's gamma)
             const float c = gg[q] * dv;
             nx += comp == 0 ? c : 0.f;
             ny += comp == 1 ? c : 0.f;
@@ -617,15 +674,7 @@ NCW_DEV void s16s_prefetch(S16WS& r, const void* w, const void* wlo, int rb_stri
     for (int d = 0; d < S16_D; ++d) s16s_ld_unit(r.f[d], w, wlo, rb_stride, wave, d, lane);
 }
 
-NCW_DEV void s16s_split8(const f32x16& v, int t, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float x = v[8 * t + e];
-        const ncw_h16 h = (ncw_h16)x;
-        hi[e] = h;
-        lo[e] = (ncw_h16)(x - (float)h);
-    }
-}
+NCW_DEV void s16s_split8(const f32x16& v, int t, bf16x8& hi, bf16x8& lo) { ncw_split8(v, t, hi, lo); }
 
 // six MFMAs per (unit, tile): blocks w and w + 8, {hi.hi, lo.hi, hi.lo}; consecutive MFMAs go to different accumulators
 NCW_DEV void s16s_unit(f32x16 (&acc)[2][S16S_T], const bf16x8 (&a)[4], const s16_lfrag* in, int upt, int u, int lane) {
@@ -662,6 +711,8 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
                               int lane, int wave, float* __restrict__ sdf, const NcwSdfStash& st) {
     typedef ncw_h16 SE;
     constexpr int T = S16S_T;
+    constexpr bool TU = STASH == 0;  // value-only launches: t-units
+    const float bscale = TU ? NCW_TU : 1.f;
     const int L = net.n_layers;
     if (wave < T) {
         int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
@@ -672,6 +723,7 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
         CVec<2> gam;
         freq_encode<2, 3, 6, false>(gam, xs, lane);  // sinf / cosf: the hardware v_sin / v_cos are not fp32-accurate
         if (STASH == 2) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        if (TU) cvec_scale<2>(gam, NCW_TU);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             bf16x8 hi, lo;
@@ -687,7 +739,7 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const f32x16 y = s16_softplus(acc[j][t]);
+                const f32x16 y = s16_softplus<TU>(acc[j][t]);
                 const int ob = wave + 8 * j;
                 if (STASH >= 1) stash_store_block_keep((SE*)st.h[l_out], (size_t)(tile0 + t), 16, ob, y, lane);
 #pragma unroll
@@ -704,14 +756,14 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
 #pragma unroll
         for (int q = 0; q < 3; ++q) s16s_ld_unit(w0[q], net.w[0], net.w_lo[0], 16, wave, q, lane);
         if (L - 1 > 1) s16s_prefetch(r, net.w[1], net.w_lo[1], 16, wave, lane);
-        s16_fill<T>(acc, s16_bias(net.b[0], wave, lane), s16_bias(net.b[0], wave + 8, lane));
+        s16_fill<T>(acc, s16_bias(net.b[0], wave, lane) * bscale, s16_bias(net.b[0], wave + 8, lane) * bscale);
         ncw_lds_barrier();  // gamma visible
 #pragma unroll
         for (int q = 0; q < 3; ++q) s16s_unit(acc, w0[q], gsbuf, 4, q, lane);
         epilogue(1);
     }
     for (int l = 1; l < L - 1; ++l) {
-        const f32x16 b0 = s16_bias(net.b[l], wave, lane), b1 = s16_bias(net.b[l], wave + 8, lane);
+        const f32x16 b0 = s16_bias(net.b[l], wave, lane) * bscale, b1 = s16_bias(net.b[l], wave + 8, lane) * bscale;
         ncw_lds_barrier();  // layer l-1 outputs of all waves are in sbuf
         s16_fill<T>(acc, b0, b1);
         s16s_mma(acc, r, net.w[l], net.w_lo[l], wave, sbuf, lane);
@@ -731,6 +783,7 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
     if (wave < T) {  // sdf row (1 output block), tile = wave
         CVec<1> o;
         load_bias(o, net.b[L - 1], lane);
+        if (TU) cvec_scale<1>(o, NCW_TU);
 #pragma unroll
         for (int c = 0; c < S16_KU; c += 8) {
             bf16x8 vh[8], vl[8];
@@ -745,7 +798,7 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
             }
         }
         const int64_t p = (tile0 + wave) * 32 + (lane & 31);
-        if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+        if (p < n && lane < 32) sdf[p] = o.v[0][0] / (net.scale * bscale);
     }
 }
 
@@ -764,7 +817,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void sdf_inferS16_kernel(NcwSdfNet 
     s16s_value_chain<0>(net, src, n, tile0, sbuf, gsbuf, lane, wave, sdf, none);
 }
 
-template <bool TRAIN, bool ADJ>  // TRAIN false: forward-only render (no gamma / t_l stash); ADJ: adjoint sweep with hi + lo weights
+template <bool TRAIN, int ADJ>  // TRAIN false: forward-only render (no gamma / t_l stash); ADJ 1: adjoint sweep with hi + lo weights, 2: and hi + lo t_l
 __global__ __launch_bounds__(64 * S16_WAVES) void sdf_fwdS16_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
                                                                    float* __restrict__ sdf, float* __restrict__ grad, NcwSdfStash st) {
     S16S_LDS_DECL();
@@ -844,12 +897,15 @@ int ncw_sdf_fwdS16_launch_f16(const NcwSdfNet* net, const NcwPoints& src, int64_
     for (int l = 0; l < net->n_layers; ++l) adj = adj && net->wt_lo[l] != nullptr;
     const bool render = stash.t[0] == nullptr;  // forward-only render
     const dim3 grid((unsigned)((tiles + S16S_T - 1) / S16S_T)), block(64 * S16_WAVES);
-    if (adj) {
-        if (render) hipLaunchKernelGGL((sdf_fwdS16_kernel<false, true>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
-        else hipLaunchKernelGGL((sdf_fwdS16_kernel<true, true>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
+    if (adj && net->adj_mode == 2) {  // ... and t_l as a hi + lo pair
+        if (render) hipLaunchKernelGGL((sdf_fwdS16_kernel<false, 2>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
+        else hipLaunchKernelGGL((sdf_fwdS16_kernel<true, 2>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
+    } else if (adj) {
+        if (render) hipLaunchKernelGGL((sdf_fwdS16_kernel<false, 1>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
+        else hipLaunchKernelGGL((sdf_fwdS16_kernel<true, 1>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
     } else {
-        if (render) hipLaunchKernelGGL((sdf_fwdS16_kernel<false, false>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
-        else hipLaunchKernelGGL((sdf_fwdS16_kernel<true, false>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
+        if (render) hipLaunchKernelGGL((sdf_fwdS16_kernel<false, 0>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
+        else hipLaunchKernelGGL((sdf_fwdS16_kernel<true, 0>), grid, block, 0, st, *net, src, n, sdf, grad, stash);
     }
     NCW_CHECK_LAUNCH();
     return 0;

@@ -46,16 +46,8 @@ NCW_DEV void ss_load_half(bf16x8 (&h)[NU], bf16x8 (&l)[NU], const void* w, const
     }
 }
 
-// fp16 hi + lo images of accumulator registers 8t..8t+7 (one k-unit of the next layer)
-NCW_DEV void ss_split8(const f32x16& v, int t, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float x = v[8 * t + e];
-        const ncw_h16 h = (ncw_h16)x;
-        hi[e] = h;
-        lo[e] = (ncw_h16)(x - (float)h);
-    }
-}
+// fp16 hi + lo images of accumulator registers 8t..8t+7 (one k-unit of the next layer): ncw_common.h ncw_split8 (ONE conversion)
+NCW_DEV void ss_split8(const f32x16& v, int t, bf16x8& hi, bf16x8& lo) { ncw_split8(v, t, hi, lo); }
 
 // acc[t] += W[ob, units u0 .. u0 + NU) . in[t, the same units], three MFMAs per unit; tiles in pairs so that consecutive
 // MFMAs alternate between two accumulators
@@ -100,6 +92,11 @@ template <int STASH>
 NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t n, int64_t tile0, ss_lfrag* abuf, ss_lfrag* gbuf,
                             int lane, int wave, float* __restrict__ sdf, const NcwSdfStash& st) {
     typedef ncw_h16 SE;
+    // value-only launches (STASH 0: the sampler's queries, sdf(), the grid sweep) run the hidden layers in t-units (ncw_common.h
+    // softplus_tu): gamma and the biases x 100 log2 e, the sdf row's result / it; with a stash the chain stays in the units the
+    // backward reads
+    constexpr bool TU = STASH == 0;
+    const float bscale = TU ? NCW_TU : 1.f;
     const int L = net.n_layers;
     if (wave < SS_TILES) {
         int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
@@ -110,6 +107,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         CVec<2> gam;
         freq_encode<2, 3, 6, false>(gam, xs, lane);  // sinf / cosf: the hardware v_sin / v_cos are not fp32-accurate
         if (STASH == 2) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        if (TU) cvec_scale<2>(gam, NCW_TU);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             bf16x8 hi, lo;
@@ -129,7 +127,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         for (int t = 0; t < SS_TILES; ++t) {
             f32x16 yv;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { float y, s; softplus100<true>(acc[t][r], y, s); yv[r] = y; }
+            for (int r = 0; r < 16; ++r) yv[r] = softplus_sel<TU>(acc[t][r]);
             if (STASH >= 1) stash_store_block_keep((SE*)st.h[l_out], (size_t)(tile0 + t), 8, wave, yv, lane);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
@@ -146,7 +144,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         bf16x8 w0h[3], w0l[3];
         ss_load_half<3>(w0h, w0l, net.w[0], net.w_lo[0], 8, wave, 0, lane);
         if (L - 1 > 1) ss_load_half<8>(Ah, Al, net.w[1], net.w_lo[1], 8, wave, 0, lane);
-        const f32x16 bias = ss_bias(net.b[0], wave, lane);
+        const f32x16 bias = ss_bias(net.b[0], wave, lane) * bscale;
 #pragma unroll
         for (int t = 0; t < SS_TILES; ++t) acc[t] = bias;
         ncw_lds_barrier();  // gamma visible
@@ -155,7 +153,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
     }
     // ---- hidden layers 1 .. L-2 ------------------------------------------------------------------------------
     for (int l = 1; l < L - 1; ++l) {
-        const f32x16 bias = ss_bias(net.b[l], wave, lane);
+        const f32x16 bias = ss_bias(net.b[l], wave, lane) * bscale;
 #pragma unroll
         for (int t = 0; t < SS_TILES; ++t) acc[t] = bias;
         ss_load_half<8>(Bh, Bl, net.w[l], net.w_lo[l], 8, wave, 8, lane);  // second half: lands during the first
@@ -173,6 +171,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
     if (wave < SS_TILES) {
         CVec<1> o;
         load_bias(o, net.b[L - 1], lane);
+        if (TU) cvec_scale<1>(o, NCW_TU);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             bf16x8 wh[8], wl[8];
@@ -187,7 +186,7 @@ NCW_DEV void ss_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
             }
         }
         const int64_t p = (tile0 + wave) * 32 + (lane & 31);
-        if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+        if (p < n && lane < 32) sdf[p] = o.v[0][0] / (net.scale * bscale);
     }
 }
 
@@ -274,13 +273,18 @@ NCW_DEV void s2_segment(f32x16& m, bf16x8 (&wh)[16], bf16x8 (&wl)[16], const ss_
 // every fourth step one 8-byte stash piece (4 consecutive features), every eighth step one k-unit (hi fragment + lo fragment)
 // of the next layer's input, in place.
 template <bool STASH>
-NCW_DEV void s2_epi_step(int u, const f32x16& e, bf16x8& fh, bf16x8& fl, ss_lfrag* out, int ob, int lane, ncw_h16* __restrict__ st_h,
-                         size_t tile) {
-    float y, sgm;
-    softplus100<true>(e[u], y, sgm);
-    const ncw_h16 hh = (ncw_h16)y;
-    fh[u & 7] = hh;
-    fl[u & 7] = (ncw_h16)(y - (float)hh);
+NCW_DEV void s2_epi_step(int u, const f32x16& e, bf16x8& fh, bf16x8& fl, float& ycarry, ss_lfrag* out, int ob, int lane,
+                         ncw_h16* __restrict__ st_h, size_t tile) {
+    const float y = softplus_sel<!STASH>(e[u]);  // (value-only launches: t-units, see ss_value_chain)
+    // hi / lo in PAIRS (even step: keep y; odd step: one packed conversion, both residuals from it -- ncw_common.h ncw_split2)
+    if ((u & 1) == 0) {
+        ycarry = y;
+    } else {
+        ncw_h16 h0, h1, l0, l1;
+        ncw_split2(ycarry, y, h0, h1, l0, l1);
+        fh[(u & 7) - 1] = h0; fh[u & 7] = h1;
+        fl[(u & 7) - 1] = l0; fl[u & 7] = l1;
+    }
     if (STASH && (u & 3) == 3) {  // registers 4g .. 4g+3, g = u >> 2: one [tile][block][g][lane][4] piece of the stash
         bf16x4 t;
 #pragma unroll
@@ -300,7 +304,9 @@ NCW_DEV void s2_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
     typedef ncw_h16 SE;
     const int L = net.n_layers, NL = L - 1;
     const int ob = wave;
-    for (int i = threadIdx.x; i < NL * 64; i += 64 * SS_WAVES) bbuf[i] = reinterpret_cast<const f32x4*>(net.b[i >> 6])[i & 63];
+    constexpr bool TU = !STASH;  // value-only: t-units (ss_value_chain)
+    const float bscale = TU ? NCW_TU : 1.f;
+    for (int i = threadIdx.x; i < NL * 64; i += 64 * SS_WAVES) bbuf[i] = reinterpret_cast<const f32x4*>(net.b[i >> 6])[i & 63] * bscale;
     if (wave < SS_TILES) {
         int64_t p = (tile0 + wave) * 32 + (lane & 31), ray;
         if (p >= n) p = n - 1;
@@ -310,6 +316,7 @@ NCW_DEV void s2_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         CVec<2> gam;
         freq_encode<2, 3, 6, false>(gam, xs, lane);  // sinf / cosf: the hardware v_sin / v_cos are not fp32-accurate
         if (STASH == 2) stash_store<2>((SE*)st.gamma, (size_t)(tile0 + wave), gam, lane);
+        if (TU) cvec_scale<2>(gam, NCW_TU);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             bf16x8 hi, lo;
@@ -321,6 +328,7 @@ NCW_DEV void s2_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
     bf16x8 wh[16], wl[16];
     f32x16 x, y;  // tiles 0, 2 accumulate into x, tiles 1, 3 into y
     bf16x8 fh, fl;
+    float yc = 0.f;  // s2_epi_step's carry between an even and the following odd step
     auto region = [&](int t) { return abuf + t * (S2_TILE / 16); };
     auto gin = [&](int t) { return gbuf + t * 3 * 2 * 64 + lane; };
     auto bias_of = [&](int l) { return s2_bias(bbuf + (l * 8 + ob) * 8, lane); };
@@ -333,9 +341,9 @@ NCW_DEV void s2_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         s2_mma_x<3>(x, wh, wl, gin(0));
         s2_mma_x<3>(y, wh, wl, gin(1));
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, x, fh, fl, region(0), ob, lane, (SE*)st.h[1], (size_t)tile0);
+        for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, x, fh, fl, yc, region(0), ob, lane, (SE*)st.h[1], (size_t)tile0);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, y, fh, fl, region(1), ob, lane, (SE*)st.h[1], (size_t)(tile0 + 1));
+        for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, y, fh, fl, yc, region(1), ob, lane, (SE*)st.h[1], (size_t)(tile0 + 1));
         x = bias_of(0);
         y = x;
         s2_mma_x<3>(x, wh, wl, gin(2));
@@ -343,7 +351,7 @@ NCW_DEV void s2_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         // the first hidden layer's slice (its latency hides behind the epilogue)
         if (NL > 1) ss_load_half<16>(wh, wl, net.w[1], net.w_lo[1], 8, ob, 0, lane);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, x, fh, fl, region(2), ob, lane, (SE*)st.h[1], (size_t)(tile0 + 2));
+        for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, x, fh, fl, yc, region(2), ob, lane, (SE*)st.h[1], (size_t)(tile0 + 2));
         s2_barrier();
     }
     // ---- hidden layer l >= 1, tile t: [M(l, t) | E(previous segment)] bar ---------------------------------------------------
@@ -353,28 +361,28 @@ NCW_DEV void s2_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         if (skip) ss_load_half<3>(gh, gl, net.w[l], net.w_lo[l], 8, ob, 16, lane);  // the gamma columns: units 16..18
         {   // t = 0 -> x;  E(l-1, 3) <- y
             x = bias_of(l);
-            auto epi = [&](int u) { s2_epi_step<STASH>(u, y, fh, fl, region(3), ob, lane, (SE*)st.h[l], (size_t)(tile0 + 3)); };
+            auto epi = [&](int u) { s2_epi_step<STASH>(u, y, fh, fl, yc, region(3), ob, lane, (SE*)st.h[l], (size_t)(tile0 + 3)); };
             s2_segment<false>(x, wh, wl, region(0) + lane, nullptr, nullptr, ob, lane, epi);
             if (skip) s2_mma_x<3>(x, gh, gl, gin(0));
             s2_barrier();
         }
         {   // t = 1 -> y;  E(l, 0) <- x
             y = bias_of(l);
-            auto epi = [&](int u) { s2_epi_step<STASH>(u, x, fh, fl, region(0), ob, lane, (SE*)st.h[l + 1], (size_t)tile0); };
+            auto epi = [&](int u) { s2_epi_step<STASH>(u, x, fh, fl, yc, region(0), ob, lane, (SE*)st.h[l + 1], (size_t)tile0); };
             s2_segment<false>(y, wh, wl, region(1) + lane, nullptr, nullptr, ob, lane, epi);
             if (skip) s2_mma_x<3>(y, gh, gl, gin(1));
             s2_barrier();
         }
         {   // t = 2 -> x;  E(l, 1) <- y
             x = bias_of(l);
-            auto epi = [&](int u) { s2_epi_step<STASH>(u, y, fh, fl, region(1), ob, lane, (SE*)st.h[l + 1], (size_t)(tile0 + 1)); };
+            auto epi = [&](int u) { s2_epi_step<STASH>(u, y, fh, fl, yc, region(1), ob, lane, (SE*)st.h[l + 1], (size_t)(tile0 + 1)); };
             s2_segment<false>(x, wh, wl, region(2) + lane, nullptr, nullptr, ob, lane, epi);
             if (skip) s2_mma_x<3>(x, gh, gl, gin(2));
             s2_barrier();
         }
         {   // t = 3 -> y;  E(l, 2) <- x; the layer's last use of its weight slice -> the next layer's takes its registers
             y = bias_of(l);
-            auto epi = [&](int u) { s2_epi_step<STASH>(u, x, fh, fl, region(2), ob, lane, (SE*)st.h[l + 1], (size_t)(tile0 + 2)); };
+            auto epi = [&](int u) { s2_epi_step<STASH>(u, x, fh, fl, yc, region(2), ob, lane, (SE*)st.h[l + 1], (size_t)(tile0 + 2)); };
             if (more) s2_segment<true>(y, wh, wl, region(3) + lane, net.w[l + 1], net.w_lo[l + 1], ob, lane, epi);
             else s2_segment<false>(y, wh, wl, region(3) + lane, nullptr, nullptr, ob, lane, epi);
             if (skip) s2_mma_x<3>(y, gh, gl, gin(3));
@@ -383,12 +391,13 @@ NCW_DEV void s2_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
     }
     // ---- drain: E(NL-1, 3) --------------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, y, fh, fl, region(3), ob, lane, (SE*)st.h[NL], (size_t)(tile0 + 3));
+    for (int u = 0; u < 16; ++u) s2_epi_step<STASH>(u, y, fh, fl, yc, region(3), ob, lane, (SE*)st.h[NL], (size_t)(tile0 + 3));
     s2_barrier();
     // ---- sdf row (1 output block), tile t by wave t -------------------------------------------------------------------
     if (wave < SS_TILES) {
         CVec<1> o;
         load_bias(o, net.b[L - 1], lane);
+        if (TU) cvec_scale<1>(o, NCW_TU);
         const ss_lfrag* in = region(wave) + lane;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -404,7 +413,7 @@ NCW_DEV void s2_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
             }
         }
         const int64_t p = (tile0 + wave) * 32 + (lane & 31);
-        if (p < n && lane < 32) sdf[p] = o.v[0][0] / net.scale;
+        if (p < n && lane < 32) sdf[p] = o.v[0][0] / (net.scale * bscale);
     }
 }
 

@@ -46,8 +46,11 @@ __device__ __forceinline__ void dda_walk(const float (&u)[3], const float (&du)[
     }
     if (!(t1 >= fmaxf(t0, 0.f))) return;
     float t_entry = fmaxf(t0, 0.f);
+    // The exit depth of the current voxel along axis a is computed FROM THE VOXEL INDEX at every step, (boundary - u) / du, not by
+    // accumulating tmax += 1 / |du|: at level 10 a ray crosses up to 3072 voxels and the accumulated rounding (up to ~0.1 voxel at the
+    // far side of the cube) let the walk visit voxels the ray does not touch (tests/test_gpu_voxel.py, level 10).
     int idx[3], step[3];
-    float tmax[3], tdelta[3];
+    float tmax[3], inv[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float pos = u[a] + du[a] * t_entry;
@@ -57,9 +60,8 @@ __device__ __forceinline__ void dda_walk(const float (&u)[3], const float (&du)[
         else i = min(max((int)ceilf(pos) - 1, 0), G - 1);
         idx[a] = i;
         step[a] = du[a] > 0.f ? 1 : -1;
-        const float nb = (float)(i + (du[a] > 0.f ? 1 : 0));
-        tmax[a] = (nb - u[a]) / du[a];
-        tdelta[a] = fabsf(1.0f / du[a]);
+        inv[a] = 1.0f / du[a];
+        tmax[a] = ((float)(i + (du[a] > 0.f ? 1 : 0)) - u[a]) * inv[a];
     }
     int cur_brick = -1;
     bool brick_on = false;
@@ -78,9 +80,9 @@ __device__ __forceinline__ void dda_walk(const float (&u)[3], const float (&du)[
         }
         // advance to the next voxel along the ray
         t_entry = tmax[ax];
-        if (ax == 0) { idx[0] += step[0]; tmax[0] += tdelta[0]; }
-        else if (ax == 1) { idx[1] += step[1]; tmax[1] += tdelta[1]; }
-        else { idx[2] += step[2]; tmax[2] += tdelta[2]; }
+        if (ax == 0) { idx[0] += step[0]; tmax[0] = ((float)(idx[0] + (step[0] > 0 ? 1 : 0)) - u[0]) * inv[0]; }
+        else if (ax == 1) { idx[1] += step[1]; tmax[1] = ((float)(idx[1] + (step[1] > 0 ? 1 : 0)) - u[1]) * inv[1]; }
+        else { idx[2] += step[2]; tmax[2] = ((float)(idx[2] + (step[2] > 0 ? 1 : 0)) - u[2]) * inv[2]; }
         if (idx[0] < 0 || idx[0] >= G || idx[1] < 0 || idx[1] >= G || idx[2] < 0 || idx[2] >= G) break;
     }
 }

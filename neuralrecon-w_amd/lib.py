@@ -51,7 +51,7 @@ class NcwSdfNet(C.Structure):
         ("w", C.c_void_p * MAX_LAYERS), ("b", C.c_void_p * MAX_LAYERS), ("wt", C.c_void_p * MAX_LAYERS),
         ("w_feat", C.c_void_p), ("b_feat", C.c_void_p), ("wt_feat", C.c_void_p),
         ("n_layers", C.c_int32), ("skip_layer", C.c_int32), ("rb", C.c_int32), ("multires", C.c_int32),
-        ("scale", C.c_float), ("_pad", C.c_int32), ("w_lo", C.c_void_p * MAX_LAYERS),
+        ("scale", C.c_float), ("adj_mode", C.c_int32), ("w_lo", C.c_void_p * MAX_LAYERS),
         ("wt_lo", C.c_void_p * MAX_LAYERS),
     ]
 
@@ -83,7 +83,8 @@ class NcwColorNet(C.Structure):
                 ("w_l", C.c_void_p * 8), ("wt_l", C.c_void_p * 8), ("b_l", C.c_void_p * 8),
                 ("n_head", C.c_int32), ("n_lin", C.c_int32), ("rbf", C.c_int32), ("rbh", C.c_int32),
                 ("rbc", C.c_int32), ("n_a", C.c_int32),
-                ("w_f_lo", C.c_void_p), ("w_e_lo", C.c_void_p * 4), ("w_l_lo", C.c_void_p * 8)]
+                ("w_f_lo", C.c_void_p), ("w_e_lo", C.c_void_p * 4), ("w_l_lo", C.c_void_p * 8),
+                ("act_split", C.c_int32), ("_pad", C.c_int32)]
 
 
 class NcwColorStash(C.Structure):

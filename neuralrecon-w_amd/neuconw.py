@@ -188,18 +188,20 @@ class SDFNetwork(nn.Module):
         plan = PackPlan(dev, prec)
         net = L.NcwSdfNet()
         slots, lo, lo_t = {}, {}, {}
-        # the adjoint sweep's transposed residuals (NcwSdfNet.wt_lo; csrc/ncw_split.hip sdf_fwdSA, ncw_sdf16.hip sdf_fwdS16<., true>); NEUCONW_SDF_ADJ_SPLIT=0
-        # / .adj_split = False = single-rounded weights in the adjoint sweep (round 4's kernels)
-        # Default: ON at W = 256, OFF at W = 512 -- there (shipped 8 + 16 shape: 5x larger sample spacing, K = 512) the weight
-        # operand alone is not enough: with W^T as hi + lo and t_l single the timed batch's worst ray on trained weights goes 3.2e-4
-        # -> 6.2e-4 (GPU; emulated 6.1e-4), only BOTH operands as hi + lo pairs bring it to 1.0e-4 (profiles/r05/
-        # emul_timed_batch_shipped.log), at +0.32 ms for the weight operand alone (sdf_fwd 0.96 -> 1.28 ms).  `.adj_split = True`
-        # / NEUCONW_SDF_ADJ_SPLIT=1 force it on at either width.
+        # the adjoint sweep's transposed residuals (NcwSdfNet.wt_lo; csrc/ncw_split.hip sdf_fwdSA, ncw_sdf16.hip sdf_fwdS16<., ADJ>):
+        # `.adj_split` / NEUCONW_SDF_ADJ_SPLIT = 0 | False: single-rounded operands in the adjoint sweep (round 4's kernels);
+        # 1 | True: W^T as hi + lo pairs, t_l single fp16 (round 5); 2: t_l as a pair too (round 6, W = 512 only).
+        # Default: 1 at W = 256, 2 at W = 512 -- at the shipped 8 + 16 shape ONE sample carries most of a ray's weight and the
+        # colour network reads that sample's normal: with W^T alone as a pair the timed batch's worst ray on trained weights went
+        # 3.2e-4 -> 6.2e-4 (profiles/r05/emul_timed_batch_shipped.log), with both operands as pairs AND the colour network's
+        # activations as pairs the worst of 256 rays is at 2e-5 (profiles/r06/emul_timed_batch_shipped_tangent*.log).
         adj = self.__dict__.get("adj_split")
         if adj is None:
             env = os.environ.get("NEUCONW_SDF_ADJ_SPLIT")
-            adj = (RB == 8) if env is None else (env not in ("0", ""))
-        adj = bool(adj) and split and RB in (8, 16)
+            adj = (2 if RB == 16 else 1) if env is None else (int(env) if env.isdigit() else 1)
+        adj = int(adj) if (split and RB in (8, 16)) else 0
+        if RB == 8:
+            adj = min(adj, 1)
         for l in range(Lm):
             v, g, b = _wvb(getattr(self, "lin%d" % l))
             n_out, n_in = v.shape
@@ -254,6 +256,7 @@ class SDFNetwork(nn.Module):
         s = slots[Lm - 1]
         net.w_feat, net.b_feat, net.wt_feat = plan.mat_ptr(s[4]), plan.bias_ptr(s[5]), plan.mat_ptr(s[6])
         net.n_layers, net.skip_layer, net.rb, net.multires, net.scale = Lm, skip, RB, self.multires, self.scale
+        net.adj_mode = adj
         plan.net = net
         plan.slots = slots
         plan.packed_version = None
@@ -448,10 +451,16 @@ class RenderingNetwork(_PackedNet):
         # product: W_hi x + W_lo x); NEUCONW_COLOR_WSPLIT=0 / .weight_split = False = one rounding per weight (set before the
         # first forward: the packed-weight plan is built once per precision)
         self.weight_split = os.environ.get("NEUCONW_COLOR_WSPLIT", "1") != "0"
+        # fp16 mode, with weight_split: the ACTIVATIONS of every layer as hi + lo pairs too (NcwColorNet.act_split: a third pass of the
+        # weight ring per layer, forward only).  None = the default: on at d_feature = 512 (the shipped width: 8 + 16 samples per ray,
+        # one sample carries a ray), off at 256 (the headline's ten ray batches are under 1e-4 without it; emulated gain there 8.4e-5
+        # -> 3.8e-5).  NEUCONW_COLOR_ASPLIT=0 / 1 or `.act_split = False / True` override.
+        env = os.environ.get("NEUCONW_COLOR_ASPLIT")
+        self.act_split = None if env is None else (env not in ("0", ""))
         self._init_plans()
 
     def _plan_switches(self):
-        return (bool(self.weight_split),)
+        return (bool(self.weight_split), self.act_split)
 
     @property
     def n_lin(self):
@@ -499,6 +508,8 @@ class RenderingNetwork(_PackedNet):
             net.w_l[l], net.b_l[l], net.wt_l[l] = plan.mat_ptr(s[0]), plan.bias_ptr(s[1]), plan.mat_ptr(s[2])
             net.w_l_lo[l] = plan.mat_ptr(s[4]) if split else None
         net.n_head, net.n_lin, net.rbf, net.rbh, net.rbc, net.n_a = self.n_head, self.n_lin, RBF, RBH, RBC, A
+        asplit = (RBF == 16) if self.act_split is None else bool(self.act_split)
+        net.act_split = 1 if (split and asplit and (RBF, RBH, RBC) in ((8, 4, 8), (16, 4, 8))) else 0
         plan.net, plan.slots = net, sl
         return plan
 

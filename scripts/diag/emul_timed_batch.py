@@ -40,16 +40,32 @@ print("variance in the saved state: %.3f (inv_s %.0f)" % (float(sd["neuconw.devi
 
 
 def run(modes):
+    modes = dict(modes)
+    tangent = modes.pop("tc", None)  # round 6: the normal's component ALONG THE RAY from a forward-mode tangent of the split value chain
     for k in MODE:
         MODE[k] = modes.get(k)
-    keep = O.sdf_net, O.color_net, O.nerf_net
+    keep = O.sdf_net, O.color_net, O.nerf_net, O.neuconw_forward
     if modes:
         O.sdf_net, O.color_net, O.nerf_net = ns["sdf_net_e"], ns["color_net_e"], ns["nerf_net_e"]
+    if tangent is not None:
+        exact_sdf = keep[0]
+
+        def forward_tc(sd_, pts, dirs, a, cfg_, prefix=""):
+            # the colour network sees the fp16-adjoint normals n16; what leaves for the compositor (true_cos = d . n,
+            # rendering/renderer.py:613, and the eikonal term) has its component along d replaced by the tangent's
+            sdf, feat, n16 = O.sdf_net(sd_, pts, prefix + "sdf_net.", cfg_.get("skip_in", (4,)), cfg_.get("multires", 6), cfg_.get("scale", 1.0))
+            rgb = O.color_net(sd_, pts, n16, dirs, feat, a, prefix + "color_net.", cfg_.get("multires_view", 4))
+            _, _, n_ex = exact_sdf(sd_, pts, prefix + "sdf_net.", cfg_.get("skip_in", (4,)), cfg_.get("multires", 6), cfg_.get("scale", 1.0))
+            tc = tangent((dirs * n_ex).sum(-1, keepdim=True))  # (tangent = ident: exact; rnd32: an fp32-rounded scalar)
+            n_out = n16 + dirs * (tc - (dirs * n16).sum(-1, keepdim=True)) / (dirs * dirs).sum(-1, keepdim=True)
+            return rgb, O.inv_s_from_variance(sd_[prefix + "deviation_network.variance"]), sdf, n_out
+
+        O.neuconw_forward = forward_tc
     try:
         with torch.no_grad():
             return O.render(sd, cfg, rays.double(), ts, label, 0.5, torch.zeros(1, 3, dtype=torch.float64))
     finally:
-        O.sdf_net, O.color_net, O.nerf_net = keep
+        O.sdf_net, O.color_net, O.nerf_net, O.neuconw_forward = keep
 
 
 ref = run({})
@@ -114,6 +130,24 @@ if "--sampler" in argv_keep:  # the sampler's SDF queries (split precision, 3 MF
                  ("sampler: weights hi+lo, layer inputs single fp16 (2 MFMAs)", dict(now, samp_h=rnd)),
                  ("sampler: layer inputs hi+lo, weights single fp16 (2 MFMAs)", dict(now, samp_w=rnd)),
                  ("sampler: plain fp16 (1 MFMA)", dict(now, samp_h=rnd, samp_w=rnd))]
+if "--tangent" in argv_keep:  # round 6: true_cos from a forward-mode tangent, normals for the colour input stay fp16
+    rnd32 = lambda x: x.float().double()  # noqa: E731
+    w512 = dict(now, tail_adj=rnd, adj_t=rnd, adj_w=rnd)  # the shipped W = 512 kernels: adjoint sweep single-rounded (adj_split off)
+    cases_all = [("round-5 kernels at W = 512 (adjoint sweep plain fp16)", w512),
+                 ("+ true_cos from the tangent (exact), normals for the colour input fp16", dict(w512, tc=ident)),
+                 ("+ true_cos from the tangent (fp32-rounded scalar)", dict(w512, tc=rnd32)),
+                 ("+ tangent + adjoint W^T hi+lo (adj_split on)", dict(now, tc=ident)),
+                 ("+ tangent + adjoint W^T and t hi+lo", dict(now, adj_t=None, tc=ident)),
+                 ("+ tangent + colour activations hi+lo", dict(w512, clay=split, tc=ident)),
+                 ("+ tangent + feature rows hi+lo", dict(w512, tail_feat=split, tc=ident)),
+                 ("+ tangent + colour activations + feature rows + colour feat input hi+lo", dict(w512, clay=split, tail_feat=split, cin_f=split, tc=ident)),
+                 ("adjoint W^T and t hi+lo, no tangent (round 5's emulated fix)", dict(now, adj_t=None)),
+                 ("colour activations hi+lo, no tangent", dict(w512, clay=split)),
+                 ("adjoint W^T and t hi+lo + colour activations hi+lo, no tangent", dict(now, adj_t=None, clay=split)),
+                 ("adjoint W^T and t hi+lo, phi' exact + colour activations hi+lo, no tangent", dict(now, adj_t=None, adj_s=None, clay=split)),
+                 ("adjoint W^T and t hi+lo + colour activations + colour feat input hi+lo", dict(now, adj_t=None, clay=split, cin_f=split)),
+                 ("adjoint W^T and t hi+lo + colour activations + feature rows hi+lo", dict(now, adj_t=None, clay=split, tail_feat=split)),
+                 ("+ tangent + colour activations hi+lo + adjoint W^T hi+lo", dict(now, clay=split, tc=ident))]
 if "--next" in argv_keep:  # what is left after R5.8, one candidate at a time
     cases_all = [("final round-5 kernels", now),
                  ("+ colour feat input hi+lo", dict(now, cin_f=split)),
@@ -126,7 +160,9 @@ if "--next" in argv_keep:  # what is left after R5.8, one candidate at a time
                  ("+ per-ray head columns exact instead of fp32 (cin_da)", dict(now)),
                  ("+ feature rows + colour feat + activations hi+lo", dict(now, tail_feat=split, cin_f=split, clay=split)),
                  ("+ everything hi+lo", dict(now, tail_feat=split, cin_f=split, clay=split, adj_t=None, adj_s=None))]
-cases = [c for c in cases_all if "--sampler" in argv_keep or "--next" in argv_keep or ("--only-new" not in argv_keep) or "--candidates" in argv_keep or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
+if "--only" in argv_keep:
+    cases_all = [c for c in cases_all if argv_keep[argv_keep.index("--only") + 1] in c[0] or c is cases_all[0]]
+cases = [c for c in cases_all if "--sampler" in argv_keep or "--next" in argv_keep or "--tangent" in argv_keep or ("--only-new" not in argv_keep) or "--candidates" in argv_keep or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
 res = {}
 worst_rays = None
 for name, m in cases:
@@ -166,7 +202,7 @@ if with_ref and os.path.isdir("/root/reference"):
              "weights_sum": rel(o32["weights_sum"], ref["weights_sum"]), "weights": rel(o32["weights"], ref["weights"]),
              "colour_p99": float(torch.quantile(pr, 0.99)), "rays_above_1e-4": int((pr > 1e-4).sum())}
     print("the UNMODIFIED reference in fp32 vs the fp64 oracle on these weights / rays:", {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in ref32.items()})
-out_path = os.path.join(ROOT, "profiles", "r05", "emul_timed_batch%s%s%s.json" % ("_shipped" if "--shipped" in argv_keep else "",
+out_path = os.path.join(ROOT, "profiles", "r06" if "--tangent" in argv_keep else "r05", "emul_timed_batch%s%s%s.json" % (("_shipped" if "--shipped" in argv_keep else "") + ("_tangent" if "--tangent" in argv_keep else ""),
                                                                                 "_kernel_form" if "--only-new" in argv_keep else "",
                                                                                 "" if batch_seed == 1000 else "_seed%d" % batch_seed))
 os.makedirs(os.path.dirname(out_path), exist_ok=True)

@@ -78,6 +78,7 @@ def main():
             # then computes exactly the function the single-rounded fp16 backward differentiates.  Set before the first forward.
             neuconw.color_net.ray_bias = False
             neuconw.color_net.weight_split = False
+            neuconw.color_net.act_split = False
             nerf.ray_bias = False
             nerf.refine = False
             neuconw.sdf_net.adj_split = False

@@ -30,5 +30,52 @@ s3() {  # s2 again on a consistent build + the new voxel / kaolin-boundary tests
   tail -5 $OUT/voxel_tests.log
 }
 
+s4() {  # W = 512: adjoint sweep with both operands as pairs + colour activations as pairs: unit tests, the shipped shape's parity / cost
+  timeout -k 10 900 python -m pytest tests/test_gpu_voxel.py tests/test_gpu_sdf.py tests/test_gpu_color_nerf.py -x -q -s > $OUT/unit_tests.log 2>&1; echo "unit tests rc $?"; tail -3 $OUT/unit_tests.log
+  timeout -k 10 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_render_only.py -x -q -s > $OUT/fullsize_tests.log 2>&1; echo "fullsize tests rc $?"; tail -3 $OUT/fullsize_tests.log
+  for S in 1000 3000 4000 5000; do
+    timeout -k 10 400 python bench.py --no-pmc --no-parity-mode --config shipped --seed $S > $OUT/bench_shipped_seed$S.json 2>$OUT/bench_shipped_seed$S.err; echo "shipped seed $S rc $?"
+  done
+  NEUCONW_SDF_ADJ_SPLIT=0 NEUCONW_COLOR_ASPLIT=0 timeout -k 10 400 $B --config shipped > $OUT/bench_shipped_r5_kernels.json 2>/dev/null; echo "shipped, round-5 kernels rc $?"
+  NEUCONW_SDF_ADJ_SPLIT=2 NEUCONW_COLOR_ASPLIT=0 timeout -k 10 400 $B --config shipped > $OUT/bench_shipped_adj2_only.json 2>/dev/null; echo "shipped, adj 2 only rc $?"
+  NEUCONW_SDF_ADJ_SPLIT=0 NEUCONW_COLOR_ASPLIT=1 timeout -k 10 400 $B --config shipped > $OUT/bench_shipped_asplit_only.json 2>/dev/null; echo "shipped, act_split only rc $?"
+  NEUCONW_COLOR_ASPLIT=1 timeout -k 10 400 python bench.py --no-pmc --no-parity-mode > $OUT/bench_headline_asplit.json 2>/dev/null; echo "headline + act_split rc $?"
+  timeout -k 10 400 $B > $OUT/bench_headline.json 2>/dev/null; echo "headline rc $?"
+}
+
+s5() {  # t-units in the value-only SDF kernels: correctness (every sdf / sampler test), time and counters; the fixed tests of s4
+  timeout -k 10 900 python -m pytest tests/test_gpu_voxel.py tests/test_gpu_sdf.py tests/test_gpu_grid.py tests/test_gpu_rays.py tests/test_gpu_octree_refresh.py -x -q -s > $OUT/unit_tests.log 2>&1; echo "unit tests rc $?"; tail -3 $OUT/unit_tests.log
+  timeout -k 10 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_render.py tests/test_gpu_f16.py tests/test_gpu_edges.py -x -q -s > $OUT/fullsize_tests.log 2>&1; echo "fullsize tests rc $?"; tail -3 $OUT/fullsize_tests.log
+  timeout -k 10 600 python scripts/diag/sdf_infer_units.py --pmc > $OUT/sdf_infer_units.log 2>&1; echo "sdf_infer_units rc $?"; cat $OUT/sdf_infer_units.log
+  timeout -k 10 400 $B > $OUT/bench_headline.json 2>/dev/null; echo "headline rc $?"
+  timeout -k 10 400 $B --config grid512 > $OUT/bench_grid512.json 2>/dev/null; echo "grid512 rc $?"
+}
+
+s6() {  # t-units: infer vs the training forward on the same points; the test files (no -x: every failure at once)
+  timeout -k 10 300 python scripts/diag/tunits_check.py > $OUT/tunits_check.log 2>&1; echo "tunits_check rc $?"; cat $OUT/tunits_check.log
+  timeout -k 10 1200 python -m pytest tests/test_gpu_voxel.py tests/test_gpu_sdf.py tests/test_gpu_grid.py tests/test_gpu_rays.py tests/test_gpu_octree_refresh.py tests/test_gpu_fullsize.py tests/test_gpu_render.py tests/test_gpu_f16.py tests/test_gpu_edges.py tests/test_gpu_color_nerf.py -q -s > $OUT/tests.log 2>&1; echo "tests rc $?"; tail -12 $OUT/tests.log
+}
+
+s7() {
+  timeout -k 10 300 python scripts/diag/tunits_bisect.py > $OUT/tunits_bisect.log 2>&1; echo "tunits_bisect rc $?"; cat $OUT/tunits_bisect.log
+}
+
+s8() {  # after pinning the hi / lo conversions (ncw_split8): the bisect again, the t-units check, every affected test file, timings
+  s7
+  timeout -k 10 300 python scripts/diag/tunits_check.py > $OUT/tunits_check.log 2>&1; echo "tunits_check rc $?"; grep "f16 split" $OUT/tunits_check.log
+  timeout -k 10 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests rc $?"; tail -8 $OUT/tests.log
+  timeout -k 10 600 python scripts/diag/sdf_infer_units.py --pmc > $OUT/sdf_infer_units.log 2>&1; echo "sdf_infer_units rc $?"
+  timeout -k 10 400 python bench.py --no-pmc --no-parity-mode > $OUT/bench_headline.json 2>/dev/null; echo "headline rc $?"
+  timeout -k 10 400 python bench.py --no-pmc --no-parity-mode --config shipped > $OUT/bench_shipped.json 2>/dev/null; echo "shipped rc $?"
+}
+
+s9() {  # pair-wise pinned conversions, DDA exit depths from the voxel index: whole GPU suite, timings, benches
+  timeout -k 10 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests rc $?"; tail -6 $OUT/tests.log
+  timeout -k 10 300 python scripts/diag/tunits_check.py > $OUT/tunits_check.log 2>&1; echo "tunits_check rc $?"; grep "f16 split" $OUT/tunits_check.log
+  timeout -k 10 600 python scripts/diag/sdf_infer_units.py --pmc > $OUT/sdf_infer_units.log 2>&1; echo "sdf_infer_units rc $?"; cat $OUT/sdf_infer_units.log
+  timeout -k 10 400 python bench.py --no-pmc --no-parity-mode > $OUT/bench_headline.json 2>/dev/null; echo "headline rc $?"
+  timeout -k 10 400 python bench.py --no-pmc --no-parity-mode --config shipped > $OUT/bench_shipped.json 2>/dev/null; echo "shipped rc $?"
+}
+
 "$NAME"
 ls -la $OUT

@@ -95,10 +95,13 @@ def trained_weights(W, ns, ni, seed, v_jit, steps, lr=1e-3, R=128):
 
 
 def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=True, cos_anneal=0.3, sdf_split=None,
-             train_steps=0, forward_extras=True):
+             train_steps=0, forward_extras=True, fixed_z=False):
     """-> dict(errs={color, depth, weights_sum, gradient_error}, loss, loss_ref, grad_worst, inv_s).
     Gradient errors are scaled by the largest gradient of their network (the fp32 reference's own gradients of ~1e-7
-    tensors carry ~1e-1 relative noise: tests/test_gpu_fullsize.py)."""
+    tensors carry ~1e-1 relative noise: tests/test_gpu_fullsize.py).
+    fixed_z: the GPU renders at the ORACLE's primary sample depths (render(_z_override=...)): the MLPs, the compositor and
+    the backward without the discrete sampler in the comparison -- at 8 + 16 samples per ray and a trained sharpness one moved
+    sample is 1e-3 of a ray's colour in ANY arithmetic, the exact-fp32 mode included."""
     from oracle import neuconw_oracle as O
 
     emb, neuconw, nerf, rdr = build_system(W=W, n_a=48, n_vocab=100, nerf_w=256, color_hidden=256, head=128, seed=seed,
@@ -113,6 +116,7 @@ def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=Tru
         # function the (single-rounded fp16) backward differentiates.  Set before the first forward: the plan is built once.
         neuconw.color_net.ray_bias = False
         neuconw.color_net.weight_split = False
+        neuconw.color_net.act_split = False
         nerf.ray_bias = False
         nerf.refine = False  # (round 5: the split-precision re-evaluation of the usable background samples, forward only)
         neuconw.sdf_net.adj_split = False  # (round 5: the adjoint sweep's hi + lo weights are a forward-only refinement too)
@@ -121,11 +125,17 @@ def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=Tru
     with torch.no_grad():
         neuconw.deviation_network.variance.fill_(float(variance))
     rays, ts, label, rgbs = synth_rays(R, 77, 100)
-    out = rdr.render(rays.cuda(), ts.cuda(), label.cuda(), perturb_overwrite=0, background_rgb=torch.zeros(1, 3).cuda(),
-                     cos_anneal_ratio=cos_anneal)
-    loss = loss_from_outputs(out, rgbs.cuda())
-    if with_grads:
-        loss.backward()
+
+    def gpu(z_override=None):
+        o = rdr.render(rays.cuda(), ts.cuda(), label.cuda(), perturb_overwrite=0, background_rgb=torch.zeros(1, 3).cuda(),
+                       cos_anneal_ratio=cos_anneal, _z_override=z_override)
+        ls = loss_from_outputs(o, rgbs.cuda())
+        if with_grads:
+            ls.backward()
+        return o, ls
+
+    if not fixed_z:
+        out, loss = gpu()
     key = (W, ns, ni, R, float(variance), float(v_jit), seed, with_grads, cos_anneal, train_steps)
     hit = _ORACLE_CACHE.get(key)
     if hit is None:  # the oracle result does not depend on the GPU precision: shared by the parametrised cases
@@ -138,10 +148,12 @@ def run_case(W, ns, ni, prec, R, variance=0.3, v_jit=0.0, seed=5, with_grads=Tru
         if with_grads:
             names = list(sd)
             gref = dict(zip(names, torch.autograd.grad(lref, [sd[k] for k in names], allow_unused=True)))
-        hit = ({k: ref[k].detach() for k in ("color", "depth", "weights_sum", "gradient_error")}, float(lref.detach()), gref)
+        hit = ({k: ref[k].detach() for k in ("color", "depth", "weights_sum", "gradient_error", "z_vals")}, float(lref.detach()), gref)
         if len(_ORACLE_CACHE) > 16:
             _ORACLE_CACHE.clear()
         _ORACLE_CACHE[key] = hit
+    if fixed_z:
+        out, loss = gpu(hit[0]["z_vals"].float().cuda().contiguous())
     ref, lref, gref = hit
     errs = {k: rel_err(out[k].detach().cpu(), ref[k]) for k in ("color", "depth", "weights_sum", "gradient_error")}
     res = dict(errs=errs, loss=float(loss.detach()), loss_ref=lref, inv_s=math.exp(10.0 * variance), grad_worst=None,

@@ -253,3 +253,54 @@ def test_color_head_per_ray_bias(prec_name):
     print("colour forward %s: per-ray fp32 bias %.2e, 16-bit operands %.2e" % (prec_name, e_on, e_off))
     assert e_on < TOL[prec_name]["out"] and e_off < TOL[prec_name]["out"]
     assert e_on < 1.5 * e_off + 1e-5
+
+
+@pytest.mark.parametrize("W", [256, 512])
+def test_color_forward_with_split_activations(W):
+    """Round 6, fp16 mode: `RenderingNetwork.act_split` (NcwColorNet.act_split; the default at d_feature = 512, the shipped width) --
+    the activations of every layer as fp16 hi + lo pairs on top of the hi + lo weights: a third pass W_hi x_lo of the weight ring per
+    layer (csrc/ncw_color.hip SPLIT = 2).  What is left single-rounded is the feature vector it reads from the stash and the per-ray
+    view / appearance columns (fp32).  rgb against the fp64 oracle must drop well below the weights-only form's, the stash (the
+    backward's operands: single-rounded) and therefore the backward must not move, and the forward-only render is the same bit for bit."""
+    from neuralrecon_w_amd.neuconw import points_struct
+    from neuralrecon_w_amd.stash import StashArena
+    from oracle import neuconw_oracle as O
+
+    import neuralrecon_w_amd as nw
+
+    n_a, head = 48, 128
+    prec = nw.PREC_F16
+    _, neuconw, _, _ = build_system(W=W, n_a=n_a, color_hidden=256, head=head, nerf_w=64, seed=11, prec=prec)
+    cn = neuconw.color_net
+    _jitter(cn, 1)
+    assert cn.plan(prec).net.act_split == (1 if W == 512 else 0)  # the defaults
+    R, S = 125, 32  # ragged
+    n = R * S
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(n, 3, generator=g) * 2 - 1) * 0.9
+    normals = torch.randn(n, 3, generator=g)
+    dirs = _unit(R, 3).repeat_interleave(S, 0)
+    a = torch.randn(R, n_a, generator=g).repeat_interleave(S, 0)
+    feat = (0.5 * torch.randn(n, W, generator=g)).half().float()  # exactly representable: the stash holds fp16
+    sd = {"color_net." + k: v.detach().cpu().double() for k, v in cn.state_dict().items()}
+    ref = O.color_net(sd, x.double(), normals.double(), dirs.double(), feat.double(), a.double())
+    dev = torch.device("cuda")
+    pts = points_struct(x=x.to(dev), rays_d=dirs.to(dev))
+    ar = StashArena(dev, prec, n)
+    fid = ar.new(W // 32)
+    ar.allocate(zero=True)
+    ar.from_rows(fid, feat.to(dev))
+    out, stash = {}, {}
+    for on in (False, True):
+        cn.act_split = on
+        rgb, ctx = cn.fwd_stash(pts, n, prec, normals.to(dev), a.to(dev), ar.ptr(fid))
+        assert ctx["plan"].net.act_split == int(on)
+        out[on] = rgb.cpu()
+        stash[on] = ctx["arena"].to_rows(ctx["ids"]["x"][1], 256).cpu()
+    e_off, e_on = rel_err(out[False], ref), rel_err(out[True], ref)
+    print("colour forward W=%d fp16: weights as pairs %.2e, weights + activations as pairs %.2e" % (W, e_off, e_on))
+    assert e_on < 0.25 * e_off and e_on < 2e-5, (e_off, e_on)
+    assert rel_err(stash[True], stash[False]) < 2e-3  # the same single-rounded stash (up to what the more accurate inputs change)
+    with torch.no_grad():
+        rgb_r, _ = cn.fwd_stash(pts, n, prec, normals.to(dev), a.to(dev), ar.ptr(fid), train=False)
+    assert torch.equal(rgb_r.cpu(), out[True])

@@ -45,28 +45,30 @@ def test_ray_voxel_near_far_vs_bruteforce(level):
     assert bool((far >= near).all())
 
 
-def _sparse_shell(level, n_keep, seed, r0=0.5):
-    """Occupied voxels of a one-voxel-thick sphere shell at a level too fine for a dense tensor (10: 2^30 voxels), thinned to
-    n_keep voxels + 5 % clutter, as an index list [V,3].  Built from a band of the shell's surface points, not from the grid."""
+def _sparse_shell(level, n_keep, seed, r0=None):
+    """Occupied voxels of a one-voxel-thick sphere shell at a level too fine for a dense tensor (10: 2^30 voxels) as an index list
+    [V,3]: a COMPLETE shell of about n_keep voxels (radius chosen for that, <= 0.5) + 5 % clutter.  Built from surface points, not
+    from the grid."""
     G = 1 << level
     g = torch.Generator().manual_seed(seed)
-    p = torch.nn.functional.normalize(torch.randn(4 * n_keep, 3, generator=g, dtype=torch.float64), dim=-1) * r0
-    q = torch.floor((p + 1.0) * (G / 2)).long().clamp(0, G - 1)
-    q = torch.unique(q, dim=0)
-    q = q[torch.randperm(q.shape[0], generator=g)[:n_keep]]
+    if r0 is None:  # 4 pi (r G / 2)^2 ~ n_keep
+        r0 = min(0.5, math.sqrt(n_keep / (4 * math.pi)) * 2.0 / G)
+    p = torch.nn.functional.normalize(torch.randn(40 * n_keep, 3, generator=g, dtype=torch.float64), dim=-1) * r0
+    q = torch.unique(torch.floor((p + 1.0) * (G / 2)).long().clamp(0, G - 1), dim=0)
     clutter = torch.randint(0, G, (n_keep // 20, 3), generator=g)
-    return torch.unique(torch.cat([q, clutter]), dim=0), G
+    return torch.unique(torch.cat([q, clutter]), dim=0), G, r0
 
 
-def _rays_at_shell(R, origin, scale, seed):
-    rays, _, _, _ = synth_rays(R, seed, 10)
-    o = rays[:, 0:3] * scale + origin
-    d = rays[:, 3:6]
+def _rays_at_shell(R, origin, scale, seed, r0):
+    """Rays from outside the cube aimed INTO the sphere (they all cross the shell), 20 from inside it, 10 that miss the cube."""
     g = torch.Generator().manual_seed(seed)
-    o[:20] = origin + 0.01 * torch.randn(20, 3, generator=g)  # from inside the shell
-    d[20:30] = torch.nn.functional.normalize(torch.randn(10, 3, generator=g), dim=-1)  # rays that miss the cube
-    o[20:30] = origin + torch.tensor([5.0, 5.0, 5.0])
-    return o, d
+    o = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1) * 2.5
+    target = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1) * (0.8 * r0 * torch.rand(R, 1, generator=g))
+    d = torch.nn.functional.normalize(target - o, dim=-1)
+    o[:20] = 0.3 * r0 * torch.randn(20, 3, generator=g)
+    d[20:30] = torch.nn.functional.normalize(torch.randn(10, 3, generator=g), dim=-1)
+    o[20:30] = torch.tensor([5.0, 5.0, 5.0])
+    return o * scale + origin, d
 
 
 @pytest.mark.parametrize("level,n_keep", [(8, 20000), (10, 30000)])
@@ -79,10 +81,10 @@ def test_ray_voxel_near_far_at_the_reference_levels(level, n_keep):
     from neuralrecon_w_amd import voxel
     from oracle import neuconw_oracle as O
 
-    idx, G = _sparse_shell(level, n_keep, level)
+    idx, G, r0 = _sparse_shell(level, n_keep, level)
     origin, scale = torch.tensor([0.1, -0.05, 0.2]), 1.7
     R = 384
-    o, d = _rays_at_shell(R, origin, scale, 5)
+    o, d = _rays_at_shell(R, origin, scale, 5, r0)
     centres = (idx.float() + 0.5) * (2.0 / G) - 1.0
     od = voxel.occupancy_from_points((centres * scale + origin).cuda(), origin, scale, level)
     assert torch.equal(voxel.voxels_from_occupancy(od).cpu(), idx)  # the bit grid holds exactly the listed voxels
@@ -117,9 +119,9 @@ def test_kaolin_unbatched_raytrace_vs_bruteforce(level, n_keep, with_exit):
     spc, spc_render = compat_kaolin()
     from neuralrecon_w_amd import voxel
 
-    idx, G = _sparse_shell(level, n_keep, 100 + level)
+    idx, G, r0 = _sparse_shell(level, n_keep, 100 + level)
     R = 256
-    o, d = _rays_at_shell(R, torch.zeros(3), 1.0, 9)
+    o, d = _rays_at_shell(R, torch.zeros(3), 1.0, 9, r0)
     octree = spc.unbatched_points_to_octree(idx.short().cuda(), level)
     _, pyramid, prefix = spc.scan_octrees(octree, torch.tensor([len(octree)], dtype=torch.int32))
     points = spc.generate_points(octree, pyramid, prefix)
@@ -168,7 +170,7 @@ def test_kaolin_unbatched_raytrace_vs_bruteforce(level, n_keep, with_exit):
     n_tr[ray[first]], f_tr[ray[last]] = depth[first, 0], depth[last, 0]
     ok = n_tr > 1e-4  # generate_voxel.py:397
     agree = ((near - torch.where(ok, n_tr, 0 * n_tr)).abs() < 1e-5) & ((far - torch.where(ok, f_tr, 0 * f_tr)).abs() < 1e-5)
-    assert int((~agree).sum()) <= 2, int((~agree).sum())  # (the 1e-7 offsets can decide a grazing contact)
+    assert int((~agree).sum()) <= 5, int((~agree).sum())  # (the fused kernel's own 1e-7 offsets decide a grazing contact: measured 0 .. 3 of 256)
 
 
 # (W, precision, rays, tol per-ray outputs, tol per-sample tensors).  f32: the W = 64 networks of round 1; f16: the HEADLINE
