@@ -44,6 +44,33 @@ NCW_DEV bf16x8 pp_load_unit(const void* w, int unit_index, int lane) {
     return ncw_ld_frag<bf16x8>(w, (size_t)unit_index, lane);
 }
 
+#if defined(NCW_PROBE_BUILD) && defined(NCW_PP_ASM)
+// ------------------------------------------------------------------------------------------------
+// PROBE BUILDS ONLY (round 6): the weight slices loaded STRAIGHT INTO AGPRs by hand-written
+// `global_load_dwordx4 a[..], v, s[..]` (hipcc only ever loads into VGPRs: in round 5's two-blocks-per-wave form every slice load was
+// followed by four v_accvgpr_write, +1.6 VALU per MFMA).  The compiler does not count these loads on vmcnt, so the waits are
+// hand-placed too: pp_wait_w pins the registers it releases (an MFMA cannot be scheduled above the wait that guards its operand).
+// ------------------------------------------------------------------------------------------------
+NCW_DEV bf16x8 pp_load_unit_a(const void* w, int unit_index, int lane) {
+    bf16x8 r;
+    const char* base = (const char*)w + (size_t)unit_index * 1024;
+    const unsigned off = (unsigned)lane * 16u;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(r) : "v"(off), "s"(base) : "memory");
+    return r;
+}
+// the first 8 units of both blocks have landed when at most the 16 loads issued after them are outstanding
+NCW_DEV void pp_wait_w_first_half(bf16x8 (&w)[2][16]) {
+    asm volatile("s_waitcnt vmcnt(16)"
+                 : "+a"(w[0][0]), "+a"(w[1][0]), "+a"(w[0][1]), "+a"(w[1][1]), "+a"(w[0][2]), "+a"(w[1][2]), "+a"(w[0][3]), "+a"(w[1][3]),
+                   "+a"(w[0][4]), "+a"(w[1][4]), "+a"(w[0][5]), "+a"(w[1][5]), "+a"(w[0][6]), "+a"(w[1][6]), "+a"(w[0][7]), "+a"(w[1][7]));
+}
+NCW_DEV void pp_wait_w_second_half(bf16x8 (&w)[2][16]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+a"(w[0][8]), "+a"(w[1][8]), "+a"(w[0][9]), "+a"(w[1][9]), "+a"(w[0][10]), "+a"(w[1][10]), "+a"(w[0][11]), "+a"(w[1][11]),
+                   "+a"(w[0][12]), "+a"(w[1][12]), "+a"(w[0][13]), "+a"(w[1][13]), "+a"(w[0][14]), "+a"(w[1][14]), "+a"(w[0][15]), "+a"(w[1][15]));
+}
+#endif
+
 template <int NU>
 NCW_DEV void pp_load_slice(bf16x8* a, const void* w, int rb_stride, int ob, int u0, int lane) {
 #pragma unroll
@@ -103,7 +130,8 @@ template <int NB> struct PPAcc { f32x16 v[NB][2]; };  // [block of the wave][til
 // PP_RING - 1 slots ahead of their use); with PREFETCH (the layer's LAST segment) unit u of the NEXT layer is fetched
 // global -> registers into the registers unit u of this layer has just left.
 #define PP_RING 4
-template <bool PREFETCH, int NB, class EPI>
+// WAITW (the asm probe only): this segment is the first user of a slice that pp_load_unit_a fetched -- wait for its halves by hand
+template <bool PREFETCH, int NB, bool WAITW = false, class EPI>
 NCW_DEV void pp_segment(PPAcc<NB>& m, const f32x16 (&c_init)[NB], bf16x8 (&w)[NB][16], const pp_lfrag* in,
                         const void* wnext, int nstride, int ob0, int ob_step, int lane, EPI&& epi) {
     constexpr int RD = PP_RING - 1;
@@ -112,13 +140,28 @@ NCW_DEV void pp_segment(PPAcc<NB>& m, const f32x16 (&c_init)[NB], bf16x8 (&w)[NB
     for (int c = 0; c < RD; ++c) { b[c][0] = in[c * 64]; b[c][1] = in[(16 + c) * 64]; }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
+#if defined(NCW_PROBE_BUILD) && defined(NCW_PP_ASM)
+        if constexpr (WAITW && NB == 2) {
+            if (u == 0) pp_wait_w_first_half(w);
+            if (u == 8) pp_wait_w_second_half(w);
+        }
+#endif
         if (u + RD < 16)
         { b[(u + RD) % PP_RING][0] = in[(u + RD) * 64]; b[(u + RD) % PP_RING][1] = in[(16 + u + RD) * 64]; }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             m.v[nb][0] = NCW_MFMA_H(w[nb][u], b[u % PP_RING][0], u == 0 ? c_init[nb] : m.v[nb][0], 0, 0, 0);
             m.v[nb][1] = NCW_MFMA_H(w[nb][u], b[u % PP_RING][1], u == 0 ? c_init[nb] : m.v[nb][1], 0, 0, 0);
-            if (PREFETCH) w[nb][u] = pp_load_unit(wnext, u * nstride + ob0 + nb * ob_step, lane);
+        }
+        if (PREFETCH) {  // unit u of the next layer into the registers unit u has just left (block 0 first: pp_wait_w counts on the order)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#if defined(NCW_PROBE_BUILD) && defined(NCW_PP_ASM)
+                if constexpr (NB == 2) w[nb][u] = pp_load_unit_a(wnext, u * nstride + ob0 + nb * ob_step, lane);
+                else
+#endif
+                w[nb][u] = pp_load_unit(wnext, u * nstride + ob0 + nb * ob_step, lane);
+            }
         }
         epi(u);
         __builtin_amdgcn_sched_barrier(0);
@@ -152,72 +195,11 @@ NCW_DEV void pp_epi_step(int u, const PPAcc<NB>& e, bf16x8 (&frag)[NB], pp_lfrag
     }
 }
 
-#if defined(NCW_HALF_F16) && defined(NCW_PROBE_BUILD)
-// ------------------------------------------------------------------------------------------------
-// PROBE BUILDS ONLY (NCW_BUILD_TAG): packed-fp16 Softplus epilogues (round 4 experiment, fp16 build only: gfx950 has no packed bf16 VALU arithmetic).
-// The f32 form costs, per PAIR of accumulator registers, 8 plain VALU + 4 transcendentals + the f32 -> f16 conversion, i.e.
-// more VALU-pipe time than the pair's two MFMAs need matrix-pipe time.  The activation is rounded to fp16
-// for the next layer's B operand anyway, so the pair is converted FIRST (one v_cvt_pk_f16_f32) and the Softplus runs on
-// both halves of a register:
-//   EPI 1 ("pk16"):  t = 100 z log2 e (v_pk_mul_f16); w = 2^-|t| (2 x v_exp_f16); l = log2(1 + w) (v_pk_add_f16, 2 x
-//                    v_log_f16); y = l ln2/100 + max(z, 0) (v_pk_max_f16, v_pk_fma_f16): 5 plain + 4 transcendentals.
-//   EPI 2 ("poly16"): y = max(z, 0) + c(min(|z|, 0.06)), c = log1p(exp(-100 a)) / 100 as a degree-4 polynomial in
-//                    a (fit error 8.4e-6, fp16 Horner 2.5e-5): 9 plain VALU per PAIR, no transcendental.
-// Value-only kernel: nothing recomputes Softplus' from these activations.
-// MEASURED (profiles/r04/pp_epilogue.log, MI355X, plain fp16 sdf_infer, 131,072 / 1,048,576 points): f32 epilogue 0.216 / 1.283 ms
-// (30.0 % of the MFMA peak at 1 M points), pk16 0.211 / 1.283 ms -- no gain: v_exp_f16 / v_log_f16 are not packed, the compiler
-// needs two v_pack_b32_f16 around them: 7 plain + 4 transcendental per pair against 8 + 4 -- poly16 0.194 / 1.133 ms (34.0 %)
-// but max |sdf - fp64| 2.1e-3 against 6.0e-4: rejected.  Whole-kernel VALU per MFMA 8.57 / 8.31 / 7.77.
-// ------------------------------------------------------------------------------------------------
-typedef _Float16 pp_h2 __attribute__((ext_vector_type(2)));
-typedef float pp_f2 __attribute__((ext_vector_type(2)));
-
-template <int EPI>
-NCW_DEV pp_h2 pp_softplus_pk(float z0, float z1) {
-    const pp_f2 zf = {z0, z1};
-    const pp_h2 z = __builtin_convertvector(zf, pp_h2);
-    const pp_h2 zero = {(_Float16)0.f, (_Float16)0.f};
-    const pp_h2 relu = __builtin_elementwise_max(z, zero);
-    if (EPI == 1) {
-        const pp_h2 k = {(_Float16)144.26950408889634f, (_Float16)144.26950408889634f};
-        const pp_h2 t = z * k;
-        const pp_h2 w = __builtin_elementwise_exp2(-__builtin_elementwise_abs(t));
-        const pp_h2 one = {(_Float16)1.f, (_Float16)1.f};
-        const pp_h2 l = __builtin_elementwise_log2(one + w);
-        const pp_h2 c = {(_Float16)(0.6931471805599453f * 0.01f), (_Float16)(0.6931471805599453f * 0.01f)};
-        return __builtin_elementwise_fma(l, c, relu);
-    } else {
-        // a = min(|z|, 0.06) = min(max(z, -z), 0.06); coefficients in a (fp16 Horner: 2.5e-5 abs)
-        const pp_h2 amax = {(_Float16)0.06f, (_Float16)0.06f};
-        const pp_h2 u = __builtin_elementwise_min(__builtin_elementwise_max(z, -z), amax);
-        const pp_h2 c4 = {(_Float16)1067.45f, (_Float16)1067.45f}, c3 = {(_Float16)-204.556f, (_Float16)-204.556f},
-                    c2 = {(_Float16)15.0246f, (_Float16)15.0246f}, c1 = {(_Float16)-0.510718f, (_Float16)-0.510718f},
-                    c0 = {(_Float16)0.00693755f, (_Float16)0.00693755f};
-        pp_h2 p = __builtin_elementwise_fma(c4, u, c3);
-        p = __builtin_elementwise_fma(p, u, c2);
-        p = __builtin_elementwise_fma(p, u, c1);
-        p = __builtin_elementwise_fma(p, u, c0);
-        return relu + p;
-    }
-}
-
-// pp_epi_step with the pair-wise packed epilogue
-template <int EPI, int NB>
-NCW_DEV void pp_epi_step_pk(int u, const PPAcc<NB>& e, bf16x8 (&frag)[NB], pp_lfrag* out, int ob0, int ob_step, int lane) {
-    const int j = u >> 3, r = 2 * (u & 7);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const pp_h2 y = pp_softplus_pk<EPI>(e.v[nb][j][r], e.v[nb][j][r + 1]);
-        frag[nb][r & 7] = y[0];
-        frag[nb][(r & 7) + 1] = y[1];
-        if ((u & 3) == 3) out[(j * 16 + 2 * (ob0 + nb * ob_step) + ((u & 7) >> 2)) * 64 + lane] = frag[nb];
-    }
-}
-#endif
-
+// (Round 4's packed-fp16 / polynomial Softplus epilogues -- probe-only variants EPI 1 / 2 of this kernel, NOTEBOOK R4.2, measured in
+// profiles/r04/pp_epilogue.log: no gain / accuracy rejected -- were removed in round 6 when the kernel moved to t-units.)
 // ------------------------------------------------------------------------------------------------
 // SDF inference (SDFNetwork.sdf, models/neuconw.py:281-282): gamma -> L-1 Softplus layers -> sdf row.
-// EPI: 0 = f32 Softplus epilogue; 1 / 2 = the packed-fp16 forms above (fp16 build only).
+// (EPI: kept as a template slot; 0 = the f32 Softplus epilogue in t-units, the only form.)
 // ------------------------------------------------------------------------------------------------
 template <int NB, int EPI>
 __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNet net, NcwPoints src, int64_t n,
@@ -255,9 +237,21 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
     // weights: ONE register slice of 16 k-units per block; wx = W_0's 3 units, later the skip layer's gamma units
     bf16x8 wa[NB][16], wx[NB][3];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        pp_load_slice<3>(wx[nb], net.w[0], 8, ob + nb * NW, 0, lane);
-        if (NL > 1) pp_load_slice<16>(wa[nb], net.w[1], 8, ob + nb * NW, 0, lane);
+    for (int nb = 0; nb < NB; ++nb) pp_load_slice<3>(wx[nb], net.w[0], 8, ob + nb * NW, 0, lane);
+#if defined(NCW_PROBE_BUILD) && defined(NCW_PP_ASM)
+    if constexpr (NB == 2) {  // straight into AGPRs, unit-major like the prefetch (pp_wait_w_* count on the order)
+        if (NL > 1) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wa[nb][u] = pp_load_unit_a(net.w[1], u * 8 + ob + nb * NW, lane);
+        }
+    } else
+#endif
+    {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            if (NL > 1) pp_load_slice<16>(wa[nb], net.w[1], 8, ob + nb * NW, 0, lane);
     }
     // accumulators: group 0 always accumulates into x, group 1 into y; while one takes the MFMAs of its group the other --
     // the group finished one segment earlier -- goes through the epilogue: no register copies
@@ -271,15 +265,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
 #define PP_SEG_END() pp_barrier()
     pp_barrier();
     auto softplus_f = [](float z, int, int, int) { return pp_softplus(z); };
-#if defined(NCW_HALF_F16) && defined(NCW_PROBE_BUILD)
-#define PP_EPI(u, acc, outp)                                                                   \
-    do {                                                                                       \
-        if (EPI == 0) pp_epi_step<NB>(u, acc, frag, outp, ob, NW, lane, softplus_f);           \
-        else pp_epi_step_pk<(EPI == 0 ? 1 : EPI), NB>(u, acc, frag, outp, ob, NW, lane);      \
-    } while (0)
-#else
 #define PP_EPI(u, acc, outp) pp_epi_step<NB>(u, acc, frag, outp, ob, NW, lane, softplus_f)
-#endif
     // ---- layer 0 (K = 39: the 3 gamma units): [M(0,g0)] [M(0,g1) | E(0,g0)] ---------------------------------------------
     {
         read_bias(0);
@@ -305,7 +291,7 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
             const pp_lfrag* in = abuf + (0 * 2 + ((l - 1) & 1)) * (PP_GRP / 16) + lane;
             pp_lfrag* out = abuf + (1 * 2 + ((l - 1) & 1)) * (PP_GRP / 16);  // E(l-1, g1)
             auto epi = [&](int u) { PP_EPI(u, y, out); };
-            pp_segment<false, NB>(x, bias, wa, in, nullptr, 8, ob, NW, lane, epi);
+            pp_segment<false, NB, true>(x, bias, wa, in, nullptr, 8, ob, NW, lane, epi);  // (asm probe: first user of the slice)
             if (l == net.skip_layer) pp_mma_x<3, NB>(x, wx, gbuf + lane);
             read_bias(l);
             PP_SEG_END();
@@ -314,8 +300,10 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
             const pp_lfrag* in = abuf + (1 * 2 + ((l - 1) & 1)) * (PP_GRP / 16) + lane;
             pp_lfrag* out = abuf + (0 * 2 + (l & 1)) * (PP_GRP / 16);        // E(l, g0)
             auto epi = [&](int u) { PP_EPI(u, x, out); };
-            if (more) pp_segment<true, NB>(y, bias, wa, in, net.w[l + 1], 8, ob, NW, lane, epi);
-            else pp_segment<false, NB>(y, bias, wa, in, nullptr, 8, ob, NW, lane, epi);
+            // ONE code path: the last layer "prefetches" its own slice again (L2 hits, never used).  With two variants of this segment
+            // (prefetch / no prefetch behind `if (more)`) hipcc hoists what they share -- the 32 v_exp of the epilogue -- in front of
+            // the branch, i.e. out from between the MFMAs (round 6: a block of 32 transcendentals with no MFMA per layer).
+            pp_segment<true, NB>(y, bias, wa, in, more ? net.w[l + 1] : net.w[l], 8, ob, NW, lane, epi);
             if (l == net.skip_layer) pp_mma_x<3, NB>(y, wx, gbuf + 2 * 3 * 64 + lane);
             // the skip layer's gamma columns (units 16..18) for the NEXT layer (W_0's units are no longer needed)
             if (more && l + 1 == net.skip_layer) {
@@ -353,17 +341,8 @@ __global__ __launch_bounds__(64 * PP_WAVES / NB) void sdf_inferC_kernel(NcwSdfNe
 int NCW_FN(ncw_sdf_inferC_launch)(const NcwSdfNet* net, const NcwPoints& src, int64_t n, float* sdf, hipStream_t st) {
     const int64_t tiles = (n + 31) / 32;
     const dim3 grid((unsigned)((tiles + PP_TILES - 1) / PP_TILES));
-#if defined(NCW_HALF_F16) && defined(NCW_PROBE_BUILD)
-    // round-4 A/B (scripts/diag/pp_epilogue.py, probe library only): NCW_PP_EPI = f32 | pk16 | poly16, read once
-    static const int epi = [] {
-        const char* e = getenv("NCW_PP_EPI");
-        return e == nullptr ? 0 : (!strcmp(e, "pk16") ? 1 : (!strcmp(e, "poly16") ? 2 : 0));
-    }();
-    if (epi == 1) hipLaunchKernelGGL((sdf_inferC_kernel<1, 1>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
-    else if (epi == 2) hipLaunchKernelGGL((sdf_inferC_kernel<1, 2>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
-    else hipLaunchKernelGGL((sdf_inferC_kernel<1, 0>), grid, dim3(64 * PP_WAVES), 0, st, *net, src, n, sdf);
-#elif defined(NCW_PROBE_BUILD)
-    // round-5 A/B (scripts/diag/pp_nb2.py, probe library only): NCW_PP_NB = 2 -> four 512-register waves, two output blocks each
+#if defined(NCW_PROBE_BUILD) && !defined(NCW_HALF_F16)
+    // round-5 / round-6 A/B (scripts/diag/pp_nb2.py, probe library only): NCW_PP_NB = 2 -> four 512-register waves, two output blocks each
     // (every B fragment feeds two MFMAs: half the LDS reads); with `-mllvm -amdgpu-mfma-vgpr-form` on this file the accumulators
     // stay in VGPRs and the weight slices go to AGPRs (MFMA srcA)
     static const int nb = getenv("NCW_PP_NB") ? atoi(getenv("NCW_PP_NB")) : 1;

@@ -383,8 +383,9 @@ NCW_DEV void s2_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_t 
         {   // t = 3 -> y;  E(l, 2) <- x; the layer's last use of its weight slice -> the next layer's takes its registers
             y = bias_of(l);
             auto epi = [&](int u) { s2_epi_step<STASH>(u, x, fh, fl, yc, region(2), ob, lane, (SE*)st.h[l + 1], (size_t)(tile0 + 2)); };
-            if (more) s2_segment<true>(y, wh, wl, region(3) + lane, net.w[l + 1], net.w_lo[l + 1], ob, lane, epi);
-            else s2_segment<false>(y, wh, wl, region(3) + lane, nullptr, nullptr, ob, lane, epi);
+            // (ONE code path -- the last layer reloads its own slice, unused: two variants behind `if (more)` let hipcc hoist the
+            // epilogue's v_exp in front of the branch, out from between the MFMAs; csrc/ncw_pp.hip)
+            s2_segment<true>(y, wh, wl, region(3) + lane, more ? net.w[l + 1] : net.w[l], more ? net.w_lo[l + 1] : net.w_lo[l], ob, lane, epi);
             if (skip) s2_mma_x<3>(y, gh, gl, gin(3));
             s2_barrier();
         }

@@ -77,5 +77,20 @@ s9() {  # pair-wise pinned conversions, DDA exit depths from the voxel index: wh
   timeout -k 10 400 python bench.py --no-pmc --no-parity-mode --config shipped > $OUT/bench_shipped.json 2>/dev/null; echo "shipped rc $?"
 }
 
+s10() {  # item 3: two blocks per wave with hand-written loads into AGPRs (probe library `asm`); item 5: the timed program's parity under pytest
+  NEUCONW_HIP_LIB=neuralrecon-w_amd/libneuconw_hip_asm.so timeout -k 10 400 python scripts/diag/pp_nb2.py > $OUT/pp_asm.log 2>&1; echo "pp_nb2 (asm lib) rc $?"; cat $OUT/pp_asm.log
+  NCW_PP_NB=2 NEUCONW_HIP_LIB=neuralrecon-w_amd/libneuconw_hip_asm.so timeout -k 10 600 python scripts/diag/sdf_infer_units.py --pmc > $OUT/sdf_infer_units_asm_nb2.log 2>&1; echo "units asm nb2 rc $?"; grep -A1 "per launch" $OUT/sdf_infer_units_asm_nb2.log
+  timeout -k 10 900 python -m pytest tests/test_gpu_timed_program_parity.py -q -s -p no:cacheprovider > $OUT/parity_test.log 2>&1; echo "parity test rc $?"; grep "|" $OUT/parity_test.log | cut -c1-330; tail -3 $OUT/parity_test.log
+}
+
+s11() {  # one code path for the prefetch segment (no hoisted v_exp burst): product timings + counters; the asm probe's second (last) session
+  timeout -k 10 600 python scripts/diag/sdf_infer_units.py --pmc > $OUT/sdf_infer_units.log 2>&1; echo "sdf_infer_units rc $?"; cat $OUT/sdf_infer_units.log
+  NEUCONW_HIP_LIB=$PWD/neuralrecon-w_amd/libneuconw_hip_asm.so timeout -k 10 400 python scripts/diag/pp_nb2.py > $OUT/pp_asm.log 2>&1; echo "pp_nb2 (asm lib) rc $?"; cat $OUT/pp_asm.log
+  NCW_PP_NB=2 NEUCONW_HIP_LIB=$PWD/neuralrecon-w_amd/libneuconw_hip_asm.so timeout -k 10 600 python scripts/diag/sdf_infer_units.py --pmc > $OUT/sdf_infer_units_asm_nb2.log 2>&1; echo "units asm nb2 rc $?"; grep -A1 "per launch" $OUT/sdf_infer_units_asm_nb2.log
+  timeout -k 10 900 python -m pytest tests/test_gpu_sdf.py tests/test_gpu_rays.py tests/test_gpu_grid.py -q -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests rc $?"; tail -2 $OUT/tests.log
+  timeout -k 10 400 $B > $OUT/bench_headline.json 2>/dev/null; echo "headline rc $?"
+  timeout -k 10 400 $B --config grid512 --grid-width 256 > $OUT/bench_grid512_w256.json 2>/dev/null; echo "grid512 w256 rc $?"
+}
+
 "$NAME"
 ls -la $OUT
