@@ -722,10 +722,15 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="record the step into HIP graphs and replay it (trainer.TrainStep(capture=True)); measured "
                          "4.78 vs 4.80 ms eager on one MI355X -- the step is not host-launch-bound -- so eager is the default")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="run the background NeRF's launches on the main stream too (NEUCONW_BG_STREAM=0): nothing overlaps, so a rocprofv3 "
+                         "kernel trace of this run reproduces `per_step_kernel_ms` kernel by kernel (profiles/r06/bench_onestream_*)")
     ap.add_argument("--dist-check", action="store_true",
                     help="initialise the process group, print {world, ranks, devices} from rank 0 and exit (launcher test; "
                          "needs no GPU with NCW_DIST_BACKEND=gloo)")
     args = ap.parse_args()
+    if args.one_stream:  # read when the renderer is constructed (and inherited by the PMC / parity child processes)
+        os.environ["NEUCONW_BG_STREAM"] = "0"
     # ---- self-launch: `python bench.py --gpus N` (N > 1) outside torch.distributed.run starts the N ranks itself,
     # one process per GPU over RCCL (train.py:53-55: gpus=N, accelerator='ddp'); under torchrun WORLD_SIZE is set
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1147,6 +1152,7 @@ def main():
                        "rays_per_gpu": R, "samples_per_ray": S, "global_rays": world * R, "parallelism": "dp%d" % world,
                        "world_size": world, "ranks": ranks,
                        "submission": "hip-graph replay" if args.graph else "eager",
+                       "streams": 1 if os.environ.get("NEUCONW_BG_STREAM", "1") in ("0", "") else 2,
                        "final_loss": float(loss.detach()), "skipped_steps": skipped},
             "allreduce": allreduce, "allreduce_ms": allreduce.get("allreduce_ms") if allreduce else None,
             "roofline": roofline, "parity": parity_obj, "parity_mode": parity, "alt_mode": alt, "plain_f16_mode": plain,

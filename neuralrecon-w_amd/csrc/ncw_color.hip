@@ -57,16 +57,16 @@ NCW_DEV void relu_epilogue_hl(Act<P, RB>& act, Act<P, RB>& act_lo, CVec<RB>& acc
     }
 }
 
-// acc += W_hi in + W_lo in + W_hi in_lo: weights AND activations as fp16 hi + lo pairs, three passes of the weight ring
-// (round 6, ASPLIT).  Chaining like mma_stream_split: self_bytes = first-chunk bytes of this matrix shape.
+// acc += W_hi (in + in_lo) + W_lo in: weights AND activations as fp16 hi + lo pairs (round 6, ASPLIT) in TWO passes of the weight ring --
+// the W_hi pass feeds every fragment to two MFMAs (the hi and the lo half of the activations), the W_lo pass to one.
+// Chaining like mma_stream_split: self_bytes = first-chunk bytes of this matrix shape.
 template <int RB_IN, int RB_OUT, int K_REAL, int SLOT, class P>
 NCW_DEV void mma_stream_split3(CVec<RB_OUT>& acc, const Act<P, RB_IN>& in, const Act<P, RB_IN>& in_lo, WRing& ring,
                                const typename P::welem* __restrict__ w_hi, const void* w_lo, int self_bytes, const void* w_next,
                                int next_bytes, int lane) {
     typedef typename P::welem WE;
-    mma_stream<RB_IN, RB_OUT, K_REAL, SLOT>(acc, in, ring, w_hi, w_lo, self_bytes, lane);
-    mma_stream<RB_IN, RB_OUT, K_REAL, SLOT>(acc, in, ring, (const WE*)w_lo, w_hi, self_bytes, lane);
-    mma_stream<RB_IN, RB_OUT, K_REAL, SLOT>(acc, in_lo, ring, w_hi, w_next, next_bytes, lane);
+    mma_stream2<RB_IN, RB_OUT, K_REAL, SLOT>(acc, in, in_lo, ring, w_hi, w_lo, self_bytes, lane);
+    mma_stream<RB_IN, RB_OUT, K_REAL, SLOT>(acc, in, ring, (const WE*)w_lo, w_next, next_bytes, lane);
 }
 
 template <class P, int RBF, int RBH, int RBC, bool WIDE = false>
@@ -176,11 +176,8 @@ NCW_DEV void color_fwd_body(const NcwColorNet& net, const NcwPoints& src, int64_
         const void* wn = net.n_head > 1 ? net.w_e[1] : net.w_l[0];
         const int nb = net.n_head > 1 ? SH::FCB_E : SH::FCB_L0;
         if constexpr (AS) {
-            // (the lo operand's AUX1 blocks are zero: its pass stops after the f columns -- same first chunk, fewer units)
-            static_assert(ncw_first_chunk_bytes<P, RBF + 3, 32 * RBF, RBH, SH::SLOT>() == SH::FCB_E0, "lo pass: same first chunk");
-            mma_stream<RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e[0], net.w_e_lo[0], SH::FCB_E0, lane);
-            mma_stream<RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e_lo[0], net.w_e[0], SH::FCB_E0, lane);
-            mma_stream<RBF + 3, RBH, 32 * RBF, SH::SLOT>(e, cat1_lo, ring, (const WE*)net.w_e[0], wn, nb, lane);
+            mma_stream_split3<RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, cat1_lo, ring, (const WE*)net.w_e[0], net.w_e_lo[0],
+                                                                     SH::FCB_E0, wn, nb, lane);
             relu_epilogue_hl<P, RBH>(ea, ea_lo, e, stp(st.e[0]), tile, lane);
         } else {
             mma_stream_split<(SPLIT != 0), RBF + 3, RBH, 32 * RBF + 96, SH::SLOT>(e, cat1, ring, (const WE*)net.w_e[0], net.w_e_lo[0],
@@ -217,18 +214,25 @@ NCW_DEV void color_fwd_body(const NcwColorNet& net, const NcwPoints& src, int64_
             // --candidates: a surface ray at 8.8e-5 -> 1.3e-5).  Third pass of the ring: W_hi . lo([p | n]) -- the e blocks of the
             // operand are zero, the AUX2 block holds h16(v - h16(v)).  Forward only (the stash keeps the single-rounded AUX2).
             const int nxt = 1 == last ? SH::FCB_LAST : SH::FCB_L;
-            mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l_lo[0], SH::FCB_L0, lane);
-            mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l_lo[0], net.w_l[0], SH::FCB_L0, lane);
+            if constexpr (AS) {  // W_hi against both halves in one pass of the ring, then W_lo
+                Act<P, RBH + 1> cat2lo;  // [lo(e) | lo([p | n])]
 #pragma unroll
-            for (int i = 0; i < 2 * RBH; ++i)
+                for (int i = 0; i < 2 * RBH; ++i) cat2lo.f[i] = ea_lo.f[i];
+                cat2lo.f[2 * RBH] = aux2lo.f[0];
+                cat2lo.f[2 * RBH + 1] = aux2lo.f[1];
+                mma_stream_split3<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, cat2lo, ring, (const WE*)net.w_l[0], net.w_l_lo[0], SH::FCB_L0,
+                                                                        net.w_l[1], nxt, lane);
+            } else {  // round 5's three passes (two workgroups per CU: a merged pass's second operand does not fit 256 registers)
+                mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l_lo[0], SH::FCB_L0, lane);
+                mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l_lo[0], net.w_l[0], SH::FCB_L0, lane);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if constexpr (AS) cat2.f[i][e] = ea_lo.f[i][e];  // (AS: the head's output as a pair too)
-                    else cat2.f[i][e] = (ncw_h16)0.f;
-                }
-            cat2.f[2 * RBH] = aux2lo.f[0];
-            cat2.f[2 * RBH + 1] = aux2lo.f[1];
-            mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l[1], nxt, lane);
+                for (int i = 0; i < 2 * RBH; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cat2.f[i][e] = (ncw_h16)0.f;  // in place: the e blocks of the lo operand are zero
+                cat2.f[2 * RBH] = aux2lo.f[0];
+                cat2.f[2 * RBH + 1] = aux2lo.f[1];
+                mma_stream<RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l[1], nxt, lane);
+            }
         } else {
             mma_stream_split<false, RBH + 1, RBC, 32 * RBH + 6, SH::SLOT>(x, cat2, ring, (const WE*)net.w_l[0], net.w_l_lo[0], SH::FCB_L0,
                                                                           net.w_l[1], 1 == last ? SH::FCB_LAST : SH::FCB_L, lane);

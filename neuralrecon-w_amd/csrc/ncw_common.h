@@ -281,9 +281,12 @@ struct CatB {
 // own a whole SIMD (one workgroup per CU, 64 KiB slots); the two-workgroups-per-CU kernels (32 KiB slots) are
 // capped at 256 registers -- there the other workgroup's waves hide the LDS latency and PIPE only spills.
 // 16 out-blocks (W = 512): the second fragment set alone is 64 registers on top of 256 accumulators: off.
-template <int RB_OUT, int K_REAL, int SLOT, int RB_STRIDE, class P, class BP, bool PIPE = (SLOT != 32768) && (RB_OUT <= 8)>
+// BP2 (optional second B provider, same shape): acc += W . B + W . B2 in ONE pass of the ring -- every weight fragment read from LDS
+// feeds two MFMAs (round 6: the hi and the lo half of an activation pair against W_hi; csrc/ncw_color.hip).
+struct NoB2 {};
+template <int RB_OUT, int K_REAL, int SLOT, int RB_STRIDE, class P, class BP, bool PIPE = (SLOT != 32768) && (RB_OUT <= 8), class BP2 = NoB2>
 NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename P::welem* __restrict__ wp,
-                          const void* w_next, int next_bytes, int lane) {
+                          const void* w_next, int next_bytes, int lane, BP2* bp2 = nullptr) {
     constexpr int RB_IN = BP::RB_IN;
     constexpr int UPB = UnitsPerBlock<P>::v;
     constexpr int NU = ncw_nb_used(RB_IN, K_REAL) * UPB;
@@ -333,6 +336,11 @@ NCW_DEV void mma_stream_b(CVec<RB_OUT>& acc, BP& bp, WRing& ring, const typename
             const auto b = bp.b(rb, sub);
 #pragma unroll
             for (int ro = 0; ro < RB_OUT; ++ro) acc.v[ro] = unit_mfma(cur[ro], b, acc.v[ro]);
+            if constexpr (!std::is_same<BP2, NoB2>::value) {
+                const auto b2 = bp2->b(rb, sub);
+#pragma unroll
+                for (int ro = 0; ro < RB_OUT; ++ro) acc.v[ro] = unit_mfma(cur[ro], b2, acc.v[ro]);
+            }
             if (PIPE && un >= 0) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -353,6 +361,14 @@ NCW_DEV void mma_stream(CVec<RB_OUT>& acc, const Act<P, RB_IN>& in, WRing& ring,
                         const void* w_next, int next_bytes, int lane) {
     ActB<P, RB_IN> bp(in);
     mma_stream_b<RB_OUT, K_REAL, SLOT, RB_STRIDE, P>(acc, bp, ring, wp, w_next, next_bytes, lane);
+}
+// acc += W . in + W . in2, one pass of the ring (two MFMAs per weight fragment)
+template <int RB_IN, int RB_OUT, int K_REAL, int SLOT, int RB_STRIDE = RB_OUT, class P>
+NCW_DEV void mma_stream2(CVec<RB_OUT>& acc, const Act<P, RB_IN>& in, const Act<P, RB_IN>& in2, WRing& ring,
+                         const typename P::welem* __restrict__ wp, const void* w_next, int next_bytes, int lane) {
+    ActB<P, RB_IN> bp(in), bp2(in2);
+    mma_stream_b<RB_OUT, K_REAL, SLOT, RB_STRIDE, P, ActB<P, RB_IN>, (SLOT != 32768) && (RB_OUT <= 8), ActB<P, RB_IN>>(
+        acc, bp, ring, wp, w_next, next_bytes, lane, &bp2);
 }
 
 // concatenation of two activation vectors along the feature axis (skip connections: zero cost)

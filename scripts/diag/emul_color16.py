@@ -42,7 +42,7 @@ def split(x, dt=H):
     return hi + rnd(x - hi, dt)
 
 
-MODE = {"samp_w": None, "samp_h": None, "tail_feat": None, "tail_adj": None, "adj_t": None, "adj_w": None, "adj_s": None, "nin": None, "nda": None, "nw": None, "nact": None, "tail": None, "cin": None, "clay": None, "cw": None, "cin_f": None, "cin_da": None, "cin_p": None}   # None = exact; rnd / split
+MODE = {"adj_layers": None, "samp_w": None, "samp_h": None, "tail_feat": None, "tail_adj": None, "adj_t": None, "adj_w": None, "adj_s": None, "nin": None, "nda": None, "nw": None, "nact": None, "tail": None, "cin": None, "clay": None, "cw": None, "cin_f": None, "cin_da": None, "cin_p": None}   # None = exact; rnd / split
 
 
 def q(x, key):
@@ -90,7 +90,10 @@ def sdf_net_e(sd, x, prefix="sdf_net.", skip_in=(4,), multires=6, scale=1.0, wit
                 t = t * (1.0 - torch.exp(-100.0 * MODE["adj_s"](O.softplus100(zs[l]))))
             else:
                 t = t * O.softplus100_d1(zs[l])
-        qq = q(t, "adj_t") @ q(Ws[l], "adj_w")
+        if MODE.get("adj_layers") is not None and l not in MODE["adj_layers"]:  # round 6: the pairs only in some layers, single fp16 in the others
+            qq = rnd(t) @ rnd(Ws[l])
+        else:
+            qq = q(t, "adj_t") @ q(Ws[l], "adj_w")
         if l in skip_in:
             qq = qq / math.sqrt(2.0)
             g_gamma = g_gamma + qq[:, -n_gamma:]

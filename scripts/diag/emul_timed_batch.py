@@ -148,6 +148,11 @@ if "--tangent" in argv_keep:  # round 6: true_cos from a for
                  ("adjoint W^T and t hi+lo + colour activations + colour feat input hi+lo", dict(now, adj_t=None, clay=split, cin_f=split)),
                  ("adjoint W^T and t hi+lo + colour activations + feature rows hi+lo", dict(now, adj_t=None, clay=split, tail_feat=split)),
                  ("+ tangent + colour activations hi+lo + adjoint W^T hi+lo", dict(now, clay=split, tc=ident))]
+if "--adj-layers" in argv_keep:  # round 6: does the adjoint sweep need its operands as pairs in EVERY layer?
+    full = dict(now, adj_t=None, clay=split)
+    cases_all = [("adjoint W^T and t hi+lo in all layers + colour activations hi+lo (shipped, round 6)", full)] + [
+        ("... pairs only in layers %s" % (sorted(ls),), dict(full, adj_layers=set(ls)))
+        for ls in ([4, 5, 6, 7, 8], [5, 6, 7, 8], [3, 4, 5, 6, 7, 8], [4, 5, 6, 7], [0, 1, 2, 3, 4], [6, 7, 8], [0, 1, 2], [2, 3, 4, 5, 6], [1, 3, 5, 7], [0, 2, 4, 6, 8])]
 if "--next" in argv_keep:  # what is left after R5.8, one candidate at a time
     cases_all = [("final round-5 kernels", now),
                  ("+ colour feat input hi+lo", dict(now, cin_f=split)),
@@ -162,7 +167,7 @@ if "--next" in argv_keep:  # what is left after R5.8, one candidate at a time
                  ("+ everything hi+lo", dict(now, tail_feat=split, cin_f=split, clay=split, adj_t=None, adj_s=None))]
 if "--only" in argv_keep:
     cases_all = [c for c in cases_all if argv_keep[argv_keep.index("--only") + 1] in c[0] or c is cases_all[0]]
-cases = [c for c in cases_all if "--sampler" in argv_keep or "--next" in argv_keep or "--tangent" in argv_keep or ("--only-new" not in argv_keep) or "--candidates" in argv_keep or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
+cases = [c for c in cases_all if "--sampler" in argv_keep or "--next" in argv_keep or "--tangent" in argv_keep or "--adj-layers" in argv_keep or ("--only-new" not in argv_keep) or "--candidates" in argv_keep or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
 res = {}
 worst_rays = None
 for name, m in cases:
@@ -202,7 +207,7 @@ if with_ref and os.path.isdir("/root/reference"):
              "weights_sum": rel(o32["weights_sum"], ref["weights_sum"]), "weights": rel(o32["weights"], ref["weights"]),
              "colour_p99": float(torch.quantile(pr, 0.99)), "rays_above_1e-4": int((pr > 1e-4).sum())}
     print("the UNMODIFIED reference in fp32 vs the fp64 oracle on these weights / rays:", {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in ref32.items()})
-out_path = os.path.join(ROOT, "profiles", "r06" if "--tangent" in argv_keep else "r05", "emul_timed_batch%s%s%s.json" % (("_shipped" if "--shipped" in argv_keep else "") + ("_tangent" if "--tangent" in argv_keep else ""),
+out_path = os.path.join(ROOT, "profiles", "r06" if ("--tangent" in argv_keep or "--adj-layers" in argv_keep) else "r05", "emul_timed_batch%s%s%s.json" % (("_shipped" if "--shipped" in argv_keep else "") + ("_tangent" if "--tangent" in argv_keep else "") + ("_adj_layers" if "--adj-layers" in argv_keep else ""),
                                                                                 "_kernel_form" if "--only-new" in argv_keep else "",
                                                                                 "" if batch_seed == 1000 else "_seed%d" % batch_seed))
 os.makedirs(os.path.dirname(out_path), exist_ok=True)

@@ -92,5 +92,14 @@ s11() {  # one code path for the prefetch segment (no hoisted v_exp burst): prod
   timeout -k 10 400 $B --config grid512 --grid-width 256 > $OUT/bench_grid512_w256.json 2>/dev/null; echo "grid512 w256 rc $?"
 }
 
+s12() {  # colour activations as pairs in two ring passes instead of three: tests, cost at the shipped shape and at the headline's
+  timeout -k 10 900 python -m pytest tests/test_gpu_color_nerf.py tests/test_gpu_fullsize.py tests/test_gpu_render_only.py tests/test_gpu_timed_program_parity.py -q -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests rc $?"; tail -3 $OUT/tests.log
+  for S in 1000 3000; do
+    timeout -k 10 400 python bench.py --no-pmc --no-parity-mode --config shipped --seed $S > $OUT/bench_shipped_seed$S.json 2>/dev/null; echo "shipped seed $S rc $?"
+  done
+  NEUCONW_COLOR_ASPLIT=1 timeout -k 10 400 $B > $OUT/bench_headline_asplit.json 2>/dev/null; echo "headline + act_split rc $?"
+  timeout -k 10 400 $B > $OUT/bench_headline.json 2>/dev/null; echo "headline rc $?"
+}
+
 "$NAME"
 ls -la $OUT
