@@ -699,6 +699,10 @@ NCW_DEV void s16s_mma(f32x16 (&acc)[2][S16S_T], S16WS& r, const void* w, const v
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = r.f[q % S16_D][k];
         if (q + S16_D < S16_KU) s16s_ld_unit(r.f[q % S16_D], w, wlo, 16, wave, q + S16_D, lane);
+        // keep the ring's loads where they are issued: hipcc otherwise sinks them next to their use (s_waitcnt vmcnt(0 / 1) in front of every
+        // k-unit instead of 12-15 loads in flight).  Measured, round 6: value chain 0.607 -> 0.569 ms per 49,152 points, 10.9 -> 10.45 ms per
+        // 1,048,576 (profiles/r06/w512_probe.log); a ring of 8 units instead of 4 is slower (registers).
+        __builtin_amdgcn_sched_barrier(0);
         s16s_unit(acc, a, in, S16_KU, q, lane);
     }
 }

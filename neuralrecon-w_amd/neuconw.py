@@ -451,10 +451,12 @@ class RenderingNetwork(_PackedNet):
         # product: W_hi x + W_lo x); NEUCONW_COLOR_WSPLIT=0 / .weight_split = False = one rounding per weight (set before the
         # first forward: the packed-weight plan is built once per precision)
         self.weight_split = os.environ.get("NEUCONW_COLOR_WSPLIT", "1") != "0"
-        # fp16 mode, with weight_split: the ACTIVATIONS of every layer as hi + lo pairs too (NcwColorNet.act_split: a third pass of the
-        # weight ring per layer, forward only).  None = the default: on at d_feature = 512 (the shipped width: 8 + 16 samples per ray,
-        # one sample carries a ray), off at 256 (the headline's ten ray batches are under 1e-4 without it; emulated gain there 8.4e-5
-        # -> 3.8e-5).  NEUCONW_COLOR_ASPLIT=0 / 1 or `.act_split = False / True` override.
+        # fp16 mode, with weight_split: the ACTIVATIONS of every layer as hi + lo pairs too (NcwColorNet.act_split: the W_hi pass of the
+        # weight ring feeds every fragment to two MFMAs; forward only).  None = the default: ON at d_feature = 256 and 512.  At 512 (the
+        # shipped width: 8 + 16 samples per ray, one sample carries a ray) it is half of what brings the trained-weights colour from
+        # 3.1e-4 to 2e-5; at 256 (headline) ten ray batches measured, same box, alternating: worst trained-weights colour 8.4e-5 -> 5.2e-5,
+        # mean 5.2e-5 -> 3.4e-5, for +0.03 ms per step (4.136 -> 4.167 ms; profiles/r06/bench_seed*_asplit{0,1}.json).
+        # NEUCONW_COLOR_ASPLIT=0 / 1 or `.act_split = False / True` override.
         env = os.environ.get("NEUCONW_COLOR_ASPLIT")
         self.act_split = None if env is None else (env not in ("0", ""))
         self._init_plans()
@@ -508,7 +510,7 @@ class RenderingNetwork(_PackedNet):
             net.w_l[l], net.b_l[l], net.wt_l[l] = plan.mat_ptr(s[0]), plan.bias_ptr(s[1]), plan.mat_ptr(s[2])
             net.w_l_lo[l] = plan.mat_ptr(s[4]) if split else None
         net.n_head, net.n_lin, net.rbf, net.rbh, net.rbc, net.n_a = self.n_head, self.n_lin, RBF, RBH, RBC, A
-        asplit = (RBF == 16) if self.act_split is None else bool(self.act_split)
+        asplit = True if self.act_split is None else bool(self.act_split)
         net.act_split = 1 if (split and asplit and (RBF, RBH, RBC) in ((8, 4, 8), (16, 4, 8))) else 0
         plan.net, plan.slots = net, sl
         return plan

@@ -7,7 +7,7 @@ res = collections.defaultdict(dict)
 for gi, grp in enumerate(groups):
     d = "/tmp/pmc_pass_%d" % gi
     cmd = ["rocprofv3", "--pmc"] + grp.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--",
-           sys.executable, os.path.join(repo, "bench.py"), "--inner", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-pmc", "--no-parity-mode"]
+           sys.executable, os.path.join(repo, "bench.py"), "--inner", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-pmc", "--no-parity-mode"] + os.environ.get("NCW_PMC_BENCH_ARGS", "").split()  # e.g. "--config shipped"
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)

@@ -101,5 +101,27 @@ s12() {  # colour activations as pairs in two ring passes instead of three: test
   timeout -k 10 400 $B > $OUT/bench_headline.json 2>/dev/null; echo "headline rc $?"
 }
 
+s13() {  # where do the W = 512 kernels' weights come from?  L2 hit / miss and memory-side requests of the shipped shape's kernels
+  (cd /tmp && rocprofv3 --list-avail 2>/dev/null | grep -i -E "TCC_|TCP_" | cut -c1-160 | sort -u | head -150) > $OUT/counters_avail.log 2>&1
+  NCW_PMC_BENCH_ARGS="--config shipped" timeout -k 10 900 python scripts/pmc_pass.py $OUT/pmc_shipped_l2.json "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE" "TCC_TAG_STALL_sum TCC_BUBBLE_sum" > $OUT/pmc_shipped_l2.log 2>&1; echo "pmc shipped rc $?"
+  grep -E "sdf_fwdS16|sdf_inferS16|sdf_bwd16|group failed" $OUT/pmc_shipped_l2.log | cut -c1-400
+}
+
+s14() {  # W = 512 split kernels: does pinning the weight ring's loads / a deeper ring help?  (probe libraries pin, d8, pind8)
+  for rep in 1 2; do
+    for L in "" pin d8 pind8; do
+      if [ -z "$L" ]; then timeout -k 10 200 python scripts/diag/w512_probe.py; else NEUCONW_HIP_LIB=$PWD/neuralrecon-w_amd/libneuconw_hip_$L.so timeout -k 10 200 python scripts/diag/w512_probe.py; fi
+    done
+  done 2>&1 | grep -v amdgpu.ids | tee $OUT/w512_probe.log
+}
+
+s15() {  # headline shape, ten ray batches: trained-weights colour and step time with the colour activations as pairs (act_split) and without
+  for S in 1000 2000 3000 4000 5000 6000 7000 8000 9000 10000; do
+    for A in 0 1; do
+      NEUCONW_COLOR_ASPLIT=$A timeout -k 10 300 python bench.py --no-pmc --no-parity-mode --seed $S > $OUT/bench_seed${S}_asplit$A.json 2>/dev/null; echo "seed $S asplit $A rc $?"
+    done
+  done
+}
+
 "$NAME"
 ls -la $OUT

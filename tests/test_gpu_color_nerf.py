@@ -257,7 +257,7 @@ def test_color_head_per_ray_bias(prec_name):
 
 @pytest.mark.parametrize("W", [256, 512])
 def test_color_forward_with_split_activations(W):
-    """Round 6, fp16 mode: `RenderingNetwork.act_split` (NcwColorNet.act_split; the default at d_feature = 512, the shipped width) --
+    """Round 6, fp16 mode: `RenderingNetwork.act_split` (NcwColorNet.act_split; the default at d_feature = 256 / 512) --
     the activations of every layer as fp16 hi + lo pairs on top of the hi + lo weights: a third pass W_hi x_lo of the weight ring per
     layer (csrc/ncw_color.hip SPLIT = 2).  What is left single-rounded is the feature vector it reads from the stash and the per-ray
     view / appearance columns (fp32).  rgb against the fp64 oracle must drop well below the weights-only form's, the stash (the
@@ -273,7 +273,7 @@ def test_color_forward_with_split_activations(W):
     _, neuconw, _, _ = build_system(W=W, n_a=n_a, color_hidden=256, head=head, nerf_w=64, seed=11, prec=prec)
     cn = neuconw.color_net
     _jitter(cn, 1)
-    assert cn.plan(prec).net.act_split == (1 if W == 512 else 0)  # the defaults
+    assert cn.plan(prec).net.act_split == 1  # the default at both shipped widths
     R, S = 125, 32  # ragged
     n = R * S
     g = torch.Generator().manual_seed(2)
