@@ -164,16 +164,25 @@ _OCC_CACHE = {}
 
 
 def _occupancy_of(point_hierarchy, pyramid, level):
-    key = (point_hierarchy.data_ptr(), point_hierarchy._version, int(point_hierarchy.shape[0]), int(level))
+    """(occ, brick, Morton codes of the level's points, their offset in the hierarchy, level) of an SPC, cached per point-hierarchy
+    TENSOR: the entry holds a weak reference to it and is only used while that very object is alive and unmodified (an address can be
+    reused by another tensor of the same shape)."""
+    import weakref
+
+    key = (id(point_hierarchy), int(level))
     hit = _OCC_CACHE.get(key)
+    if hit is not None and (hit[0]() is not point_hierarchy or hit[1] != point_hierarchy._version):
+        hit = None
     if hit is None:
         pts, start, lvl = level_points(point_hierarchy, pyramid, level)
         occ, brick = occupancy_bits(pts, lvl)
         mort = points_to_morton(pts)  # ascending by construction
+        for k in [k for k, v in _OCC_CACHE.items() if v[0]() is None]:
+            del _OCC_CACHE[k]
         if len(_OCC_CACHE) > 8:
             _OCC_CACHE.clear()
-        hit = _OCC_CACHE[key] = (occ, brick, mort, start, lvl)
-    return hit
+        hit = _OCC_CACHE[key] = (weakref.ref(point_hierarchy), point_hierarchy._version, occ, brick, mort, start, lvl)
+    return hit[2:]
 
 
 def unbatched_raytrace(octree, point_hierarchy, pyramid, exsum, origin, direction, level, return_depth=True, with_exit=False):
