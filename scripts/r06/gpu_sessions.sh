@@ -123,5 +123,12 @@ s15() {  # headline shape, ten ray batches: trained-weights colour and step time
   done
 }
 
+s16() {  # W = 512 split value chain: k-units walked in an order rotated per workgroup (probe `rot`): is the L2 limited by every CU asking for the same lines at once?
+  for rep in 1 2; do
+    timeout -k 10 200 python scripts/diag/w512_probe.py
+    NEUCONW_HIP_LIB=$PWD/neuralrecon-w_amd/libneuconw_hip_rot.so timeout -k 10 200 python scripts/diag/w512_probe.py
+  done 2>&1 | grep -v amdgpu.ids | tee $OUT/w512_rot.log
+}
+
 "$NAME"
 ls -la $OUT
