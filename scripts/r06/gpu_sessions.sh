@@ -130,5 +130,11 @@ s16() {  # W = 512 split value chain: k-units walked in an order rotated per wor
   done 2>&1 | grep -v amdgpu.ids | tee $OUT/w512_rot.log
 }
 
+s17() {  # nerf_bwdB with its ReLU masks prefetched a layer ahead: tests, bench (per-kernel times)
+  timeout -k 10 900 python -m pytest tests/test_gpu_color_nerf.py tests/test_gpu_bg_select.py tests/test_gpu_render.py -q -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests rc $?"; tail -2 $OUT/tests.log
+  for i in 1 2; do timeout -k 10 400 $B > $OUT/bench_headline_$i.json 2>/dev/null; echo "headline rc $?"; done
+  timeout -k 10 400 $B --bg-eliminate > $OUT/bench_elim.json 2>/dev/null; echo "elim rc $?"
+}
+
 "$NAME"
 ls -la $OUT
