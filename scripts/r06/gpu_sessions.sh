@@ -136,5 +136,24 @@ s17() {  # nerf_bwdB with its ReLU masks prefetched a layer ahead: tests, bench 
   timeout -k 10 400 $B --bg-eliminate > $OUT/bench_elim.json 2>/dev/null; echo "elim rc $?"
 }
 
+s18() {  # kernel time (rocprofv3) of the value-only kernels, to set beside round 5's 0.157 ms / 131,072 points
+  cd /tmp && rm -rf /tmp/units_stats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/units_stats -o p -- python $GRAFT_REPO_ROOT/scripts/diag/sdf_infer_units.py > $GRAFT_REPO_ROOT/$OUT/units_under_rocprof.log 2>&1; head -1 $(find /tmp/units_stats -name '*kernel_trace.csv' | head -1) > $GRAFT_REPO_ROOT/$OUT/trace_header.txt
+  cd $GRAFT_REPO_ROOT; f=$(find /tmp/units_stats -name '*kernel_trace.csv' | head -1); python - "$f" > $OUT/sdf_infer_kernel_times.log <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"]
+    if "sdf_infer" in k:
+        g = r.get("Grid_Size") or r.get("Grid_Size_X") or r.get("Grid_Size_x") or "0"
+        import re
+        m = re.search(r"(sdf_infer\w*?_kernel(?:<[^>]*>)?)", k)
+        acc[(m.group(1) if m else k[:40], int(g))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+for (k, g), v in sorted(acc.items()):
+    v.sort()
+    print("%-42s grid %9d  launches %3d  median %.4f ms  min %.4f ms" % (k, g, len(v), v[len(v) // 2], v[0]))
+PY
+  cat $OUT/sdf_infer_kernel_times.log
+}
+
 "$NAME"
 ls -la $OUT
