@@ -190,7 +190,10 @@ int ncw_sdf_infer_points(const NcwSdfNet* net, int prec, const NcwPoints* pts, i
 typedef struct NcwSdfStash {
     void* gamma;                 /* encoding, 2 blocks                                        */
     void* h[NCW_MAX_LAYERS];     /* h[l], l>=1: input of layer l = Softplus(z_{l-1}), rb blocks */
-    void* s[NCW_MAX_LAYERS];     /* unused (Softplus'(z_l) is recomputed as 1 - exp(-100 h[l+1])); kept for ABI */
+    void* s[NCW_MAX_LAYERS];     /* Softplus'(z_l) is recomputed as 1 - exp(-100 h[l+1]): no stash of its own.  fp16 mode with
+                                  * NcwSdfNet.adj_mode 2 (rb = 16): s[l], l >= 1 = the fp16 RESIDUALS of h[l] (h_lo = h16(h - h16(h))),
+                                  * written by the split value chain and read back by the adjoint sweep of the SAME launch, whose
+                                  * phi' = 1 - exp(-100 (h + h_lo)) then carries no fp16 rounding of h; NULL = phi' from h[l] alone */
     void* t[NCW_MAX_LAYERS];     /* t[l] = a_l * s[l] (adjoint pass), l <= L-2                 */
     void* feat;                  /* feature vector z_{L-1}[1:], rb blocks                      */
     void* dfeat;                 /* upstream d(feat), rb blocks                                */

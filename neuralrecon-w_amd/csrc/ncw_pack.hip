@@ -214,7 +214,7 @@ extern "C" int ncw_stash_to_rows(int prec, const void* stash, int64_t n, int F, 
     return 0;
 }
 
-extern "C" int ncw_abi_version(void) { return 17; }
+extern "C" int ncw_abi_version(void) { return 18; }
 
 extern "C" int ncw_device_info(char* buf, int buflen) {
     int cnt = 0;

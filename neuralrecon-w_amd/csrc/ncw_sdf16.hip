@@ -204,6 +204,16 @@ NCW_DEV f32x16 s16_sprime(const ncw_h16* __restrict__ st_h, size_t tile, int ob,
     return sv;
 }
 
+// ... from h as an fp16 hi + lo pair (st_lo = NcwSdfStash.s: the residual stash of the split value chain; adj_mode 2)
+NCW_DEV f32x16 s16_sprime_hl(const ncw_h16* __restrict__ st_h, const ncw_h16* __restrict__ st_lo, size_t tile, int ob, int lane) {
+    f32x16 sv, lv;
+    stash_load_block(sv, st_h, tile, 16, ob, lane);
+    stash_load_block(lv, st_lo, tile, 16, ob, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = 1.f - __builtin_amdgcn_exp2f((sv[r] + lv[r]) * -144.26950408889634f);
+    return sv;
+}
+
 // abuf: the activations, rewritten in place by every layer; gbuf: per tile 4 units (gamma / qbar_0: 3, the d_sdf unit: 1)
 #define S16_LDS_DECL()                                                                \
     __shared__ __attribute__((aligned(16))) char lds[T * S16_KU * 1024 + T * 4096];   \
@@ -337,7 +347,9 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                f32x16 sv = s16_sprime((const SE*)st.h[L - 1], (size_t)(tile0 + t), wave + 8 * j, lane);
+                f32x16 sv = (ADJ == 2 && st.s[L - 1] != nullptr)
+                                ? s16_sprime_hl((const SE*)st.h[L - 1], (const SE*)st.s[L - 1], (size_t)(tile0 + t), wave + 8 * j, lane)
+                                : s16_sprime((const SE*)st.h[L - 1], (size_t)(tile0 + t), wave + 8 * j, lane);
                 const f32x16& aa = j ? a1 : a0;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) sv[q] *= aa[q];
@@ -367,7 +379,9 @@ NCW_DEV void s16_fwd_tail(const NcwSdfNet& net, const NcwPoints& src, int64_t n,
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                f32x16 sv = s16_sprime((const SE*)st.h[l], (size_t)(tile0 + t), wave + 8 * j, lane);
+                f32x16 sv = (ADJ == 2 && st.s[l] != nullptr)
+                                ? s16_sprime_hl((const SE*)st.h[l], (const SE*)st.s[l], (size_t)(tile0 + t), wave + 8 * j, lane)
+                                : s16_sprime((const SE*)st.h[l], (size_t)(tile0 + t), wave + 8 * j, lane);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) sv[q] *= acc[j][t][q];
                 if (TRAIN) stash_store_block((SE*)st.t[l - 1], (size_t)(tile0 + t), 16, wave + 8 * j, sv, lane);
@@ -745,13 +759,29 @@ NCW_DEV void s16s_value_chain(const NcwSdfNet& net, const NcwPoints& src, int64_
             for (int j = 0; j < 2; ++j) {
                 const f32x16 y = s16_softplus<TU>(acc[j][t]);
                 const int ob = wave + 8 * j;
-                if (STASH >= 1) stash_store_block_keep((SE*)st.h[l_out], (size_t)(tile0 + t), 16, ob, y, lane);
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     bf16x8 hi, lo;
                     s16s_split8(y, tt, hi, lo);
                     sbuf[((t * S16_KU + 2 * ob + tt) * 2 + 0) * 64 + lane] = hi;
                     sbuf[((t * S16_KU + 2 * ob + tt) * 2 + 1) * 64 + lane] = lo;
+                    // the stash h (the backward's operand, the adjoint sweep's phi') takes the SAME hi bits the LDS holds -- registers 8 tt .. 8 tt + 7
+                    // are groups 2 tt, 2 tt + 1 of the stash block: no second conversion -- and, adj_mode 2, NcwSdfStash.s their residuals
+                    // (phi' = 1 - exp(-100 (h + h_lo)) then carries no fp16 rounding of h)
+                    if (STASH >= 1) {
+                        typedef ncw_h16 h4 __attribute__((ext_vector_type(4)));
+                        const size_t at = (((size_t)(tile0 + t) * 16 + ob) * 4 + 2 * tt) * 64 + lane;
+                        h4* qh = reinterpret_cast<h4*>(st.h[l_out]) + at;
+                        const h4 a = {hi[0], hi[1], hi[2], hi[3]}, b = {hi[4], hi[5], hi[6], hi[7]};
+                        qh[0] = a;
+                        qh[64] = b;
+                        if (st.s[l_out] != nullptr) {
+                            h4* ql = reinterpret_cast<h4*>(st.s[l_out]) + at;
+                            const h4 c = {lo[0], lo[1], lo[2], lo[3]}, d = {lo[4], lo[5], lo[6], lo[7]};
+                            ql[0] = c;
+                            ql[64] = d;
+                        }
+                    }
                 }
             }
     };

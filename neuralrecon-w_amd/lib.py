@@ -15,7 +15,7 @@ PREC_BF16 = 1
 PREC_F16 = 2  # fp16 operands, f32 accumulate; backward needs the loss scale (renderer.grad_scale)
 MAX_LAYERS = 12
 MAX_SEGS = 4
-ABI_VERSION = 17  # 17: ncw_ray_voxel_trace (all ray / voxel intersections: kaolin's unbatched_raytrace contract);  16: NcwSdfNet.wt_lo (adjoint sweep with hi + lo weights), NcwNerfNet.w_*_lo;  15: forward-only render form of ncw_sdf_fwd / ncw_color_fwd / ncw_nerf_fwd (NULL stash members);  14: NcwColorNet.w_*_lo (split colour weights, forward);  13: NcwNerfStash.aux_bias;  12: ncw_aux_ray_bias, NcwColorStash.aux_bias, ncw_source_hash;  11: marching cubes (ncw_mc_count / ncw_mc_emit replace the marching-tetrahedra entry points);  10: split-precision SDF value path (NcwSdfNet.w_lo, NcwPackDesc.residual);  9: device-resident optimiser state (ncw_adam_step_dev, NcwAdamState), dynamic loss scale (grad_scale_dev / grad_mul_dev);  8: NcwPoints mode 4 (idx / count), NcwWgradDesc.n_points_dev, ncw_bg_select;  7: fp16 (prec 2), grad_scale / grad_mul;  6: ray prologue / inv_s / loss launches, NcwCompositeOut.weights_max;  5: ncw_scatter_add_rows;  4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
+ABI_VERSION = 18  # 18: NcwSdfStash.s = residuals of h (adj_mode 2), NcwSdfNet.adj_mode, NcwColorNet.act_split;  17: ncw_ray_voxel_trace (all ray / voxel intersections: kaolin's unbatched_raytrace contract);  16: NcwSdfNet.wt_lo (adjoint sweep with hi + lo weights), NcwNerfNet.w_*_lo;  15: forward-only render form of ncw_sdf_fwd / ncw_color_fwd / ncw_nerf_fwd (NULL stash members);  14: NcwColorNet.w_*_lo (split colour weights, forward);  13: NcwNerfStash.aux_bias;  12: ncw_aux_ray_bias, NcwColorStash.aux_bias, ncw_source_hash;  11: marching cubes (ncw_mc_count / ncw_mc_emit replace the marching-tetrahedra entry points);  10: split-precision SDF value path (NcwSdfNet.w_lo, NcwPackDesc.residual);  9: device-resident optimiser state (ncw_adam_step_dev, NcwAdamState), dynamic loss scale (grad_scale_dev / grad_mul_dev);  8: NcwPoints mode 4 (idx / count), NcwWgradDesc.n_points_dev, ncw_bg_select;  7: fp16 (prec 2), grad_scale / grad_mul;  6: ray prologue / inv_s / loss launches, NcwCompositeOut.weights_max;  5: ncw_scatter_add_rows;  4: ncw_batch_assemble;  3: ordered fp32 wgrad, d_a_rows / ncw_ray_sum_rows, per-ray d_inv_s;  2: 2: NcwWgradDesc.ksplit/n_points, NcwCompositeIn.cos_anneal_dev, ray tail / mesh / optimiser entry points
 
 
 class NcwSeg(C.Structure):

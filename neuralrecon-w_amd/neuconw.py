@@ -304,23 +304,29 @@ class SDFNetwork(nn.Module):
         dev = self.lin0.bias.device
         plan = self.packed(prec)
         RB, Lm = self.d_hidden // 32, self.n_lin
+        h_lo = int(plan.net.adj_mode) == 2  # the adjoint sweep takes phi' from h as an fp16 hi + lo pair (csrc/ncw_sdf16.hip)
 
         def build_render():
             ar = StashArena(dev, prec, n)
             ids = dict(feat=ar.new(RB))
             ids["h"] = {l: ar.new(RB) for l in range(1, Lm)}
+            ids["s"] = {l: ar.new(RB) for l in range(1, Lm)} if h_lo else {}
             ar.allocate()
             st = L.NcwSdfStash()
             st.feat = ar.ptr(ids["feat"])
             for l, i in ids["h"].items():
                 st.h[l] = ar.ptr(i)
+            for l, i in ids["s"].items():
+                st.s[l] = ar.ptr(i)
             return dict(arena=ar, ids=ids, stash=st)
 
         def build():
             ar = StashArena(dev, prec, n)
             ids = dict(gamma=ar.new(2), feat=ar.new(RB), dfeat=ar.new(RB), zsdf=ar.new(1), one=ar.new(1))
             ids["h"] = {l: ar.new(RB) for l in range(1, Lm)}
-            ids["s"] = {}  # Softplus' is recomputed from h (s = 1 - exp(-100 h)): no stash vector
+            # Softplus' is recomputed from h (s = 1 - exp(-100 h)): no stash vector of its own.  adj_mode 2 (W = 512): the slots hold the fp16
+            # RESIDUALS of h (NcwSdfStash.s = h_lo), written by the split value chain and read by the adjoint sweep of the same launch
+            ids["s"] = {l: ar.new(RB) for l in range(1, Lm)} if h_lo else {}
             ids["t"] = {l: ar.new(RB) for l in range(Lm - 1)}
             ids["qbar"] = {l: ar.new(2 if l == 0 else RB) for l in range(Lm)}
             ids["zbar"] = {l: ar.new(RB) for l in range(Lm - 1)}
@@ -333,7 +339,7 @@ class SDFNetwork(nn.Module):
                     getattr(st, k)[l] = ar.ptr(i)
             return dict(arena=ar, ids=ids, stash=st)
 
-        ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev), bool(train)),
+        ent = self.__dict__.setdefault("_stash_cache", StashCache()).acquire((prec, n, str(dev), h_lo, bool(train)),
                                                                              build if train else build_render)
         ar, ids, st = ent["arena"], ent["ids"], ent["stash"]
         sdf = torch.empty(n, device=dev, dtype=torch.float32)

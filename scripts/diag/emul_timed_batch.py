@@ -153,6 +153,16 @@ if "--adj-layers" in argv_keep:  # round 6: does the adjoint sweep need its oper
     cases_all = [("adjoint W^T and t hi+lo in all layers + colour activations hi+lo (shipped, round 6)", full)] + [
         ("... pairs only in layers %s" % (sorted(ls),), dict(full, adj_layers=set(ls)))
         for ls in ([4, 5, 6, 7, 8], [5, 6, 7, 8], [3, 4, 5, 6, 7, 8], [4, 5, 6, 7], [0, 1, 2, 3, 4], [6, 7, 8], [0, 1, 2], [2, 3, 4, 5, 6], [1, 3, 5, 7], [0, 2, 4, 6, 8])]
+if "--r6" in argv_keep:  # round 6: what is left at the shipped shape after the adjoint pairs + colour activation pairs
+    cur = dict(now, adj_t=None, clay=split)
+    cases_all = [("round-6 kernels (adjoint both operands as pairs, phi' from the fp16 stash of h; colour activations as pairs)", cur),
+                 ("+ phi' exact in the adjoint sweep", dict(cur, adj_s=None)),
+                 ("+ feature rows hi+lo", dict(cur, tail_feat=split)),
+                 ("+ colour feat input hi+lo", dict(cur, cin_f=split)),
+                 ("+ feature rows + colour feat input hi+lo", dict(cur, tail_feat=split, cin_f=split)),
+                 ("+ phi' exact + feature rows + colour feat input hi+lo", dict(cur, adj_s=None, tail_feat=split, cin_f=split)),
+                 ("+ final g_gamma exact (tail_adj None)", dict(cur, tail_adj=None)),
+                 ("+ everything exact but the NeRF", dict(cur, adj_s=None, tail_feat=None, tail_adj=None, adj_w=None, cin_f=None, cin_p=None, clay=None, cw=None, cin_da=None, tail=None))]
 if "--next" in argv_keep:  # what is left after R5.8, one candidate at a time
     cases_all = [("final round-5 kernels", now),
                  ("+ colour feat input hi+lo", dict(now, cin_f=split)),
@@ -167,7 +177,7 @@ if "--next" in argv_keep:  # what is left after R5.8, one candidate at a time
                  ("+ everything hi+lo", dict(now, tail_feat=split, cin_f=split, clay=split, adj_t=None, adj_s=None))]
 if "--only" in argv_keep:
     cases_all = [c for c in cases_all if argv_keep[argv_keep.index("--only") + 1] in c[0] or c is cases_all[0]]
-cases = [c for c in cases_all if "--sampler" in argv_keep or "--next" in argv_keep or "--tangent" in argv_keep or "--adj-layers" in argv_keep or ("--only-new" not in argv_keep) or "--candidates" in argv_keep or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
+cases = [c for c in cases_all if "--sampler" in argv_keep or "--next" in argv_keep or "--tangent" in argv_keep or "--adj-layers" in argv_keep or "--r6" in argv_keep or ("--only-new" not in argv_keep) or "--candidates" in argv_keep or ("kernel" in c[0] or "adjoint" in c[0] or "round-4" in c[0])]
 res = {}
 worst_rays = None
 for name, m in cases:
@@ -207,7 +217,7 @@ if with_ref and os.path.isdir("/root/reference"):
              "weights_sum": rel(o32["weights_sum"], ref["weights_sum"]), "weights": rel(o32["weights"], ref["weights"]),
              "colour_p99": float(torch.quantile(pr, 0.99)), "rays_above_1e-4": int((pr > 1e-4).sum())}
     print("the UNMODIFIED reference in fp32 vs the fp64 oracle on these weights / rays:", {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in ref32.items()})
-out_path = os.path.join(ROOT, "profiles", "r06" if ("--tangent" in argv_keep or "--adj-layers" in argv_keep) else "r05", "emul_timed_batch%s%s%s.json" % (("_shipped" if "--shipped" in argv_keep else "") + ("_tangent" if "--tangent" in argv_keep else "") + ("_adj_layers" if "--adj-layers" in argv_keep else ""),
+out_path = os.path.join(ROOT, "profiles", "r06" if ("--tangent" in argv_keep or "--adj-layers" in argv_keep or "--r6" in argv_keep) else "r05", "emul_timed_batch%s%s%s.json" % (("_shipped" if "--shipped" in argv_keep else "") + ("_tangent" if "--tangent" in argv_keep else "") + ("_adj_layers" if "--adj-layers" in argv_keep else "") + ("_r6" if "--r6" in argv_keep else ""),
                                                                                 "_kernel_form" if "--only-new" in argv_keep else "",
                                                                                 "" if batch_seed == 1000 else "_seed%d" % batch_seed))
 os.makedirs(os.path.dirname(out_path), exist_ok=True)

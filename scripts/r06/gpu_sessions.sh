@@ -155,5 +155,32 @@ PY
   cat $OUT/sdf_infer_kernel_times.log
 }
 
+s19() {  # the shipped shape's trained-weights parity point over ten ray batches (final kernels); the whole GPU suite once more
+  for S in 1000 2000 3000 4000 5000 6000 7000 8000 9000 10000; do
+    timeout -k 10 300 python bench.py --no-pmc --no-parity-mode --config shipped --seed $S > $OUT/bench_shipped_seed$S.json 2>/dev/null; echo "shipped seed $S rc $?"
+  done
+  timeout -k 10 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests rc $?"; tail -2 $OUT/tests.log
+}
+
+s20() {  # trained states of the shipped shape's outlier batches for the CPU emulation
+  for S in 7000 10000 6000; do
+    timeout -k 10 300 python bench.py --no-pmc --no-parity-mode --config shipped --seed $S --save-trained-state $OUT/trained_shipped_seed$S.pt > $OUT/bench_shipped_seed$S.json 2>/dev/null; echo "shipped seed $S rc $?"
+  done
+}
+
+s21() {  # phi' of the W = 512 adjoint sweep from h as a hi + lo pair (residual stash): tests, the outlier ray batches, cost
+  timeout -k 10 900 python -m pytest tests/test_gpu_sdf.py tests/test_gpu_sdf_train.py tests/test_gpu_fullsize.py tests/test_gpu_render_only.py tests/test_gpu_grid.py -q -s -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests rc $?"; tail -3 $OUT/tests.log; grep "W=512 normals" $OUT/tests.log
+  for S in 7000 1000 5000 10000; do
+    timeout -k 10 300 python bench.py --no-pmc --no-parity-mode --config shipped --seed $S > $OUT/bench_shipped_seed$S.json 2>/dev/null; echo "shipped seed $S rc $?"
+  done
+}
+
+s22() {  # whole GPU suite on the residual-stash build; shipped ten ray batches again
+  timeout -k 10 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests rc $?"; tail -3 $OUT/tests.log
+  for S in 2000 3000 4000 6000 8000 9000; do
+    timeout -k 10 300 python bench.py --no-pmc --no-parity-mode --config shipped --seed $S > $OUT/bench_shipped_seed$S.json 2>/dev/null; echo "shipped seed $S rc $?"
+  done
+}
+
 "$NAME"
 ls -la $OUT

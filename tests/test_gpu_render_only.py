@@ -49,8 +49,9 @@ def test_no_grad_render_is_bitwise_the_training_forward(W, prec_name, ns, ni, bg
     k_train = next(k for k in sizes if k[-1] is True)
     k_fwd = next(k for k in sizes if k[-1] is False)
     tiles = ((R * S + 31) // 32 + 23) // 24 * 24
-    assert sizes[k_fwd] == 9 * (W // 32) * tiles * 1024 * esz          # 8 hidden activations + feat
-    assert sizes[k_train] > 3.5 * sizes[k_fwd]                           # (34 W / 32 + 6 blocks per tile against 9 W / 32)
+    h_lo = 8 if (W == 512 and prec_name == "f16") else 0  # (adj_mode 2: + the residuals of h for the adjoint sweep's phi', NcwSdfStash.s)
+    assert sizes[k_fwd] == (9 + h_lo) * (W // 32) * tiles * 1024 * esz  # 8 hidden activations + feat
+    assert sizes[k_train] > (2.3 if h_lo else 3.5) * sizes[k_fwd]        # (34 W / 32 + 6 blocks per tile against 9 W / 32; + 8 W / 32 on both sides with h_lo)
     for mod in (neuconw.color_net, nerf):
         sz = _arena_bytes(mod)
         assert max(v for k, v in sz.items() if k[-1] is False) <= 256, sz

@@ -126,8 +126,8 @@ def test_adjoint_sweep_with_split_weights(W, n_layers, skip):
 def test_adjoint_sweep_with_both_operands_split_at_w512():
     """Round 6, W = 512 (the shipped width), fp16 mode: `adj_split = 2` (the default there) runs the adjoint sweep with W^T AND t_l as
     hi + lo pairs (csrc/ncw_sdf16.hip sdf_fwdS16<., 2>): the normals come out at the value chain's accuracy class instead of the plain
-    sweep's 6e-4 / the weights-only pairs' 3.6e-4 -- what remains is phi' recomputed from the fp16 stash of h (<= 1.8e-4 per element,
-    incoherent).  sdf / feat and the stash t_l (the backward's operand: the single-rounded hi part) must not move."""
+    sweep's 6e-4 / the weights-only pairs' 3.6e-4; phi' is taken from h as an fp16 hi + lo pair (the residual stash NcwSdfStash.s the value chain
+    writes for this sweep): recomputed from the single-rounded h it left 5.7e-5 on the normals and 1.6e-4 on one ray batch's colour.  sdf / feat and the stash t_l (the backward's operand: the single-rounded hi part) must not move."""
     import neuralrecon_w_amd as nw
     from neuralrecon_w_amd.neuconw import points_struct
     from neuralrecon_w_amd.stash import StashCache
@@ -151,7 +151,7 @@ def test_adjoint_sweep_with_both_operands_split_at_w512():
         out[adj] = (sdf.cpu(), grad.cpu(), feat, t0)
     e = {a: rel_err(out[a][1], ref_grad) for a in out}
     print("W=512 normals vs fp64 oracle: plain sweep %.2e, W^T as pairs %.2e, both operands as pairs %.2e" % (e[0], e[1], e[2]))
-    assert e[2] < 0.25 * e[0] and e[2] < 1e-4, e
+    assert e[2] < 0.02 * e[0] and e[2] < 5e-6, e  # (with phi' from h as an fp16 hi + lo pair, NcwSdfStash.s: before that 5.7e-5)
     for a in (1, 2):
         assert torch.equal(out[0][0], out[a][0]) and torch.equal(out[0][2], out[a][2])
         assert rel_err(out[a][3], out[0][3]) < 2e-3
