@@ -56,7 +56,10 @@ def main():
     ap.add_argument("--precs", default="f32,f16,bf16")
     ap.add_argument("--log-every", type=int, default=100)
     ap.add_argument("--out", default="")
+    ap.add_argument("--shipped", action="store_true", help="the shipped yaml's shape: SDF 8 x 512, 8 + 16 samples per ray (bench.py --config shipped)")
     args = ap.parse_args()
+    if args.shipped:  # where the forward-only refinements differ most from the backward's function (adjoint sweep with both operands and phi' as pairs)
+        bench.__dict__.update(W_SDF=512, N_SAMPLES=8, N_IMPORTANCE=16)
     dev = torch.device("cuda:0")
     # ---- teacher: targets in fp32 ---------------------------------------------------------------------------------
     emb_t, neuconw_t, nerf_t, rdr_t = bench.build_models(dev, nw.PREC_F32, seed=100)
@@ -68,7 +71,8 @@ def main():
     rays_v, ts_v, label_v = rays_pool(8192, 777, dev)
     target_v = render_colors(rdr_t, rays_v, ts_v, label_v)
     del rdr_t, emb_t, neuconw_t, nerf_t
-    result = {"steps": args.steps, "rays": args.rays, "pool": args.pool, "lr": args.lr, "runs": {}}
+    result = {"steps": args.steps, "rays": args.rays, "pool": args.pool, "lr": args.lr, "shape": "shipped (W = 512, 8 + 16)" if args.shipped else "headline (W = 256, 64 + 64)",
+              "runs": {}}
     for name in args.precs.split(","):
         prec = {"f32": nw.PREC_F32, "f16": nw.PREC_F16, "bf16": nw.PREC_BF16, "f16_noextras": nw.PREC_F16,
                 "f32b": nw.PREC_F32}[name]  # f32b: fp32 again with ANOTHER batch order -- the run-to-run spread the others are read against

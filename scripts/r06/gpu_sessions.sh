@@ -182,5 +182,11 @@ s22() {  # whole GPU suite on the residual-stash build; shipped ten ray batches 
   done
 }
 
+s23() {  # training equivalence at the SHIPPED shape (W = 512, 8 + 16, 2048 rays per step): fp32 twice, fp16 with / without the forward-only refinements
+  for N in 1500 3000; do
+    timeout -k 10 1200 python scripts/diag/train_equivalence.py --shipped --rays 2048 --steps $N --precs f32,f32b,f16,f16_noextras --out $OUT/train_equivalence_shipped_$N.json > $OUT/train_equivalence_shipped_$N.log 2>&1; echo "train_equivalence shipped $N rc $?"; tail -4 $OUT/train_equivalence_shipped_$N.log
+  done
+}
+
 "$NAME"
 ls -la $OUT
